@@ -1,0 +1,3 @@
+/* json_utils.h -- source-compatibility forward: the whole ndlqr API lives in ndlqr.h (the
+ * reference splits it across src/json_utils.h and friends). */
+#include "ndlqr.h"

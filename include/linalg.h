@@ -1,0 +1,3 @@
+/* linalg.h -- source-compatibility forward: the whole ndlqr API lives in ndlqr.h (the
+ * reference splits it across src/linalg.h and friends). */
+#include "ndlqr.h"

@@ -1,0 +1,3 @@
+/* matrix.h -- source-compatibility forward: the whole ndlqr API lives in ndlqr.h (the
+ * reference splits it across src/matrix.h and friends). */
+#include "ndlqr.h"

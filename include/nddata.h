@@ -1,0 +1,3 @@
+/* nddata.h -- source-compatibility forward: the whole ndlqr API lives in ndlqr.h (the
+ * reference splits it across src/nddata.h and friends). */
+#include "ndlqr.h"

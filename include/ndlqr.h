@@ -1,0 +1,334 @@
+/*
+ * ndlqr.h -- public C API of the MI355X-native nested-dissection LQR solver.
+ *
+ * Drop-in boundary for the `ndlqr_*` API of bjack205/rsLQR. Every declaration below names the
+ * reference interface it replaces (file:line under /root/reference/src). Struct layouts of the
+ * caller-visible types are kept field-for-field (callers poke at them directly, e.g.
+ * `solver->soln->data`, `solver->nvars`, `solver->num_threads`, `solver->profile`).
+ * One header carries the whole API; the per-module header names of the reference
+ * (solver.h, solve.h, nested_dissection.h, ...) exist next to this file as one-line forwards.
+ *
+ * Where the work happens: everything numerical (leaf solves, separator inner products,
+ * Cholesky, triangular solves, Schur updates, the dense Matrix* helpers) runs on the GPU
+ * through the C-ABI shim declared in ndlqr_hip.h. There is no CPU fallback: with no HIP
+ * device these entry points return NDLQR_ERR_NO_DEVICE (-2) and print to stderr.
+ */
+#ifndef NDLQR_H_
+#define NDLQR_H_
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDLQR_OK 0
+#define NDLQR_ERR_INVALID (-1)   /* reference convention: -1 on NULL / bad argument */
+#define NDLQR_ERR_NO_DEVICE (-2) /* additive: no usable HIP device / HIP runtime error */
+#define NDLQR_ERR_NOT_SPD (-3)   /* additive: a Cholesky pivot was <= 0 on the device */
+
+/* ------------------------------------------------------------------ matrix.h:71-75 */
+typedef struct {
+  int rows;
+  int cols;
+  double* data; /* column-major */
+} Matrix;
+
+Matrix NewMatrix(int rows, int cols);                       /* matrix.h:84 */
+int MatrixSetConst(Matrix* mat, double val);                /* matrix.h:93 */
+int FreeMatrix(Matrix* mat);                                /* matrix.h:104 */
+int MatrixNumElements(const Matrix* mat);                   /* matrix.h:113 */
+int MatrixGetLinearIndex(const Matrix* mat, int row, int col);
+double* MatrixGetElement(const Matrix* mat, int row, int col);
+double* MatrixGetElementTranspose(const Matrix* mat, int row, int col, bool istranposed);
+int MatrixSetElement(Matrix* mat, int row, int col, double val);
+int MatrixCopy(Matrix* dest, Matrix* src);
+int MatrixCopyTranspose(Matrix* dest, Matrix* src);
+int MatrixScaleByConst(Matrix* mat, double alpha);
+double MatrixNormedDifference(Matrix* A, Matrix* B);
+int MatrixFlatten(Matrix* mat);
+int MatrixFlattenToRow(Matrix* mat);
+int PrintMatrix(const Matrix* mat);
+int PrintRowVector(const Matrix* mat);
+
+/* ------------------------------------------------------------------ linalg.h:53-153 */
+typedef struct {
+  char uplo;    /* 'L' */
+  int success;  /* 0 = factorisation succeeded */
+  char lib;     /* 'H' = HIP device backend (reference: 'B','E','I') */
+  void* fact;   /* unused (Eigen-only in the reference) */
+  int is_freed;
+} CholeskyInfo;
+
+enum MatrixLinearAlgebraLibrary { libBLAS = 0, libMKL = 1, libEigen = 2, libInternal = 3, libHIP = 4 };
+
+CholeskyInfo DefaultCholeskyInfo(void);
+void FreeFactorization(CholeskyInfo* cholinfo);
+/* Dense helpers (linalg.h:83-153). Device-backed: operands are staged to HBM, the kernel of
+ * ndlqr_hip.h runs, results are copied back. Meant for tests and small glue, not hot loops. */
+int MatrixAddition(Matrix* A, Matrix* B, double alpha);
+int MatrixCholeskyFactorize(Matrix* mat);
+int MatrixCholeskyFactorizeWithInfo(Matrix* mat, CholeskyInfo* cholinfo);
+int MatrixCholeskySolve(Matrix* A, Matrix* b);
+int MatrixCholeskySolveWithInfo(Matrix* A, Matrix* b, CholeskyInfo* cholinfo);
+void MatrixMultiply(Matrix* A, Matrix* B, Matrix* C, bool tA, bool tB, double alpha, double beta);
+void MatrixSymmetricMultiply(Matrix* Asym, Matrix* B, Matrix* C, double alpha, double beta);
+void MatrixCopyDiagonal(Matrix* dest, Matrix* src);
+enum MatrixLinearAlgebraLibrary MatrixGetLinearAlgebraLibrary(void);
+void MatrixPrintLinearAlgebraLibrary(void);
+
+/* ------------------------------------------------------------------ utils.h / linalg_utils.h */
+bool IsPowerOfTwo(int x);
+static inline int PowerOfTwo(int x) { return 1 << x; }
+int LogOfTwo(int x);
+int ReadFile(const char* filename, char** out, int* len);
+void MatrixLinAlgTimeStart(void);
+void MatrixLinAlgTimeStop(void);
+void MatrixLinAlgTimeReset(void);
+double MatrixGetLinAlgTimeMilliseconds(void);
+
+/* ------------------------------------------------------------------ lqr_data.h:54-132 */
+/* One knot point: 0.5 x'Qx + q'x + 0.5 u'Ru + r'u + c ;  x+ = Ax + Bu + d.
+ * Q and R are DIAGONALS (n and m entries). A (n x n), B (n x m) column-major.
+ * Q is the base pointer of one allocation [Q R q r c A B d] (lqr_data.c:24-49). */
+typedef struct {
+  int nstates;
+  int ninputs;
+  double* Q;
+  double* R;
+  double* q;
+  double* r;
+  double* c;
+  double* A;
+  double* B;
+  double* d;
+} LQRData;
+
+int ndlqr_InitializeLQRData(LQRData* lqrdata, double* Q, double* R, double* q, double* r,
+                            double c, double* A, double* B, double* d);
+LQRData* ndlqr_NewLQRData(int nstates, int ninputs);
+int ndlqr_FreeLQRData(LQRData* lqrdata);
+int ndlqr_CopyLQRData(LQRData* dest, LQRData* src);
+Matrix ndlqr_GetA(LQRData* lqrdata);
+Matrix ndlqr_GetB(LQRData* lqrdata);
+Matrix ndlqr_Getd(LQRData* lqrdata);
+Matrix ndlqr_GetQ(LQRData* lqrdata);
+Matrix ndlqr_GetR(LQRData* lqrdata);
+Matrix ndlqr_Getq(LQRData* lqrdata);
+Matrix ndlqr_Getr(LQRData* lqrdata);
+void ndlqr_PrintLQRData(LQRData* lqrdata);
+
+/* ------------------------------------------------------------------ lqr_problem.h:31-68 */
+typedef struct {
+  int nhorizon;
+  double* x0;
+  LQRData** lqrdata;
+} LQRProblem;
+
+int ndlqr_InitializeLQRProblem(LQRProblem* lqrproblem, double* x0, LQRData** lqrdata);
+LQRProblem* ndlqr_NewLQRProblem(int nstates, int ninputs, int nhorizon);
+int ndlqr_FreeLQRProblem(LQRProblem* lqrprob);
+
+/* ------------------------------------------------------------------ json_utils.h:46-76 */
+/* Own parser (cJSON is not a dependency). 2-D arrays are arrays of columns; "index" is 1-based. */
+LQRData* ndlqr_ReadLQRDataJSONFile(const char* filename);
+LQRProblem* ndlqr_ReadLQRProblemJSONFile(const char* filename);
+Matrix ReadMatrixJSONFile(const char* filename, const char* name);
+
+/* ------------------------------------------------------------------ binary_tree.h:21-69 */
+typedef struct {
+  int start; /* inclusive */
+  int stop;  /* inclusive for left/right_inds, as the reference fills them */
+} UnitRange;
+
+typedef struct BinaryNode_s BinaryNode;
+struct BinaryNode_s {
+  int idx;
+  int level;
+  int levelidx;
+  UnitRange left_inds;
+  UnitRange right_inds;
+  BinaryNode* parent;
+  BinaryNode* left_child;
+  BinaryNode* right_child;
+};
+
+typedef struct {
+  BinaryNode* root;
+  BinaryNode* node_list;
+  int num_elements;
+  int depth;
+} OrderedBinaryTree;
+
+OrderedBinaryTree ndlqr_BuildTree(int nhorizon);
+int ndlqr_FreeTree(OrderedBinaryTree* tree);
+int ndlqr_GetIndexFromLeaf(const OrderedBinaryTree* tree, int leaf, int level);
+int ndlqr_GetIndexLevel(const OrderedBinaryTree* tree, int index);
+int ndlqr_GetIndexAtLevel(const OrderedBinaryTree* tree, int index, int level);
+
+/* ------------------------------------------------------------------ nddata.h:40-145 */
+typedef struct {
+  Matrix lambda; /* (n, w) */
+  Matrix state;  /* (n, w) */
+  Matrix input;  /* (m, w) */
+} NdFactor;
+
+typedef struct {
+  int nstates;
+  int ninputs;
+  int nsegments; /* nhorizon - 1 */
+  int depth;
+  int width;
+  double* data;      /* host mirror, reference layout: block (k,level) at (k + N*level)*(2n+m)*w */
+  NdFactor* factors;
+} NdData;
+
+Matrix ndlqr_GetLambdaFactor(NdFactor* factor);
+Matrix ndlqr_GetStateFactor(NdFactor* factor);
+Matrix ndlqr_GetInputFactor(NdFactor* factor);
+NdData* ndlqr_NewNdData(int nstates, int ninputs, int nhorizon, int width);
+int ndlqr_FreeNdData(NdData* nddata);
+int ndlqr_GetNdFactor(NdData* nddata, int index, int level, NdFactor** factor);
+void ndlqr_ResetNdData(NdData* nddata);
+
+/* ------------------------------------------------------------------ cholesky_factors.h:30-92 */
+typedef struct {
+  int depth;
+  int nhorizon;
+  CholeskyInfo* cholinfo;
+  int numfacts;
+} NdLqrCholeskyFactors;
+
+NdLqrCholeskyFactors* ndlqr_NewCholeskyFactors(int depth, int nhorizon);
+int ndlqr_FreeCholeskyFactors(NdLqrCholeskyFactors* cholfacts);
+int ndlqr_GetQFactorizon(NdLqrCholeskyFactors* cholfacts, int index, CholeskyInfo** cholfact);
+int ndlqr_GetRFactorizon(NdLqrCholeskyFactors* cholfacts, int index, CholeskyInfo** cholfact);
+int ndlqr_GetSFactorization(NdLqrCholeskyFactors* cholfacts, int leaf, int level,
+                            CholeskyInfo** cholfact);
+
+/* ------------------------------------------------------------------ solver.h:31-226 */
+typedef struct {
+  double t_total_ms;
+  double t_leaves_ms;
+  double t_products_ms;
+  double t_cholesky_ms;
+  double t_cholsolve_ms;
+  double t_shur_ms;
+  int num_threads;
+} NdLqrProfile;
+
+NdLqrProfile ndlqr_NewNdLqrProfile(void);
+void ndlqr_ResetProfile(NdLqrProfile* prof);
+void ndlqr_CopyProfile(NdLqrProfile* dest, NdLqrProfile* src);
+void ndlqr_PrintProfile(NdLqrProfile* profile);
+void ndlqr_CompareProfile(NdLqrProfile* base, NdLqrProfile* prof);
+
+typedef struct {
+  int nstates;
+  int ninputs;
+  int nhorizon;
+  int depth;
+  int nvars;
+  OrderedBinaryTree tree;
+  Matrix* diagonals; /* (nhorizon, 2): dense Q_k, R_k host mirrors */
+  NdData* data;      /* host mirror of the KKT coupling blocks */
+  NdData* fact;      /* host mirror of the factorisation (filled by ndlqr_SyncFactorsToHost) */
+  NdData* soln;      /* rhs in, solution out (always synced by ndlqr_Solve) */
+  NdLqrCholeskyFactors* cholfacts;
+  double solve_time_ms;
+  double linalg_time_ms;
+  NdLqrProfile profile;
+  int num_threads;   /* accepted and reported; irrelevant on the device */
+  /* ---- appended (not in the reference) ---- */
+  void* device_ctx;  /* opaque: batch-of-1 device solver */
+} NdLqrSolver;
+
+NdLqrSolver* ndlqr_NewNdLqrSolver(int nstates, int ninputs, int nhorizon);
+int ndlqr_FreeNdLqrSolver(NdLqrSolver* solver);
+int ndlqr_InitializeWithLQRProblem(const LQRProblem* lqrprob, NdLqrSolver* solver);
+void ndlqr_ResetSolver(NdLqrSolver* solver);
+void ndlqr_PrintSolveSummary(NdLqrSolver* solver);
+int ndlqr_GetNumVars(NdLqrSolver* solver);
+int ndlqr_SetNumThreads(NdLqrSolver* solver, int num_threads);
+int ndlqr_GetNumThreads(NdLqrSolver* solver);
+int ndlqr_PrintSolveProfile(NdLqrSolver* solver);
+NdLqrProfile ndlqr_GetProfile(NdLqrSolver* solver);
+
+/* ------------------------------------------------------------------ solve.h:37-72 */
+/* Factor + substitute on the device. Returns 0; additionally NDLQR_ERR_NO_DEVICE /
+ * NDLQR_ERR_NOT_SPD (the reference always returns 0, solve.c:189). */
+int ndlqr_Solve(NdLqrSolver* solver);
+Matrix ndlqr_GetSolution(NdLqrSolver* solver);
+int ndlqr_CopySolution(NdLqrSolver* solver, double* soln);
+/* additive: copy the device factorisation into solver->fact->data (reference layout). */
+int ndlqr_SyncFactorsToHost(NdLqrSolver* solver);
+
+/* ------------------------------------------------------------------ nested_dissection.h:39-147 */
+/* Stage functions on the host mirrors; each runs its dense math through the device-backed
+ * Matrix* helpers above (tests / debugging; the hot path is ndlqr_Solve / ndlqr_SolveBatch). */
+int ndlqr_SolveLeaf(NdLqrSolver* solver, int index);
+int ndlqr_SolveLeaves(NdLqrSolver* solver);
+int ndlqr_FactorInnerProduct(NdData* data, NdData* fact, int index, int data_level,
+                             int fact_level);
+int ndlqr_SolveCholeskyFactor(NdData* fact, CholeskyInfo* cholinfo, int index, int level,
+                              int upper_level);
+bool ndlqr_ShouldCalcLambda(OrderedBinaryTree* tree, int index, int i);
+int ndlqr_UpdateShurFactor(NdData* fact, NdData* soln, int index, int i, int level,
+                           int upper_level, bool calc_lambda);
+int ndlqr_ComputeShurCompliment(NdLqrSolver* solver, int index, int level, int upper_level);
+
+/* ================================================================== additive: batch API */
+/*
+ * A batch of independent LQR problems of identical (nstates, ninputs, nhorizon) solved in one
+ * launch sequence on one GPU (SURVEY.md 8b "New, additive"). ndlqr_Solve == batch of 1.
+ *
+ * Flat host layout accepted by ndlqr_InitializeBatchFlat, problem p at offset p*stride:
+ *   A [batch][N][n*n] column-major, B [batch][N][n*m] column-major,
+ *   Q,q,d [batch][N][n], R,r [batch][N][m], x0 [batch][n]
+ * (every knot carries every field, like LQRData; A,B,R,r,d of the last knot are unused).
+ */
+typedef struct NdLqrBatchSolver NdLqrBatchSolver;
+
+#define NDLQR_FLAG_STRICT_FP 1u   /* separate mul/add (no FMA): bit-reproduces the reference's
+                                     default build; slower. Default: fused multiply-add. */
+#define NDLQR_FLAG_GENERIC 2u     /* force the runtime-sized kernels even when a size-specialised
+                                     variant exists (cross-check) */
+#define NDLQR_FLAG_PROFILE 4u     /* bracket every kernel with HIP events */
+
+NdLqrBatchSolver* ndlqr_NewBatchSolver(int nstates, int ninputs, int nhorizon, int batch,
+                                       int device);
+int ndlqr_FreeBatchSolver(NdLqrBatchSolver* bs);
+int ndlqr_BatchSetFlags(NdLqrBatchSolver* bs, unsigned flags);
+unsigned ndlqr_BatchGetFlags(const NdLqrBatchSolver* bs);
+int ndlqr_InitializeBatch(NdLqrBatchSolver* bs, const LQRProblem* const* probs, int count);
+int ndlqr_InitializeBatchFlat(NdLqrBatchSolver* bs, const double* A, const double* B,
+                              const double* Q, const double* R, const double* q,
+                              const double* r, const double* d, const double* x0);
+/* Seeded synthetic problems, problem p seeded with seed0 + p; generated on the
+ * host, packed and uploaded. */
+int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0);
+int ndlqr_SolveBatch(NdLqrBatchSolver* bs);      /* launch + wait */
+int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs); /* enqueue on the solver's stream */
+int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
+int ndlqr_BatchNumVars(const NdLqrBatchSolver* bs);
+int ndlqr_BatchSize(const NdLqrBatchSolver* bs);
+int ndlqr_CopyBatchSolution(NdLqrBatchSolver* bs, int p, double* soln);    /* nvars doubles */
+int ndlqr_CopyBatchSolutions(NdLqrBatchSolver* bs, double* soln);          /* batch*nvars */
+int ndlqr_CopyBatchFactors(NdLqrBatchSolver* bs, int p, double* fact);     /* reference layout */
+int ndlqr_BatchCholeskyFailures(NdLqrBatchSolver* bs);
+double ndlqr_BatchSolveTimeMs(const NdLqrBatchSolver* bs); /* HIP-event time of last solve */
+void* ndlqr_BatchDeviceContext(NdLqrBatchSolver* bs);      /* NdlqrHipCtx* (ndlqr_hip.h) */
+
+/* Seeded synthetic problem generator (host, bit-reproducible). */
+int ndlqr_GenerateSyntheticFlat(int nstates, int ninputs, int nhorizon, uint64_t seed, double* A,
+                                double* B, double* Q, double* R, double* q, double* r, double* d,
+                                double* x0);
+LQRProblem* ndlqr_NewSyntheticLQRProblem(int nstates, int ninputs, int nhorizon, uint64_t seed);
+
+const char* ndlqr_Version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDLQR_H_ */

@@ -1,0 +1,84 @@
+/*
+ * ndlqr_hip.h -- thin C-ABI shim between the plain-C host library and the HIP kernels.
+ *
+ * Plain pointers and sizes only. This is the device boundary that SURVEY.md (section 1) inserts
+ * between the reference's L2 driver (src/solve.c) and its L1/L0 numerics
+ * (src/nested_dissection.c, src/linalg_custom.c): everything behind these calls runs on
+ * gfx950. Implemented in rslqr_amd/csrc/ndlqr_hip.hip.
+ *
+ * Device data model (all fp64):
+ *   inputs  AB  [batch][N][n][n+m]   row i of knot k = [A_k(i,:) | B_k(i,:)]   (A,B row-major)
+ *           QR  [batch][N][n+m]      diag(Q_k) then diag(R_k)
+ *           rhs [batch][N][2n+m]     initial right-hand side, already negated like
+ *                                    src/solver.c:188-190: knot k = [-(x0 | d_{k-1}); -q_k; -r_k]
+ *                                    (kept untouched by the solve, so solves can be repeated)
+ *   state   F   [batch][K][N][2n+m][n]  factor block (level p, knot k), ROW-major; rows
+ *                                       0..n-1 lambda, n..2n-1 state, 2n..2n+m-1 input.
+ *                                       (reference: column-major sub-blocks, src/nddata.c:40-53)
+ *           z   [batch][N][2n+m]     rhs in / solution out, same order as the reference
+ *           info[batch]              count of non-positive Cholesky pivots
+ */
+#ifndef NDLQR_HIP_H_
+#define NDLQR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct NdlqrHipCtx NdlqrHipCtx;
+
+int ndlqr_hip_device_count(void);
+const char* ndlqr_hip_last_error(void);
+
+/* replaces the allocation half of ndlqr_NewNdLqrSolver (src/solver.c:61-96) for a batch */
+NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch, int device);
+void ndlqr_hip_destroy(NdlqrHipCtx* ctx);
+int ndlqr_hip_set_flags(NdlqrHipCtx* ctx, unsigned flags); /* NDLQR_FLAG_* of ndlqr.h */
+unsigned ndlqr_hip_get_flags(const NdlqrHipCtx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int ndlqr_hip_set_stream(NdlqrHipCtx* ctx, void* hip_stream);
+void* ndlqr_hip_get_stream(NdlqrHipCtx* ctx);
+
+/* H2D of packed inputs for problems [p0, p0+count) (host layout = device layout above).
+ * Replaces the data movement of ndlqr_InitializeWithLQRProblem (src/solver.c:122-194); the
+ * zero-padded KKT `data` array is never materialised (kernels read A,B,Q,R and the rhs directly). */
+int ndlqr_hip_upload_inputs(NdlqrHipCtx* ctx, int p0, int count, const double* AB,
+                            const double* QR, const double* rhs);
+/* Device pointers for zero-copy producers (order: AB, QR, rhs, F, z). */
+int ndlqr_hip_device_pointers(NdlqrHipCtx* ctx, void** out5);
+
+/* ndlqr_Solve (src/solve.c:38-190) for the whole batch: leaf kernel + one kernel per tree level
+ * (inner products, Cholesky, triangular solves, Schur updates, rhs sweep fused). Async on the
+ * context's stream; HIP events bracket the sequence. */
+int ndlqr_hip_solve_async(NdlqrHipCtx* ctx);
+int ndlqr_hip_synchronize(NdlqrHipCtx* ctx);
+double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
+
+/* D2H. soln: count*nvars doubles, nvars = (2n+m)N - m (src/solve.c:192-201).
+ * fact: one problem, converted to the reference's NdData layout, N*K*(2n+m)*n doubles. */
+int ndlqr_hip_download_solutions(NdlqrHipCtx* ctx, int p0, int count, double* soln);
+int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* ctx, int p, double* z_full); /* N*(2n+m) */
+int ndlqr_hip_download_factors(NdlqrHipCtx* ctx, int p, double* fact);
+int ndlqr_hip_cholesky_failures(NdlqrHipCtx* ctx);
+
+/* Per-kernel profile (NDLQR_FLAG_PROFILE): HIP-event durations accumulated since the last
+ * reset, one slot per kernel kind. Returns number of slots / fills name, total ms, launches. */
+int ndlqr_hip_profile_slots(NdlqrHipCtx* ctx);
+int ndlqr_hip_profile_get(NdlqrHipCtx* ctx, int slot, char* name, int name_cap, double* total_ms,
+                          int* launches);
+int ndlqr_hip_profile_reset(NdlqrHipCtx* ctx);
+
+/* Dense helpers behind Matrix* of ndlqr.h (src/linalg.c:55-190 -> src/linalg_custom.c).
+ * Host pointers in, host pointers out; column-major. Return 0, or -1 for a failed Cholesky. */
+int ndlqr_hip_gemm(int tA, int tB, int m, int n, int k, double alpha, const double* A, int lda,
+                   const double* B, int ldb, double beta, double* C, int ldc);
+int ndlqr_hip_potrf_lower(int n, double* A, int lda);
+int ndlqr_hip_potrs_lower(int n, int nrhs, const double* L, int ldl, double* B, int ldb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDLQR_HIP_H_ */

@@ -1,0 +1,3 @@
+/* utils.h -- source-compatibility forward: the whole ndlqr API lives in ndlqr.h (the
+ * reference splits it across src/utils.h and friends). */
+#include "ndlqr.h"

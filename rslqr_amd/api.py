@@ -1,0 +1,353 @@
+"""ctypes mirror of include/ndlqr.h and include/ndlqr_hip.h.
+
+Function names, argument order and return conventions are those of the C API (and therefore of
+the reference's src/*.h); nothing numerical happens in Python. If the shared library is missing
+it is built in-tree with hipcc (rslqr_amd.build); if that fails the import fails loudly -- there
+is no Python or CPU fallback for the solver.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from . import build as _build
+
+FLAG_STRICT_FP = 1
+FLAG_GENERIC = 2
+FLAG_PROFILE = 4
+
+ERR_INVALID = -1
+ERR_NO_DEVICE = -2
+ERR_NOT_SPD = -3
+
+dp = C.POINTER(C.c_double)
+
+
+class Matrix(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("data", dp)]
+
+    def numpy(self):
+        """Copy out as a (rows, cols) array (storage is column-major)."""
+        flat = np.ctypeslib.as_array(self.data, (self.rows * self.cols,))
+        return flat.reshape(self.cols, self.rows).T.copy()
+
+
+class CholeskyInfo(C.Structure):
+    _fields_ = [("uplo", C.c_char), ("success", C.c_int), ("lib", C.c_char), ("fact", C.c_void_p),
+                ("is_freed", C.c_int)]
+
+
+class LQRData(C.Structure):
+    _fields_ = [("nstates", C.c_int), ("ninputs", C.c_int), ("Q", dp), ("R", dp), ("q", dp),
+                ("r", dp), ("c", dp), ("A", dp), ("B", dp), ("d", dp)]
+
+
+class LQRProblem(C.Structure):
+    _fields_ = [("nhorizon", C.c_int), ("x0", dp), ("lqrdata", C.POINTER(C.POINTER(LQRData)))]
+
+
+class UnitRange(C.Structure):
+    _fields_ = [("start", C.c_int), ("stop", C.c_int)]
+
+
+class BinaryNode(C.Structure):
+    pass
+
+
+BinaryNode._fields_ = [("idx", C.c_int), ("level", C.c_int), ("levelidx", C.c_int),
+                       ("left_inds", UnitRange), ("right_inds", UnitRange),
+                       ("parent", C.POINTER(BinaryNode)), ("left_child", C.POINTER(BinaryNode)),
+                       ("right_child", C.POINTER(BinaryNode))]
+
+
+class OrderedBinaryTree(C.Structure):
+    _fields_ = [("root", C.POINTER(BinaryNode)), ("node_list", C.POINTER(BinaryNode)),
+                ("num_elements", C.c_int), ("depth", C.c_int)]
+
+
+class NdFactor(C.Structure):
+    _fields_ = [("lambda_", Matrix), ("state", Matrix), ("input", Matrix)]
+
+
+class NdData(C.Structure):
+    _fields_ = [("nstates", C.c_int), ("ninputs", C.c_int), ("nsegments", C.c_int),
+                ("depth", C.c_int), ("width", C.c_int), ("data", dp),
+                ("factors", C.POINTER(NdFactor))]
+
+    def numpy(self):
+        """View of the whole slab (no copy)."""
+        count = (self.nsegments + 1) * self.depth * (2 * self.nstates + self.ninputs) * self.width
+        return np.ctypeslib.as_array(self.data, (count,))
+
+
+class NdLqrCholeskyFactors(C.Structure):
+    _fields_ = [("depth", C.c_int), ("nhorizon", C.c_int), ("cholinfo", C.POINTER(CholeskyInfo)),
+                ("numfacts", C.c_int)]
+
+
+class NdLqrProfile(C.Structure):
+    _fields_ = [("t_total_ms", C.c_double), ("t_leaves_ms", C.c_double),
+                ("t_products_ms", C.c_double), ("t_cholesky_ms", C.c_double),
+                ("t_cholsolve_ms", C.c_double), ("t_shur_ms", C.c_double),
+                ("num_threads", C.c_int)]
+
+
+class NdLqrSolver(C.Structure):
+    _fields_ = [("nstates", C.c_int), ("ninputs", C.c_int), ("nhorizon", C.c_int),
+                ("depth", C.c_int), ("nvars", C.c_int), ("tree", OrderedBinaryTree),
+                ("diagonals", C.POINTER(Matrix)), ("data", C.POINTER(NdData)),
+                ("fact", C.POINTER(NdData)), ("soln", C.POINTER(NdData)),
+                ("cholfacts", C.POINTER(NdLqrCholeskyFactors)), ("solve_time_ms", C.c_double),
+                ("linalg_time_ms", C.c_double), ("profile", NdLqrProfile),
+                ("num_threads", C.c_int), ("device_ctx", C.c_void_p)]
+
+
+_LIB = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def exported_symbols():
+    """Every function name declared in include/ndlqr.h and include/ndlqr_hip.h."""
+    names = []
+    for hdr in ("ndlqr.h", "ndlqr_hip.h"):
+        text = open(os.path.join(_build.INCLUDE, hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"static inline[^{]*\{[^}]*\}", "", text)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text):
+            names.append(m.group(1))
+    return sorted(set(names))
+
+
+def lib():
+    """Load (building if needed) librslqr_amd.so and declare the prototypes used from Python."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_build.LIB):
+        _build.build()
+    L = C.CDLL(_build.LIB)
+    vp, ci, cd, cu64 = C.c_void_p, C.c_int, C.c_double, C.c_uint64
+    sp = C.POINTER(NdLqrSolver)
+    pp = C.POINTER(LQRProblem)
+    ndp = C.POINTER(NdData)
+    mp = C.POINTER(Matrix)
+
+    def proto(name, restype, *argtypes):
+        fn = getattr(L, name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    proto("ndlqr_Version", C.c_char_p)
+    proto("ndlqr_hip_device_count", ci)
+    proto("ndlqr_hip_last_error", C.c_char_p)
+    # problem containers
+    proto("ndlqr_NewLQRData", C.POINTER(LQRData), ci, ci)
+    proto("ndlqr_FreeLQRData", ci, C.POINTER(LQRData))
+    proto("ndlqr_InitializeLQRData", ci, C.POINTER(LQRData), dp, dp, dp, dp, cd, dp, dp, dp)
+    proto("ndlqr_CopyLQRData", ci, C.POINTER(LQRData), C.POINTER(LQRData))
+    proto("ndlqr_NewLQRProblem", pp, ci, ci, ci)
+    proto("ndlqr_InitializeLQRProblem", ci, pp, dp, C.POINTER(C.POINTER(LQRData)))
+    proto("ndlqr_FreeLQRProblem", ci, pp)
+    proto("ndlqr_ReadLQRProblemJSONFile", pp, C.c_char_p)
+    proto("ndlqr_ReadLQRDataJSONFile", C.POINTER(LQRData), C.c_char_p)
+    proto("ReadMatrixJSONFile", Matrix, C.c_char_p, C.c_char_p)
+    proto("FreeMatrix", ci, mp)
+    proto("ReadFile", ci, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(ci))
+    proto("ndlqr_NewSyntheticLQRProblem", pp, ci, ci, ci, cu64)
+    proto("ndlqr_GenerateSyntheticFlat", ci, ci, ci, ci, cu64, dp, dp, dp, dp, dp, dp, dp, dp)
+    # tree / storage
+    proto("ndlqr_BuildTree", OrderedBinaryTree, ci)
+    proto("ndlqr_FreeTree", ci, C.POINTER(OrderedBinaryTree))
+    proto("ndlqr_GetIndexFromLeaf", ci, C.POINTER(OrderedBinaryTree), ci, ci)
+    proto("ndlqr_GetIndexLevel", ci, C.POINTER(OrderedBinaryTree), ci)
+    proto("ndlqr_GetIndexAtLevel", ci, C.POINTER(OrderedBinaryTree), ci, ci)
+    proto("ndlqr_NewNdData", ndp, ci, ci, ci, ci)
+    proto("ndlqr_FreeNdData", ci, ndp)
+    proto("ndlqr_ResetNdData", None, ndp)
+    proto("ndlqr_GetNdFactor", ci, ndp, ci, ci, C.POINTER(C.POINTER(NdFactor)))
+    proto("ndlqr_NewCholeskyFactors", C.POINTER(NdLqrCholeskyFactors), ci, ci)
+    proto("ndlqr_FreeCholeskyFactors", ci, C.POINTER(NdLqrCholeskyFactors))
+    proto("ndlqr_GetSFactorization", ci, C.POINTER(NdLqrCholeskyFactors), ci, ci,
+          C.POINTER(C.POINTER(CholeskyInfo)))
+    # solver
+    proto("ndlqr_NewNdLqrSolver", sp, ci, ci, ci)
+    proto("ndlqr_FreeNdLqrSolver", ci, sp)
+    proto("ndlqr_InitializeWithLQRProblem", ci, pp, sp)
+    proto("ndlqr_ResetSolver", None, sp)
+    proto("ndlqr_GetNumVars", ci, sp)
+    proto("ndlqr_SetNumThreads", ci, sp, ci)
+    proto("ndlqr_GetNumThreads", ci, sp)
+    proto("ndlqr_PrintSolveSummary", None, sp)
+    proto("ndlqr_PrintSolveProfile", ci, sp)
+    proto("ndlqr_GetProfile", NdLqrProfile, sp)
+    proto("ndlqr_Solve", ci, sp)
+    proto("ndlqr_GetSolution", Matrix, sp)
+    proto("ndlqr_CopySolution", ci, sp, dp)
+    proto("ndlqr_SyncFactorsToHost", ci, sp)
+    # stage functions
+    proto("ndlqr_SolveLeaf", ci, sp, ci)
+    proto("ndlqr_SolveLeaves", ci, sp)
+    proto("ndlqr_FactorInnerProduct", ci, ndp, ndp, ci, ci, ci)
+    proto("ndlqr_SolveCholeskyFactor", ci, ndp, C.POINTER(CholeskyInfo), ci, ci, ci)
+    proto("ndlqr_UpdateShurFactor", ci, ndp, ndp, ci, ci, ci, ci, C.c_bool)
+    proto("ndlqr_ShouldCalcLambda", C.c_bool, C.POINTER(OrderedBinaryTree), ci, ci)
+    proto("ndlqr_ComputeShurCompliment", ci, sp, ci, ci, ci)
+    # dense helpers
+    proto("MatrixMultiply", None, mp, mp, mp, C.c_bool, C.c_bool, cd, cd)
+    proto("MatrixCholeskyFactorize", ci, mp)
+    proto("MatrixCholeskySolve", ci, mp, mp)
+    proto("MatrixSymmetricMultiply", None, mp, mp, mp, cd, cd)
+    proto("MatrixAddition", ci, mp, mp, cd)
+    # batch
+    proto("ndlqr_NewBatchSolver", vp, ci, ci, ci, ci, ci)
+    proto("ndlqr_FreeBatchSolver", ci, vp)
+    proto("ndlqr_BatchSetFlags", ci, vp, C.c_uint)
+    proto("ndlqr_BatchGetFlags", C.c_uint, vp)
+    proto("ndlqr_InitializeBatch", ci, vp, C.POINTER(pp), ci)
+    proto("ndlqr_InitializeBatchFlat", ci, vp, dp, dp, dp, dp, dp, dp, dp, dp)
+    proto("ndlqr_InitializeBatchSynthetic", ci, vp, cu64)
+    proto("ndlqr_SolveBatch", ci, vp)
+    proto("ndlqr_SolveBatchAsync", ci, vp)
+    proto("ndlqr_BatchSynchronize", ci, vp)
+    proto("ndlqr_BatchNumVars", ci, vp)
+    proto("ndlqr_BatchSize", ci, vp)
+    proto("ndlqr_CopyBatchSolution", ci, vp, ci, dp)
+    proto("ndlqr_CopyBatchSolutions", ci, vp, dp)
+    proto("ndlqr_CopyBatchFactors", ci, vp, ci, dp)
+    proto("ndlqr_BatchCholeskyFailures", ci, vp)
+    proto("ndlqr_BatchSolveTimeMs", cd, vp)
+    proto("ndlqr_BatchDeviceContext", vp, vp)
+    # shim bits used by the benchmark
+    proto("ndlqr_hip_set_stream", ci, vp, vp)
+    proto("ndlqr_hip_get_stream", vp, vp)
+    proto("ndlqr_hip_profile_slots", ci, vp)
+    proto("ndlqr_hip_profile_get", ci, vp, ci, C.c_char_p, ci, dp, C.POINTER(ci))
+    proto("ndlqr_hip_profile_reset", ci, vp)
+    proto("ndlqr_hip_device_pointers", ci, vp, C.POINTER(vp))
+    proto("ndlqr_hip_gemm", ci, ci, ci, ci, ci, ci, cd, dp, ci, dp, ci, cd, dp, ci)
+    proto("ndlqr_hip_potrf_lower", ci, ci, dp, ci)
+    proto("ndlqr_hip_potrs_lower", ci, ci, ci, dp, ci, dp, ci)
+    _LIB = L
+    return L
+
+
+def device_count():
+    return lib().ndlqr_hip_device_count()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(dp)
+
+
+def generate_synthetic(n, m, N, seed):
+    """ndlqr_GenerateSyntheticFlat -> dict of numpy arrays (A [N,n*n] col-major, ...)."""
+    out = dict(A=np.zeros((N, n * n)), B=np.zeros((N, n * m)), Q=np.zeros((N, n)),
+               R=np.zeros((N, m)), q=np.zeros((N, n)), r=np.zeros((N, m)), d=np.zeros((N, n)),
+               x0=np.zeros(n))
+    err = lib().ndlqr_GenerateSyntheticFlat(n, m, N, seed, *[_ptr(out[k]) for k in
+                                                               ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    if err:
+        raise RuntimeError("ndlqr_GenerateSyntheticFlat failed: %d" % err)
+    return out
+
+
+class BatchSolver:
+    """numpy-friendly wrapper of NdLqrBatchSolver (include/ndlqr.h, batch API)."""
+
+    def __init__(self, n, m, N, batch, device=-1, flags=0):
+        self.L = lib()
+        self.n, self.m, self.N, self.batch = n, m, N, batch
+        self.h = self.L.ndlqr_NewBatchSolver(n, m, N, batch, device)
+        if not self.h:
+            raise RuntimeError("ndlqr_NewBatchSolver failed: %s" %
+                               self.L.ndlqr_hip_last_error().decode())
+        self.nvars = self.L.ndlqr_BatchNumVars(self.h)
+        if flags:
+            self.set_flags(flags)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ndlqr_FreeBatchSolver(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_flags(self, flags):
+        self.L.ndlqr_BatchSetFlags(self.h, flags)
+
+    @property
+    def ctx(self):
+        return self.L.ndlqr_BatchDeviceContext(self.h)
+
+    def initialize_flat(self, A, B, Q, R, q, r, d, x0):
+        n, m, N, bt = self.n, self.m, self.N, self.batch
+        shapes = dict(A=(bt, N, n * n), B=(bt, N, n * m), Q=(bt, N, n), R=(bt, N, m),
+                      q=(bt, N, n), r=(bt, N, m), d=(bt, N, n), x0=(bt, n))
+        arrs = []
+        for name, a in zip(("A", "B", "Q", "R", "q", "r", "d", "x0"), (A, B, Q, R, q, r, d, x0)):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.size != int(np.prod(shapes[name])):
+                raise ValueError("bad size for %s" % name)
+            arrs.append(a)
+        err = self.L.ndlqr_InitializeBatchFlat(self.h, *[_ptr(a) for a in arrs])
+        if err:
+            raise RuntimeError("ndlqr_InitializeBatchFlat failed: %d" % err)
+
+    def initialize_synthetic(self, seed0):
+        err = self.L.ndlqr_InitializeBatchSynthetic(self.h, seed0)
+        if err:
+            raise RuntimeError("ndlqr_InitializeBatchSynthetic failed: %d" % err)
+
+    def solve(self):
+        return self.L.ndlqr_SolveBatch(self.h)
+
+    def solve_async(self):
+        return self.L.ndlqr_SolveBatchAsync(self.h)
+
+    def synchronize(self):
+        return self.L.ndlqr_BatchSynchronize(self.h)
+
+    def solve_ms(self):
+        return self.L.ndlqr_BatchSolveTimeMs(self.h)
+
+    def solution(self, p):
+        out = np.zeros(self.nvars)
+        got = self.L.ndlqr_CopyBatchSolution(self.h, p, _ptr(out))
+        if got != self.nvars:
+            raise RuntimeError("ndlqr_CopyBatchSolution failed: %d" % got)
+        return out
+
+    def solutions(self):
+        out = np.zeros((self.batch, self.nvars))
+        got = self.L.ndlqr_CopyBatchSolutions(self.h, _ptr(out))
+        if got != self.nvars:
+            raise RuntimeError("ndlqr_CopyBatchSolutions failed: %d" % got)
+        return out
+
+    def factors(self, p):
+        K = int(np.log2(self.N))
+        out = np.zeros(self.N * K * (2 * self.n + self.m) * self.n)
+        err = self.L.ndlqr_CopyBatchFactors(self.h, p, _ptr(out))
+        if err:
+            raise RuntimeError("ndlqr_CopyBatchFactors failed: %d" % err)
+        return out
+
+    def cholesky_failures(self):
+        return self.L.ndlqr_BatchCholeskyFailures(self.h)
+
+    def profile(self):
+        """{kernel name: (total ms, launches)} accumulated since the last reset."""
+        out = {}
+        for slot in range(self.L.ndlqr_hip_profile_slots(self.ctx)):
+            name = C.create_string_buffer(64)
+            ms, cnt = C.c_double(0), C.c_int(0)
+            self.L.ndlqr_hip_profile_get(self.ctx, slot, name, 64, C.byref(ms), C.byref(cnt))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+    def profile_reset(self):
+        self.L.ndlqr_hip_profile_reset(self.ctx)

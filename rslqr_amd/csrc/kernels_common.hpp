@@ -1,0 +1,46 @@
+// kernels_common.hpp -- shared device-side definitions (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ndlqr {
+
+struct Dims {
+  int n, m, N, K, batch;
+  int rows;  // 2n + m  rows of a factor block / entries of an rhs block
+  int w;     // n + m    row length of the packed [A | B] input
+  int fb;    // rows * n doubles per factor block
+};
+
+// acc + a*b. Fast mode: one fused multiply-add. Strict mode: rounded product, then rounded sum --
+// the operation order of the reference's scalar loops (src/linalg_custom.c:31-41, 88-132) as
+// its default build (-std=c11, no contraction) executes them. The translation unit is compiled
+// with -ffp-contract=off, so the compiler never fuses the strict form.
+template <bool STRICT>
+__device__ __forceinline__ double mad(double a, double b, double acc) {
+  if constexpr (STRICT) {
+    return acc + a * b;
+  } else {
+    return fma(a, b, acc);
+  }
+}
+
+// number of trailing one bits = tree level of separator k (src/binary_tree.c:9-37)
+__device__ __forceinline__ int trailing_ones(int k) { return __builtin_ctz(~k); }
+
+__device__ __forceinline__ double* Fblk(double* F, const Dims& d, int b, int level, int k) {
+  return F + (((size_t)b * d.K + level) * d.N + k) * d.fb;
+}
+__device__ __forceinline__ const double* Fblk(const double* F, const Dims& d, int b, int level, int k) {
+  return F + (((size_t)b * d.K + level) * d.N + k) * d.fb;
+}
+
+// Outer columns of the level-`l` subtree starting at knot `base` (SURVEY.md A.2 restated for the
+// block-sparse structure, DESIGN.md "live columns"): a = level of the separator left of the
+// subtree, bb = level of the separator right of it; -1 when the subtree touches that end.
+__device__ __forceinline__ void outer_columns(int base, int l, int N, int& a, int& bb) {
+  const int span = 2 << l;
+  a = base > 0 ? __builtin_ctz(base) : -1;
+  bb = (base + span < N) ? __builtin_ctz(base + span) : -1;
+}
+
+}  // namespace ndlqr

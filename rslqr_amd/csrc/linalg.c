@@ -1,0 +1,95 @@
+/*
+ * linalg.c -- the reference's dense helper layer (src/linalg.c:22-232) routed to the GPU.
+ *
+ * The reference dispatches MatrixMultiply / MatrixCholesky* to one of {internal "clap", Eigen,
+ * BLAS/LAPACKE}. Here there is exactly one backend: the HIP kernels behind ndlqr_hip_gemm /
+ * _potrf_lower / _potrs_lower (host matrices are staged to HBM per call). These entry points
+ * exist so that reference-style callers and the stage functions of stages.c keep working; the
+ * solver hot path never goes through them. No CPU fallback: without a device they report
+ * NDLQR_ERR_NO_DEVICE on stderr and leave the operands untouched.
+ */
+#include <stdio.h>
+#include <time.h>
+
+#include "ndlqr.h"
+#include "ndlqr_hip.h"
+
+/* ---- global linear-algebra timer, same (non-reentrant) contract as src/linalg_utils.c ---- */
+static struct {
+  clock_t started;
+  double total_ms;
+} la_timer = {0, 0.0};
+
+void MatrixLinAlgTimeStart(void) { la_timer.started = clock(); }
+void MatrixLinAlgTimeStop(void) {
+  la_timer.total_ms += (double)(clock() - la_timer.started) * 1000.0 / (double)CLOCKS_PER_SEC;
+}
+void MatrixLinAlgTimeReset(void) { la_timer.total_ms = 0.0; }
+double MatrixGetLinAlgTimeMilliseconds(void) { return la_timer.total_ms; }
+
+enum MatrixLinearAlgebraLibrary MatrixGetLinearAlgebraLibrary(void) { return libHIP; }
+
+void MatrixPrintLinearAlgebraLibrary(void) {
+  printf("Using HIP kernels on gfx950 (%d device(s) visible)\n", ndlqr_hip_device_count());
+}
+
+int MatrixAddition(Matrix* A, Matrix* B, double alpha) {
+  if (!A || !B) return -1;
+  /* B += alpha * A  ==  gemm with the identity is overkill; it is elementwise and tiny, but
+   * arithmetic stays on the device for consistency: B = alpha * A * I(1x1 blocks) + 1 * B is
+   * expressed as a (rows*cols x 1) * (1 x 1) product. */
+  const int count = MatrixNumElements(A);
+  double one = 1.0;
+  return ndlqr_hip_gemm(0, 0, count, 1, 1, alpha, A->data, count, &one, 1, 1.0, B->data, count);
+}
+
+int MatrixCholeskyFactorize(Matrix* mat) {
+  if (!mat) return -1;
+  return ndlqr_hip_potrf_lower(mat->rows, mat->data, mat->rows);
+}
+
+int MatrixCholeskyFactorizeWithInfo(Matrix* mat, CholeskyInfo* cholinfo) {
+  const int out = MatrixCholeskyFactorize(mat);
+  if (cholinfo) {
+    cholinfo->lib = 'H';
+    cholinfo->is_freed = 1;
+    cholinfo->success = out; /* 0 on success; the reference ends up storing `out` too (linalg.c:84) */
+    cholinfo->uplo = 'L';
+  }
+  return out;
+}
+
+int MatrixCholeskySolve(Matrix* A, Matrix* b) {
+  if (!A || !b) return -1;
+  return ndlqr_hip_potrs_lower(A->rows, b->cols, A->data, A->rows, b->data, b->rows);
+}
+
+int MatrixCholeskySolveWithInfo(Matrix* A, Matrix* b, CholeskyInfo* cholinfo) {
+  (void)cholinfo;
+  return MatrixCholeskySolve(A, b);
+}
+
+void MatrixMultiply(Matrix* A, Matrix* B, Matrix* C, bool tA, bool tB, double alpha, double beta) {
+  const int m = tA ? A->cols : A->rows;
+  const int k = tA ? A->rows : A->cols;
+  const int n = tB ? B->rows : B->cols;
+  ndlqr_hip_gemm(tA, tB, m, n, k, alpha, A->data, A->rows, B->data, B->rows, beta, C->data, C->rows);
+}
+
+void MatrixSymmetricMultiply(Matrix* Asym, Matrix* B, Matrix* C, double alpha, double beta) {
+  /* The reference reads only the lower triangle (linalg_custom.c:45-75). Mirror it into a
+   * temporary full matrix on the host (pure data movement), multiply on the device. */
+  const int n = Asym->rows;
+  Matrix full = NewMatrix(n, n);
+  for (int c = 0; c < n; ++c)
+    for (int r = 0; r < n; ++r)
+      full.data[r + n * c] = (r >= c) ? Asym->data[r + n * c] : Asym->data[c + n * r];
+  MatrixMultiply(&full, B, C, false, false, alpha, beta);
+  FreeMatrix(&full);
+}
+
+void MatrixCopyDiagonal(Matrix* dest, Matrix* src) {
+  /* src is a vector of diagonal entries, dest a square matrix (linalg.c:222-232) */
+  const int n = dest->rows;
+  for (int i = 0; i < n; ++i) dest->data[i + n * i] = src->data[i];
+}

@@ -1,0 +1,427 @@
+// ndlqr_hip.hip -- gfx950 (MI355X, CDNA4) implementation of the device boundary in
+// include/ndlqr_hip.h: context/memory management, launch sequence, D2H converters and the
+// dense Matrix* helpers. Kernels live in kernels_generic.hpp (any n, m) and kernels_small.hpp
+// (size-specialised, one knot row per lane).
+//
+// Written for wave64 / gfx950 only; built with -ffp-contract=off so that every fused
+// multiply-add in the kernels is an explicit fma() (fast mode) or an explicit mul + add
+// (NDLQR_FLAG_STRICT_FP, which reproduces the reference's default CPU build bit for bit).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ndlqr.h"
+#include "ndlqr_hip.h"
+
+#include "kernels_common.hpp"
+#include "kernels_generic.hpp"
+
+// ------------------------------------------------------------------------------ errors
+
+static thread_local std::string g_last_error = "";
+
+const char* ndlqr_hip_last_error(void) { return g_last_error.c_str(); }
+
+static int fail(const char* what, hipError_t e) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+  return NDLQR_ERR_NO_DEVICE;
+}
+#define HIP_TRY(expr)                                        \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return fail(#expr, e_);            \
+  } while (0)
+
+int ndlqr_hip_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+// ------------------------------------------------------------------------------ context
+
+enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_LEVEL, SLOT_COUNT };
+static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "level"};
+
+struct PendingEvent {
+  int slot;
+  hipEvent_t start, stop;
+};
+
+struct NdlqrHipCtx {
+  ndlqr::Dims d;
+  int device;
+  unsigned flags;
+  hipStream_t stream;
+  bool own_stream;
+  double* AB;
+  double* QR;
+  double* rhs;
+  double* F;
+  double* z;
+  int* info;
+  hipEvent_t ev_start, ev_stop;
+  bool timing_pending;
+  double last_ms;
+  int last_failures;
+  // profile
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  double slot_ms[SLOT_COUNT];
+  int slot_launches[SLOT_COUNT];
+};
+
+static size_t bytes_AB(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.n * d.w; }
+static size_t bytes_QR(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.w; }
+static size_t bytes_z(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.rows; }
+static size_t bytes_F(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.K * d.N * d.fb; }
+
+NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch, int device) {
+  if (nstates <= 0 || ninputs <= 0 || batch <= 0 || nhorizon < 2 || (nhorizon & (nhorizon - 1))) {
+    g_last_error = "invalid dimensions";
+    return nullptr;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_last_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return nullptr;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= count) {
+    g_last_error = "device index out of range";
+    return nullptr;
+  }
+  if ((e = hipSetDevice(device)) != hipSuccess) { fail("hipSetDevice", e); return nullptr; }
+
+  NdlqrHipCtx* c = new NdlqrHipCtx();
+  ndlqr::Dims& d = c->d;
+  d.n = nstates; d.m = ninputs; d.N = nhorizon; d.batch = batch;
+  d.K = 0; while ((1 << d.K) < nhorizon) ++d.K;
+  d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
+  c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
+  c->AB = c->QR = c->rhs = c->F = c->z = nullptr; c->info = nullptr;
+  c->timing_pending = false; c->last_ms = 0; c->last_failures = 0;
+  memset(c->slot_ms, 0, sizeof(c->slot_ms));
+  memset(c->slot_launches, 0, sizeof(c->slot_launches));
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess &&
+            hipMalloc(&c->AB, bytes_AB(d)) == hipSuccess && hipMalloc(&c->QR, bytes_QR(d)) == hipSuccess &&
+            hipMalloc(&c->rhs, bytes_z(d)) == hipSuccess && hipMalloc(&c->z, bytes_z(d)) == hipSuccess &&
+            hipMalloc(&c->F, bytes_F(d)) == hipSuccess &&
+            hipMalloc(&c->info, sizeof(int) * (size_t)batch) == hipSuccess;
+  if (ok) {
+    // Structural zeros of F are never written by the kernels; zero once so that the factor
+    // download matches the reference's calloc'ed array (src/nddata.c:34).
+    ok = hipMemsetAsync(c->F, 0, bytes_F(d), c->stream) == hipSuccess &&
+         hipMemsetAsync(c->z, 0, bytes_z(d), c->stream) == hipSuccess &&
+         hipMemsetAsync(c->info, 0, sizeof(int) * (size_t)batch, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess;
+  }
+  if (!ok) {
+    fail("device allocation", hipGetLastError());
+    ndlqr_hip_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+void ndlqr_hip_destroy(NdlqrHipCtx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+  for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
+  (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
+  (void)hipFree(c->z); (void)hipFree(c->info);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ndlqr_hip_set_flags(NdlqrHipCtx* c, unsigned flags) {
+  if (!c) return NDLQR_ERR_INVALID;
+  c->flags = flags;
+  return NDLQR_OK;
+}
+unsigned ndlqr_hip_get_flags(const NdlqrHipCtx* c) { return c ? c->flags : 0u; }
+
+int ndlqr_hip_set_stream(NdlqrHipCtx* c, void* hip_stream) {
+  if (!c) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) HIP_TRY(hipStreamDestroy(c->stream));
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return NDLQR_OK;
+}
+void* ndlqr_hip_get_stream(NdlqrHipCtx* c) { return c ? (void*)c->stream : nullptr; }
+
+int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB, const double* QR,
+                            const double* rhs) {
+  if (!c || !AB || !QR || !rhs || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t sAB = (size_t)d.N * d.n * d.w, sQR = (size_t)d.N * d.w, sz = (size_t)d.N * d.rows;
+  HIP_TRY(hipMemcpyAsync(c->AB + p0 * sAB, AB, sizeof(double) * sAB * count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->QR + p0 * sQR, QR, sizeof(double) * sQR * count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the host staging buffers are reused by the caller
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
+  if (!c || !out5) return NDLQR_ERR_INVALID;
+  out5[0] = c->AB; out5[1] = c->QR; out5[2] = c->rhs; out5[3] = c->F; out5[4] = c->z;
+  return NDLQR_OK;
+}
+
+// ------------------------------------------------------------------------------ launches
+
+static hipEvent_t take_event(NdlqrHipCtx* c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t ev = c->event_pool.back();
+    c->event_pool.pop_back();
+    return ev;
+  }
+  hipEvent_t ev = nullptr;
+  (void)hipEventCreate(&ev);
+  return ev;
+}
+
+struct ScopedSlot {  // brackets one kernel launch with events when profiling is on
+  NdlqrHipCtx* c;
+  PendingEvent pe;
+  bool on;
+  ScopedSlot(NdlqrHipCtx* ctx, int slot) : c(ctx), on((ctx->flags & NDLQR_FLAG_PROFILE) != 0) {
+    if (!on) return;
+    pe.slot = slot; pe.start = take_event(c); pe.stop = take_event(c);
+    (void)hipEventRecord(pe.start, c->stream);
+  }
+  ~ScopedSlot() {
+    if (!on) return;
+    (void)hipEventRecord(pe.stop, c->stream);
+    c->pending.push_back(pe);
+  }
+};
+
+template <bool STRICT>
+static int launch_generic(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  {
+    ScopedSlot t(c, SLOT_LEAF);
+    hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
+                       c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+  }
+  const size_t lds = sizeof(double) * ((size_t)3 * d.n * d.n + d.n);
+  if (lds > 160 * 1024) {
+    g_last_error = "nstates too large for the generic separator kernel's LDS staging";
+    return NDLQR_ERR_INVALID;
+  }
+  for (int l = 0; l < d.K; ++l) {
+    const int nsub = d.N >> (l + 1);
+    {
+      ScopedSlot t(c, SLOT_SEP);
+      hipLaunchKernelGGL((ndlqr::separator_generic<STRICT>), dim3(nsub, d.batch), dim3(256), lds,
+                         c->stream, d, l, c->AB, c->F, c->z, c->info);
+    }
+    {
+      ScopedSlot t(c, SLOT_SCHUR);
+      const long work = (long)d.N * d.rows * d.n;
+      hipLaunchKernelGGL((ndlqr::schur_generic<STRICT>), dim3((unsigned)((work + 255) / 256), d.batch),
+                         dim3(256), 0, c->stream, d, l, c->F, c->z);
+    }
+  }
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
+  if (!c) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int) * (size_t)d.batch, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  const bool strict = (c->flags & NDLQR_FLAG_STRICT_FP) != 0;
+  int err = NDLQR_OK;
+  err = strict ? launch_generic<true>(c) : launch_generic<false>(c);
+  if (err) return err;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+  c->timing_pending = true;
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_synchronize(NdlqrHipCtx* c) {
+  if (!c) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->timing_pending) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+    c->last_ms = ms;
+    c->timing_pending = false;
+    std::vector<int> h(c->d.batch);
+    HIP_TRY(hipMemcpy(h.data(), c->info, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int v : h) total += v;
+    c->last_failures = total;
+  }
+  for (auto& p : c->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+      c->slot_ms[p.slot] += ms;
+      c->slot_launches[p.slot] += 1;
+    }
+    c->event_pool.push_back(p.start);
+    c->event_pool.push_back(p.stop);
+  }
+  c->pending.clear();
+  return NDLQR_OK;
+}
+
+double ndlqr_hip_last_solve_ms(NdlqrHipCtx* c) { return c ? c->last_ms : -1.0; }
+int ndlqr_hip_cholesky_failures(NdlqrHipCtx* c) { return c ? c->last_failures : NDLQR_ERR_INVALID; }
+
+int ndlqr_hip_profile_slots(NdlqrHipCtx* c) { return c ? (int)SLOT_COUNT : 0; }
+int ndlqr_hip_profile_get(NdlqrHipCtx* c, int slot, char* name, int name_cap, double* total_ms, int* launches) {
+  if (!c || slot < 0 || slot >= SLOT_COUNT) return NDLQR_ERR_INVALID;
+  if (name && name_cap > 0) { strncpy(name, kSlotNames[slot], (size_t)name_cap - 1); name[name_cap - 1] = '\0'; }
+  if (total_ms) *total_ms = c->slot_ms[slot];
+  if (launches) *launches = c->slot_launches[slot];
+  return NDLQR_OK;
+}
+int ndlqr_hip_profile_reset(NdlqrHipCtx* c) {
+  if (!c) return NDLQR_ERR_INVALID;
+  memset(c->slot_ms, 0, sizeof(c->slot_ms));
+  memset(c->slot_launches, 0, sizeof(c->slot_launches));
+  return NDLQR_OK;
+}
+
+// ------------------------------------------------------------------------------ downloads
+
+int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln) {
+  if (!c || !soln || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t nvars = (size_t)d.rows * d.N - d.m, pitch = (size_t)d.rows * d.N;
+  HIP_TRY(hipMemcpy2DAsync(soln, sizeof(double) * nvars, c->z + p0 * pitch, sizeof(double) * pitch,
+                           sizeof(double) * nvars, (size_t)count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
+  if (!c || !z_full || p < 0 || p >= c->d.batch) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t pitch = (size_t)d.rows * d.N;
+  HIP_TRY(hipMemcpyAsync(z_full, c->z + p * pitch, sizeof(double) * pitch, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_download_factors(NdlqrHipCtx* c, int p, double* fact) {
+  if (!c || !fact || p < 0 || p >= c->d.batch) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t count = (size_t)d.K * d.N * d.fb;
+  std::vector<double> tmp(count);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), c->F + p * count, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // device: [level][knot][row][col] row-major -> reference: block (k,level) at (k + N*level)*fb,
+  // sub-blocks lambda (n x n), state (n x n), input (m x n), each column-major (src/nddata.c:40-53)
+  const int n = d.n, m = d.m;
+  for (int lvl = 0; lvl < d.K; ++lvl)
+    for (int k = 0; k < d.N; ++k) {
+      const double* src = tmp.data() + ((size_t)lvl * d.N + k) * d.fb;
+      double* dst = fact + ((size_t)k + (size_t)d.N * lvl) * d.fb;
+      for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < n; ++i) dst[i + n * j] = src[i * n + j];
+        for (int i = 0; i < n; ++i) dst[n * n + i + n * j] = src[(n + i) * n + j];
+        for (int i = 0; i < m; ++i) dst[2 * n * n + i + m * j] = src[(2 * n + i) * n + j];
+      }
+    }
+  return NDLQR_OK;
+}
+
+// ------------------------------------------------------------------------------ dense helpers
+
+namespace {
+struct DevBuf {
+  double* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+static int dense_ready() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    g_last_error = "no HIP device for the dense Matrix* helpers (no CPU fallback)";
+    fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+    return NDLQR_ERR_NO_DEVICE;
+  }
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_gemm(int tA, int tB, int m, int n, int k, double alpha, const double* A, int lda,
+                   const double* B, int ldb, double beta, double* C, int ldc) {
+  if (dense_ready()) return NDLQR_ERR_NO_DEVICE;
+  const int Ac = tA ? m : k, Bc = tB ? k : n;
+  DevBuf dA, dB, dC;
+  const size_t bA = sizeof(double) * (size_t)lda * Ac, bB = sizeof(double) * (size_t)ldb * Bc,
+               bC = sizeof(double) * (size_t)ldc * n;
+  HIP_TRY(hipMalloc(&dA.p, bA)); HIP_TRY(hipMalloc(&dB.p, bB)); HIP_TRY(hipMalloc(&dC.p, bC));
+  HIP_TRY(hipMemcpy(dA.p, A, bA, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dB.p, B, bB, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dC.p, C, bC, hipMemcpyHostToDevice));
+  const int total = m * n;
+  hipLaunchKernelGGL(ndlqr::dense_gemm, dim3((total + 255) / 256), dim3(256), 0, 0, tA, tB, m, n, k,
+                     alpha, dA.p, lda, dB.p, ldb, beta, dC.p, ldc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(C, dC.p, bC, hipMemcpyDeviceToHost));
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_potrf_lower(int n, double* A, int lda) {
+  if (dense_ready()) return NDLQR_ERR_NO_DEVICE;
+  DevBuf dA;
+  int* dinfo = nullptr;
+  const size_t bA = sizeof(double) * (size_t)lda * n;
+  HIP_TRY(hipMalloc(&dA.p, bA));
+  HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
+  HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
+  HIP_TRY(hipMemcpy(dA.p, A, bA, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ndlqr::dense_potrf, dim3(1), dim3(256), 0, 0, n, dA.p, lda, dinfo);
+  int info = 0;
+  hipError_t e = hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipFree(dinfo);
+  if (e != hipSuccess) return fail("potrf", e);
+  HIP_TRY(hipMemcpy(A, dA.p, bA, hipMemcpyDeviceToHost));
+  return info ? -1 : 0;
+}
+
+int ndlqr_hip_potrs_lower(int n, int nrhs, const double* L, int ldl, double* B, int ldb) {
+  if (dense_ready()) return NDLQR_ERR_NO_DEVICE;
+  DevBuf dL, dB;
+  const size_t bL = sizeof(double) * (size_t)ldl * n, bB = sizeof(double) * (size_t)ldb * nrhs;
+  HIP_TRY(hipMalloc(&dL.p, bL)); HIP_TRY(hipMalloc(&dB.p, bB));
+  HIP_TRY(hipMemcpy(dL.p, L, bL, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dB.p, B, bB, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ndlqr::dense_potrs, dim3((nrhs + 63) / 64), dim3(64), 0, 0, n, nrhs, dL.p, ldl, dB.p, ldb);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(B, dB.p, bB, hipMemcpyDeviceToHost));
+  return NDLQR_OK;
+}

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from support import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ndlqr():
+    import rslqr_amd
+    return rslqr_amd

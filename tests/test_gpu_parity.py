@@ -1,0 +1,114 @@
+"""GPU parity: the HIP path (through the C-ABI of include/ndlqr.h) against the CPU oracle on the
+same inputs. Tolerances:
+  * NDLQR_FLAG_STRICT_FP: bit-exact (np.array_equal) solution AND factor array vs the oracle,
+    which itself is bit-identical to the reference's default build.
+  * default (fused multiply-add): relative l2 error <= 1e-9 and KKT residual <= 1e-9*max(1,|b|);
+    JSON fixtures additionally the reference's own absolute ||x - soln||_2 < 1e-6
+    (test/nested_dissection_test.c:277).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from support import GOLDEN, Problem, load_json_problem
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-9
+
+
+def synth(ndlqr, n, m, N, seed):
+    g = ndlqr.generate_synthetic(n, m, N, seed)
+    return Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+
+
+def stack(probs):
+    return [np.stack([getattr(p, k) for p in probs]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
+
+
+SHAPES = [(6, 3, 8), (12, 4, 16), (12, 4, 64), (5, 2, 32), (16, 8, 8), (3, 1, 2), (1, 1, 4), (7, 9, 16)]
+
+
+@pytest.mark.parametrize("n,m,N", SHAPES)
+@pytest.mark.parametrize("flags", ["generic", "default"])
+def test_batch_strict_is_bit_exact(ndlqr, oracle, n, m, N, flags):
+    batch = 5
+    probs = [synth(ndlqr, n, m, N, 100 + p) for p in range(batch)]
+    fl = ndlqr.FLAG_STRICT_FP | (ndlqr.FLAG_GENERIC if flags == "generic" else 0)
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=fl)
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0
+    sol = bs.solutions()
+    for p, prob in enumerate(probs):
+        z, fact, _, fails = oracle.solve(prob, 1, want_fact=True)
+        assert fails == 0
+        assert np.array_equal(sol[p], z[: prob.nvars]), "solution differs from oracle (strict)"
+        assert np.array_equal(bs.factors(p), fact), "factor array differs from oracle (strict)"
+    bs.close()
+
+
+@pytest.mark.parametrize("n,m,N", SHAPES + [(12, 4, 256), (6, 3, 512)])
+@pytest.mark.parametrize("flags", ["generic", "default"])
+def test_batch_fast_within_tolerance(ndlqr, oracle, n, m, N, flags):
+    batch = 3
+    probs = [synth(ndlqr, n, m, N, 7 + p) for p in range(batch)]
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=ndlqr.FLAG_GENERIC if flags == "generic" else 0)
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0
+    sol = bs.solutions()
+    for p, prob in enumerate(probs):
+        z, _, _, _ = oracle.solve(prob, 1)
+        ref = z[: prob.nvars]
+        rel = np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref)
+        assert rel <= REL_TOL, rel
+        res, bnorm = oracle.kkt_residual(prob, sol[p])
+        assert res <= 1e-9 * max(1.0, bnorm), (res, bnorm)
+    # a second solve on the resident inputs gives the same answer (no state leaks between solves)
+    assert bs.solve() == 0
+    assert np.array_equal(bs.solutions(), sol)
+    bs.close()
+
+
+@pytest.mark.parametrize("fname", ["lqr_prob.json", "lqr_prob_256.json"])
+def test_json_fixture_through_dropin_api(ndlqr, oracle, fname):
+    """The reference's canonical caller (examples/importexample/main.c:5-27)."""
+    L = ndlqr.lib()
+    path = os.path.join(GOLDEN, fname).encode()
+    prob = L.ndlqr_ReadLQRProblemJSONFile(path)
+    assert prob
+    n = prob.contents.lqrdata[0].contents.nstates
+    m = prob.contents.lqrdata[0].contents.ninputs
+    N = prob.contents.nhorizon
+    solver = L.ndlqr_NewNdLqrSolver(n, m, N)
+    assert solver
+    assert L.ndlqr_InitializeWithLQRProblem(prob, solver) == 0
+    L.ndlqr_FreeLQRProblem(prob)  # Initialize deep-copies (test/test_problem.c:22-25)
+    assert L.ndlqr_Solve(solver) == 0
+    nvars = L.ndlqr_GetNumVars(solver)
+    x = np.zeros(nvars)
+    assert L.ndlqr_CopySolution(solver, x.ctypes.data_as(C.POINTER(C.c_double))) == nvars
+    pyprob, soln = load_json_problem(os.path.join(GOLDEN, fname))
+    assert nvars == soln.size
+    assert np.linalg.norm(x - soln) < 1e-6  # the reference's own bar
+    z, _, _, _ = oracle.solve(pyprob, 1)
+    assert np.linalg.norm(x - z[:nvars]) / np.linalg.norm(z[:nvars]) <= REL_TOL
+    view = L.ndlqr_GetSolution(solver)
+    assert view.rows == nvars and view.cols == 1
+    assert np.array_equal(view.numpy().ravel(), x)
+    assert solver.contents.solve_time_ms > 0
+    # SolveTwice (test/nested_dissection_test.c:285-313)
+    prob = L.ndlqr_ReadLQRProblemJSONFile(path)
+    L.ndlqr_ResetNdData(solver.contents.fact)
+    assert L.ndlqr_InitializeWithLQRProblem(prob, solver) == 0
+    assert L.ndlqr_Solve(solver) == 0
+    L.ndlqr_CopySolution(solver, x.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.linalg.norm(x - soln) < 1e-6
+    # factor mirror on demand
+    assert L.ndlqr_SyncFactorsToHost(solver) == 0
+    _, fact, _, _ = oracle.solve(pyprob, 1, want_fact=True)
+    got = solver.contents.fact.contents.numpy()
+    assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
+    L.ndlqr_FreeLQRProblem(prob)
+    L.ndlqr_FreeNdLqrSolver(solver)
