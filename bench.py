@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: LQR solves/sec at (nx=12, nu=4, N=256, batch=1024 per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one ndlqr_SolveBatch (factor + substitute, the reference's ndlqr_Solve,
+src/solve.c:38-190) over the rank's batch of independent synthetic problems, inputs already
+resident in HBM. The batch axis is the sharding unit: every rank owns `--batch` problems
+(weak scaling), there is no data-path collective; torch.distributed (RCCL) is used only for
+the barriers and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- dominant kernel (the per-level kernel), algorithmic bytes of SURVEY.md 8(d)
+                  model (B) for the levels it covers / its HIP-event time, vs 8 TB/s.
+  cpu_baseline -- the reference's own ndlqr_Solve (oracle/_ref/libref.so, "reference") or the
+                  plain-C oracle ("port") timed on this host on a bounded sample (N=1, rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md), ~6300 achievable
+
+
+def model_b_bytes(n, m, N):
+    """SURVEY.md 8(d) 'level-streaming' algorithmic bytes per solve: (leaves, [per level])."""
+    K = int(np.log2(N))
+    Fb = (2 * n + m) * n
+    leaves = N * (4 * n * n + 3 * m * n + m * m + 5 * n + 3 * m)
+    levels = []
+    for l in range(K):
+        L = 1 << (K - l - 1)
+        P1 = L * (K - l) * (4 * n * n + 2 * m * n) + L * (n * n + n * m)
+        P2 = 2 * L * n * n
+        P3 = L * n * n + 2 * L * (K - l - 1) * n * n
+        P4 = (N * Fb if l < K - 1 else 0) + L * (K - l - 1) * n * n + 2 * N * (K - l - 1) * Fb
+        S = L * (2 * n * n + n * m + 8 * n + 2 * m) + N * (Fb + 5 * n + 2 * m)
+        levels.append(8 * (P1 + P2 + P3 + P4 + S))
+    return 8 * leaves, levels
+
+
+def live_bytes(n, m, N):
+    """Bytes the kernels of this build actually have to move per solve (DESIGN.md "live
+    columns"): inputs + rhs once, per level read E + read/write one outer column + write the
+    other + rhs read/write, plus the separator blocks."""
+    K = int(np.log2(N))
+    Fb = (2 * n + m) * n
+    zb = 2 * n + m
+    leaves = N * (n * (n + m) + (n + m) + zb) + N * (2 * Fb + zb)
+    total = leaves
+    for l in range(K):
+        L = 1 << (K - l - 1)
+        cols = 0 if l == K - 1 else 2  # outer columns alive (upper bound; ends have one)
+        sep = L * (n * (n + m) + 2 * Fb + 2 * zb + (1 + cols) * n * n + n)
+        schur = N * (Fb + cols * Fb + (cols - 1 if cols else 0) * Fb + 2 * zb)
+        total += sep + schur
+    return 8 * total
+
+
+def host_cores():
+    """CPU cores this process may really use: min(affinity mask, cgroup cpu quota). On the GPU
+    boxes the mask shows every host CPU while the cgroup grants a share (16 per GPU)."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("NDLQR_BENCH_CORES")
+    return int(env) if env else cores
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(n, m, N, probs, gpu_solutions):
+    """Times the CPU checker on a bounded sample; returns (dict, parity_rel_err)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import support  # the oracle bindings: used here ONLY as checker / baseline
+    cores = host_cores()
+    flat = [np.ascontiguousarray(np.stack([p[k] for p in probs])) for k in
+            ("A", "B", "Q", "R", "q", "r", "d", "x0")]
+    count = len(probs)
+    import ctypes as C
+    args = [a.ctypes.data_as(support.dp) for a in flat]
+    # parity of the GPU result against the checker on the same sample
+    orc = support.Oracle()
+    worst = 0.0
+    for i, p in enumerate(probs):
+        prob = support.Problem(n, m, N, p["A"], p["B"], p["Q"], p["R"], p["q"], p["r"], p["d"], p["x0"])
+        z, _, _, _ = orc.solve(prob, 1)
+        ref = z[: prob.nvars]
+        worst = max(worst, float(np.linalg.norm(gpu_solutions[i] - ref) / np.linalg.norm(ref)))
+    out = {"cores": cores}
+    if support.have_reference():
+        ref = support.Reference()
+        # (i) reference semantics: one solve at a time, all cores inside the solve
+        ref.L.ref_bench(n, m, N, min(count, 2), 1, *args, cores)  # warm-up
+        ms_i = ref.L.ref_bench(n, m, N, count, 1, *args, cores)
+        rate_i = count / (ms_i * 1e-3)
+        # (ii) throughput: one thread per solve, all cores busy with different problems
+        ref.L.ref_bench_throughput.restype = C.c_double
+        ref.L.ref_bench_throughput.argtypes = [C.c_int] * 5 + [support.dp] * 8 + [C.c_int]
+        ref.L.ref_bench_throughput(n, m, N, min(count, cores), 1, *args, cores)
+        reps = 2
+        ms_ii = ref.L.ref_bench_throughput(n, m, N, count, reps, *args, cores)
+        rate_ii = count * reps / (ms_ii * 1e-3)
+        out.update(kind="reference", value=max(rate_i, rate_ii), unit="solves/s",
+                   sample="%d problems of (%d,%d,%d): reference ndlqr_Solve from oracle/_ref; "
+                          "(i) 1 solve at a time x %d threads = %.1f solves/s, (ii) %d solves in "
+                          "parallel x 1 thread = %.1f solves/s; value = the better"
+                          % (count, n, m, N, cores, rate_i, cores, rate_ii))
+    else:
+        ms = C.c_double(0)
+        orc.L.oracle_bench(n, m, N, min(count, cores), 1, *args, cores, 1, C.byref(ms))
+        reps = 4
+        orc.L.oracle_bench(n, m, N, count, reps, *args, cores, 1, C.byref(ms))
+        rate_ii = count * reps / (ms.value * 1e-3)
+        orc.L.oracle_bench(n, m, N, count, 1, *args, cores, 0, C.byref(ms))
+        rate_i = count / (ms.value * 1e-3)
+        out.update(kind="port", value=max(rate_i, rate_ii), unit="solves/s",
+                   sample="%d problems of (%d,%d,%d): plain-C oracle (oracle/ndlqr_oracle.c); (i) 1 "
+                          "solve at a time x %d threads = %.1f solves/s, (ii) %d solves in parallel x "
+                          "1 thread = %.1f solves/s; value = the better"
+                          % (count, n, m, N, cores, rate_i, cores, rate_ii))
+    return out, worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=12)
+    ap.add_argument("--nu", type=int, default=4)
+    ap.add_argument("--horizon", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--flags", type=int, default=0, help="NDLQR_FLAG_* bits (1 strict, 2 generic)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (no CPU fallback for the product path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import rslqr_amd
+    n, m, N, batch = args.nx, args.nu, args.horizon, args.batch
+    bs = rslqr_amd.BatchSolver(n, m, N, batch, device=local_rank,
+                               flags=args.flags | rslqr_amd.FLAG_PROFILE)
+    seed0 = 1 + rank * batch  # problem p of the whole job has seed 1 + p
+    log("rank %d: generating + uploading %d synthetic problems" % (rank, batch))
+    bs.initialize_synthetic(seed0)
+    log("rank %d: warm-up" % rank)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        bs.solve_async()
+    bs.synchronize()
+    bs.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bs.solve_async()
+    bs.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    log("rank %d: %d steps in %.3f s" % (rank, args.steps, elapsed))
+    fails = bs.cholesky_failures()
+    prof = bs.profile()
+
+    t = torch.tensor([elapsed, float(fails)], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t[0].item())
+    fails_max = int(t[1].item())
+
+    if rank == 0:
+        total_solves = batch * world * args.steps
+        value = total_solves / elapsed_max
+        leaf_b, level_b = model_b_bytes(n, m, N)
+        # dominant kernel = whichever per-level slot carries the time
+        dom = max((k for k in prof if k != "leaf"), key=lambda k: prof[k][0])
+        if dom == "level":
+            dom_ms, dom_launches = prof["level"]
+        else:  # generic path: separator + schur pair covers one level
+            dom_ms = prof["separator"][0] + prof["schur"][0]
+            dom_launches = prof["schur"][1]
+            dom = "separator+schur"
+        avg_ms = dom_ms / max(dom_launches, 1)
+        bytes_per_launch = sum(level_b) * batch / len(level_b)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        whole_solve_gbs = (leaf_b + sum(level_b)) * value / world / 1e9
+        result = {
+            "metric": "LQR solves/sec (nx=%d,nu=%d,N=%d,batch=%d per GPU)" % (n, m, N, batch),
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
+            "ms_per_solve": elapsed_max / args.steps * 1e3 / batch,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (seeded splitmix64 family of SURVEY.md 8d, time-varying A,B,Q,R)",
+            "config": {"workload": "nx=%d nu=%d N=%d batch=%d per GPU, fp64, factor+solve per step"
+                                   % (n, m, N, batch),
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "flags": args.flags, "cholesky_failures": fails_max},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": dom_launches,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "whole_solve_model_b_gbs_per_gpu": whole_solve_gbs,
+                         "live_column_bytes_per_solve": live_bytes(n, m, N),
+                         "model_b_bytes_per_solve": leaf_b + sum(level_b)},
+            "kernel_ms": {k: {"total_ms": v[0], "launches": v[1]} for k, v in prof.items() if v[1]},
+        }
+        if world == 1 and not args.no_cpu:
+            cores = host_cores()
+            log("cpu_baseline leg on %d cores" % cores)
+            count = args.cpu_sample or max(8, min(batch, 2 * cores))
+            probs = [rslqr_amd.generate_synthetic(n, m, N, seed0 + p) for p in range(count)]
+            gpu_sol = [bs.solution(p) for p in range(count)]
+            base, worst = cpu_baseline(n, m, N, probs, gpu_sol)
+            result["cpu_baseline"] = base
+            result["parity_rel_err_vs_cpu"] = worst
+            result["speedup_vs_cpu"] = value / base["value"]
+        print(json.dumps(result), flush=True)
+
+    bs.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,3 +139,33 @@ double ref_bench(int n, int m, int N, int count, int reps, const double* A, cons
   ndlqr_FreeNdLqrSolver(s);
   return total;
 }
+
+/*
+ * Throughput mode for bench.py: `nthreads` host threads, each with its own reference solver,
+ * each running whole solves with one thread inside (the nested region of ndlqr_Solve gets a
+ * team of 1). Returns wall ms of the whole loop (reset + initialise included; they are
+ * O(N n^2) against the O(N K^2 n^3) solve).
+ */
+#include <omp.h>
+double ref_bench_throughput(int n, int m, int N, int count, int reps, const double* A,
+                            const double* B, const double* Q, const double* R, const double* q,
+                            const double* r, const double* d, const double* x0, int nthreads) {
+  size_t sA = (size_t)N * n * n, sB = (size_t)N * n * m, sn = (size_t)N * n, sm = (size_t)N * m;
+  NdLqrSolver** ss = (NdLqrSolver**)malloc(sizeof(NdLqrSolver*) * nthreads);
+  for (int t = 0; t < nthreads; ++t) ss[t] = ndlqr_NewNdLqrSolver(n, m, N);
+  double t0 = omp_get_wtime();
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int p = 0; p < count; ++p) {
+      NdLqrSolver* s = ss[omp_get_thread_num()];
+      ref_reinit(s, n, m, N, A + p * sA, B + p * sB, Q + p * sn, R + p * sm, q + p * sn,
+                 r + p * sm, d + p * sn, x0 + (size_t)p * n);
+      ndlqr_SetNumThreads(s, 1);
+      ndlqr_Solve(s);
+    }
+  }
+  double ms = (omp_get_wtime() - t0) * 1e3;
+  for (int t = 0; t < nthreads; ++t) ndlqr_FreeNdLqrSolver(ss[t]);
+  free(ss);
+  return ms;
+}

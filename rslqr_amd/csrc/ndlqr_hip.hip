@@ -19,6 +19,7 @@
 
 #include "kernels_common.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_small.hpp"
 
 // ------------------------------------------------------------------------------ errors
 
@@ -248,6 +249,46 @@ static int launch_generic(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
+// Size-specialised launch sequence: generic leaf kernel, then per level one separator kernel
+// (a wavefront per separator) and one Schur kernel (a wavefront per KPW knots).
+template <int NX, int NU, bool STRICT>
+static int launch_small(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  using Sh = ndlqr::SchurShape<NX, NU>;
+  {
+    ScopedSlot t(c, SLOT_LEAF);
+    hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
+                       c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+  }
+  for (int l = 0; l < d.K; ++l) {
+    {
+      ScopedSlot t(c, SLOT_SEP);
+      hipLaunchKernelGGL((ndlqr::separator_small<NX, NU, STRICT>), dim3(d.N >> (l + 1), d.batch), dim3(64),
+                         0, c->stream, d, l, c->AB, c->F, c->z, c->info);
+    }
+    {
+      ScopedSlot t(c, SLOT_SCHUR);
+      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT>), dim3(d.N / Sh::KPB, d.batch), dim3(256), 0,
+                         c->stream, d, l, c->F, c->z);
+    }
+  }
+  return NDLQR_OK;
+}
+
+// returns true when (n, m, N) has a size-specialised instance and it was launched
+static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
+  const ndlqr::Dims& d = c->d;
+#define NDLQR_SMALL_CASE(NX_, NU_)                                                        \
+  if (d.n == NX_ && d.m == NU_ && d.N >= ndlqr::SchurShape<NX_, NU_>::KPB) {              \
+    *err = strict ? launch_small<NX_, NU_, true>(c) : launch_small<NX_, NU_, false>(c);   \
+    return true;                                                                          \
+  }
+  NDLQR_SMALL_CASE(12, 4)
+  NDLQR_SMALL_CASE(6, 3)
+#undef NDLQR_SMALL_CASE
+  return false;
+}
+
 int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
@@ -256,7 +297,9 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   const bool strict = (c->flags & NDLQR_FLAG_STRICT_FP) != 0;
   int err = NDLQR_OK;
-  err = strict ? launch_generic<true>(c) : launch_generic<false>(c);
+  bool done = false;
+  if (!(c->flags & NDLQR_FLAG_GENERIC)) done = try_launch_small(c, strict, &err);
+  if (!done) err = strict ? launch_generic<true>(c) : launch_generic<false>(c);
   if (err) return err;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));

@@ -28,7 +28,8 @@ def stack(probs):
     return [np.stack([getattr(p, k) for p in probs]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
 
 
-SHAPES = [(6, 3, 8), (12, 4, 16), (12, 4, 64), (5, 2, 32), (16, 8, 8), (3, 1, 2), (1, 1, 4), (7, 9, 16)]
+SHAPES = [(6, 3, 8), (6, 3, 16), (6, 3, 64), (12, 4, 8), (12, 4, 16), (12, 4, 64), (5, 2, 32), (16, 8, 8),
+          (3, 1, 2), (1, 1, 4), (7, 9, 16)]
 
 
 @pytest.mark.parametrize("n,m,N", SHAPES)
