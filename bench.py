@@ -153,9 +153,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from rslqr_amd import sharding
+    rank, local_rank, world = sharding.env_rank()
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback for the product path)", file=sys.stderr)
         sys.exit(2)
@@ -168,7 +167,7 @@ def main():
     n, m, N, batch = args.nx, args.nu, args.horizon, args.batch
     bs = rslqr_amd.BatchSolver(n, m, N, batch, device=local_rank,
                                flags=args.flags | rslqr_amd.FLAG_PROFILE)
-    seed0 = 1 + rank * batch  # problem p of the whole job has seed 1 + p
+    seed0 = sharding.shard_seed0(rank, batch)  # global problem g has seed 1 + g
     log("rank %d: generating + uploading %d synthetic problems" % (rank, batch))
     bs.initialize_synthetic(seed0)
     log("rank %d: warm-up" % rank)
@@ -193,11 +192,8 @@ def main():
     fails = bs.cholesky_failures()
     prof = bs.profile()
 
-    t = torch.tensor([elapsed, float(fails)], dtype=torch.float64, device="cuda")
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t[0].item())
-    fails_max = int(t[1].item())
+    elapsed_max, fails_max = sharding.max_over_ranks([elapsed, float(fails)], device="cuda")
+    fails_max = int(fails_max)
 
     if rank == 0:
         total_solves = batch * world * args.steps

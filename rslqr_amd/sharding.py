@@ -1,0 +1,48 @@
+"""Batch sharding across ranks (one process per GPU). The batch axis of independent LQR problems
+is the only thing that is ever split: rank r of W owns global problems [r*B, (r+1)*B) of a job of
+W*B problems (weak scaling, B = per-GPU batch). There is no data-path collective; the helpers
+below are the control-plane pieces bench.py and the tests share (barrier, max-over-ranks,
+optional gather of solutions to rank 0). Backend "nccl" is RCCL on ROCm; "gloo" is used by the
+CPU tests."""
+import os
+
+import numpy as np
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(rank, world, batch_per_rank):
+    """Global problem indices owned by `rank`."""
+    lo = rank * batch_per_rank
+    return lo, lo + batch_per_rank
+
+
+def shard_seed0(rank, batch_per_rank, job_seed0=1):
+    """Seed of the first problem of the shard: global problem g has seed job_seed0 + g
+    (SURVEY.md 8d), whatever the number of ranks."""
+    return job_seed0 + rank * batch_per_rank
+
+
+def max_over_ranks(values, device=None):
+    """Element-wise MAX of a small list of floats over all ranks (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+def gather_solutions(local, device=None):
+    """all_gather of per-rank solution arrays [B, nvars] -> [W*B, nvars] in global problem order."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(local)
+    t = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return torch.cat(parts, dim=0).cpu().numpy()

@@ -1,0 +1,70 @@
+"""N>1 path on CPU: world_size-2 gloo. The batch is sharded by rank with global seeds, each rank
+solves its shard (with the CPU oracle here -- no GPU in this container; on a GPU box the same
+sharding feeds BatchSolver), results are gathered and must equal the single-process answer in
+global problem order; max_over_ranks reduces timings like bench.py does."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _solve_shard(rank, world, per_rank, n, m, N):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import rslqr_amd
+    from rslqr_amd import sharding
+    from support import Oracle, Problem
+    orc = Oracle()
+    seed0 = sharding.shard_seed0(rank, per_rank)
+    out = []
+    for p in range(per_rank):
+        g = rslqr_amd.generate_synthetic(n, m, N, seed0 + p)
+        prob = Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+        z, _, _, _ = orc.solve(prob, 1)
+        out.append(z[: prob.nvars])
+    return np.stack(out)
+
+
+def _worker(rank, world, port, per_rank, n, m, N, outdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from rslqr_amd import sharding
+    assert sharding.env_rank() == (rank, rank, world)
+    lo, hi = sharding.shard_range(rank, world, per_rank)
+    assert (lo, hi) == (rank * per_rank, (rank + 1) * per_rank)
+    local = _solve_shard(rank, world, per_rank, n, m, N)
+    dist.barrier()
+    allsol = sharding.gather_solutions(local)
+    mx = sharding.max_over_ranks([1.0 + rank, 5.0 - rank])
+    if rank == 0:
+        np.save(os.path.join(outdir, "all.npy"), allsol)
+        np.save(os.path.join(outdir, "max.npy"), np.array(mx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(tmp_path):
+    world, per_rank, n, m, N = 2, 3, 6, 3, 16
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, per_rank, n, m, N, str(tmp_path)), nprocs=world, join=True)
+    allsol = np.load(tmp_path / "all.npy")
+    assert allsol.shape[0] == world * per_rank
+    single = _solve_shard(0, 1, world * per_rank, n, m, N)  # global problems 0..5, seeds 1..6
+    assert np.array_equal(allsol, single)
+    assert np.array_equal(np.load(tmp_path / "max.npy"), [2.0, 5.0])
