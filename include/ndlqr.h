@@ -295,6 +295,9 @@ typedef struct NdLqrBatchSolver NdLqrBatchSolver;
 #define NDLQR_FLAG_GENERIC 2u     /* force the runtime-sized kernels even when a size-specialised
                                      variant exists (cross-check) */
 #define NDLQR_FLAG_PROFILE 4u     /* bracket every kernel with HIP events */
+#define NDLQR_FLAG_KEEP_FACT 8u   /* also materialise the complete factor array on the device (what
+                                     the reference leaves in solver->fact); needed by
+                                     ndlqr_CopyBatchFactors. Off: only the solution is produced. */
 
 NdLqrBatchSolver* ndlqr_NewBatchSolver(int nstates, int ninputs, int nhorizon, int batch,
                                        int device);

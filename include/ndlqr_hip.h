@@ -61,7 +61,10 @@ double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
  * fact: one problem, converted to the reference's NdData layout, N*K*(2n+m)*n doubles. */
 int ndlqr_hip_download_solutions(NdlqrHipCtx* ctx, int p0, int count, double* soln);
 int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* ctx, int p, double* z_full); /* N*(2n+m) */
-int ndlqr_hip_download_factors(NdlqrHipCtx* ctx, int p, double* fact);
+int ndlqr_hip_download_factors(NdlqrHipCtx* ctx, int p, double* fact); /* needs NDLQR_FLAG_KEEP_FACT */
+/* Tuning knob: tree level J from which the upper levels run boundary-first + one apply pass
+ * (-1 = default, K = pure level-by-level streaming). Results do not depend on it. */
+int ndlqr_hip_set_fuse_level(NdlqrHipCtx* ctx, int J);
 int ndlqr_hip_cholesky_failures(NdlqrHipCtx* ctx);
 
 /* Per-kernel profile (NDLQR_FLAG_PROFILE): HIP-event durations accumulated since the last

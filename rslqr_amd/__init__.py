@@ -8,6 +8,7 @@ C API, plus a numpy-friendly ``BatchSolver``.
 from .api import (  # noqa: F401
     BatchSolver,
     FLAG_GENERIC,
+    FLAG_KEEP_FACT,
     FLAG_PROFILE,
     FLAG_STRICT_FP,
     LQRData,

@@ -16,6 +16,7 @@ from . import build as _build
 FLAG_STRICT_FP = 1
 FLAG_GENERIC = 2
 FLAG_PROFILE = 4
+FLAG_KEEP_FACT = 8
 
 ERR_INVALID = -1
 ERR_NO_DEVICE = -2
@@ -228,6 +229,7 @@ def lib():
     proto("ndlqr_hip_profile_get", ci, vp, ci, C.c_char_p, ci, dp, C.POINTER(ci))
     proto("ndlqr_hip_profile_reset", ci, vp)
     proto("ndlqr_hip_device_pointers", ci, vp, C.POINTER(vp))
+    proto("ndlqr_hip_set_fuse_level", ci, vp, ci)
     proto("ndlqr_hip_gemm", ci, ci, ci, ci, ci, ci, cd, dp, ci, dp, ci, cd, dp, ci)
     proto("ndlqr_hip_potrf_lower", ci, ci, dp, ci)
     proto("ndlqr_hip_potrs_lower", ci, ci, ci, dp, ci, dp, ci)
@@ -282,6 +284,10 @@ class BatchSolver:
     @property
     def ctx(self):
         return self.L.ndlqr_BatchDeviceContext(self.h)
+
+    def set_fuse_level(self, J):
+        """Tree level from which the upper levels run boundary-first + one apply pass."""
+        self.L.ndlqr_hip_set_fuse_level(self.ctx, J)
 
     def initialize_flat(self, A, B, Q, R, q, r, d, x0):
         n, m, N, bt = self.n, self.m, self.N, self.batch

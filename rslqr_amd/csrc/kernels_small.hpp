@@ -56,7 +56,8 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, const double (
 // ------------------------------------------------------------------------------------- separator
 template <int NX, int NU, bool STRICT>
 __global__ __launch_bounds__(64) void separator_small(Dims d, int l, const double* __restrict__ AB,
-                                                      double* F, double* z, int* __restrict__ info) {
+                                                      double* F, double* z, double* __restrict__ rec,
+                                                      int* __restrict__ info) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU;
   static_assert(3 * NX <= 64, "three lane groups of NX must fit a wavefront");
   __shared__ __attribute__((aligned(16))) double shE[W * NX];   // state+input rows of E(s)
@@ -165,7 +166,10 @@ __global__ __launch_bounds__(64) void separator_small(Dims d, int l, const doubl
     for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-readlane_f64(Lr[r], j), x[j], x[r]);
   }
 
-  // ---- store: factor of S-bar (rows), f_a / f_bb (columns), z_sep
+  // ---- store: factor of S-bar (rows), f_a / f_bb (columns), z_sep; the three right-hand
+  //      sides also go, contiguously, into this separator's record rec[b][s] = f_a | f_bb | z_sep
+  //      (what the Schur / apply kernels stage in LDS)
+  double* myrec = rec + ((size_t)b * N + s) * (2 * NX * NX + NX);
   if (grp == 0) {
     double* outS = Fblk(F, d, b, l, s + 1) + i * NX;
 #pragma unroll
@@ -174,11 +178,12 @@ __global__ __launch_bounds__(64) void separator_small(Dims d, int l, const doubl
   if (has_col) {
     if (lane == 2 * NX) {
 #pragma unroll
-      for (int k = 0; k < NX; ++k) zs1[k] = x[k];
+      for (int k = 0; k < NX; ++k) { zs1[k] = x[k]; myrec[2 * NX * NX + k] = x[k]; }
     } else {
       double* out = Fblk(F, d, b, which == 0 ? a : bb, s + 1) + col;
+      double* out2 = myrec + which * NX * NX + col;
 #pragma unroll
-      for (int k = 0; k < NX; ++k) out[k * NX] = x[k];
+      for (int k = 0; k < NX; ++k) { out[k * NX] = x[k]; out2[k * NX] = x[k]; }
     }
   }
 }
@@ -194,44 +199,55 @@ struct SchurShape {
   static constexpr int REC = 2 * NX * NX + NX;  // doubles per record: f_a | f_bb | z_sep
 };
 
-template <int NX, int NU, bool STRICT>
-__global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, double* z) {
+// BOUNDARY = false: every knot (grid.x = N / KPB workgroups of KPB consecutive knots).
+// BOUNDARY = true : only the first and the last knot of every level-l subtree, the two that
+//                   later separators read (one wavefront per subtree, KPW must be 2..; grid.x =
+//                   ceil(N / 2^(l+1) / WAVES)); used for the upper levels before apply_small.
+template <int NX, int NU, bool STRICT, bool BOUNDARY>
+__global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, double* z,
+                                                   const double* __restrict__ recs) {
   using Sh = SchurShape<NX, NU>;
-  constexpr int ROWS = Sh::ROWS, KPW = Sh::KPW, KPB = Sh::KPB, REC = Sh::REC;
-  static_assert(KPW >= 1 && (KPB & (KPB - 1)) == 0, "knots per workgroup must be a power of two");
-  __shared__ __attribute__((aligned(16))) double rec[Sh::NREC][REC];
+  constexpr int ROWS = Sh::ROWS, KPW = Sh::KPW, KPB = Sh::KPB, REC = Sh::REC, WAVES = Sh::WAVES;
+  static_assert(KPW >= 2 && (KPB & (KPB - 1)) == 0, "knots per workgroup must be a power of two");
+  constexpr int NRECS = BOUNDARY ? WAVES : Sh::NREC;
+  __shared__ __attribute__((aligned(16))) double rec[NRECS][REC];
   const int N = d.N, b = blockIdx.y;
-  const int first = blockIdx.x * KPB;
   const int half = 1 << l, T = 2 << l;
-  const int nrec = (T >= KPB) ? 1 : KPB / T;
+  const int first = BOUNDARY ? 0 : blockIdx.x * KPB;
+  const int nrec = BOUNDARY ? WAVES : ((T >= KPB) ? 1 : KPB / T);
+  const int nsub = N >> (l + 1);
 
-  // cooperative load of the separator results every knot of this workgroup needs
+  // cooperative load of the separator records every knot of this workgroup needs
   for (int q = 0; q < nrec; ++q) {
-    const int qbase = ((first + q * T) >> (l + 1)) << (l + 1);
-    const int qs = qbase + half - 1;
-    int qa, qb;
-    outer_columns(qbase, l, N, qa, qb);
-    const double* fa = qa >= 0 ? Fblk(F, d, b, qa, qs + 1) : nullptr;
-    const double* fb = qb >= 0 ? Fblk(F, d, b, qb, qs + 1) : nullptr;
-    const double* zsep = z + ((size_t)b * N + qs + 1) * ROWS;
-    for (int e = threadIdx.x; e < REC; e += 256) {
-      double v = 0.0;
-      if (e < NX * NX) { if (fa) v = fa[e]; }
-      else if (e < 2 * NX * NX) { if (fb) v = fb[e - NX * NX]; }
-      else v = zsep[e - 2 * NX * NX];
-      rec[q][e] = v;
+    int qs;
+    if (BOUNDARY) {
+      const int sub = blockIdx.x * WAVES + q;
+      if (sub >= nsub) break;
+      qs = sub * T + half - 1;
+    } else {
+      qs = (((first + q * T) >> (l + 1)) << (l + 1)) + half - 1;
     }
+    const double* src = recs + ((size_t)b * N + qs) * REC;
+    for (int e = threadIdx.x; e < REC; e += 256) rec[q][e] = src[e];
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kn = lane / ROWS, r = lane - kn * ROWS;
-  if (kn >= KPW) return;
-  const int i = first + wave * KPW + kn;
+  int i, q;
+  if (BOUNDARY) {
+    const int sub = blockIdx.x * WAVES + wave;
+    if (sub >= nsub || kn >= 2) return;
+    i = sub * T + (kn == 0 ? 0 : T - 1);
+    q = wave;
+  } else {
+    if (kn >= KPW) return;
+    i = first + wave * KPW + kn;
+    q = (T >= KPB) ? 0 : (i - first) / T;
+  }
   const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
   int a, bb;
   outer_columns(base, l, N, a, bb);
-  const int q = (T >= KPB) ? 0 : (i - first) / T;
   const double* fa = rec[q];
   const double* fb = rec[q] + NX * NX;
   const double* zsep = rec[q] + 2 * NX * NX;
@@ -293,6 +309,123 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
     for (int k = 0; k < NX; ++k) accz = mad<STRICT>(-E[k], zsep[k], accz);
     *g = accz;
   }
+}
+
+// ------------------------------------------------------------------------------------- apply
+// All upper levels J..K-1 for every knot in ONE pass (DESIGN.md "boundary-first"): once the
+// separator records of those levels exist (separator_small on the boundary knots, which
+// schur_small<BOUNDARY> keeps up to date), a knot's updates at successive levels only involve its
+// own rows: E (column l), the two live outer columns and its rhs entry stay in registers and
+// rotate from level to level; only the rhs (and, with KEEP, the finished columns) go back to HBM.
+// Same operations in the same order per element as running schur_small level by level.
+//   grid (N / KPB, batch), block 256, dynamic LDS = (K - J) * REC doubles.
+// Knots that the boundary pass already advanced (first / last knot of a 2^J block) join at the
+// level where that pass left them (lstart).
+template <int NX, int NU, bool STRICT, bool KEEP>
+__global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, double* z,
+                                                   const double* __restrict__ recs) {
+  using Sh = SchurShape<NX, NU>;
+  constexpr int ROWS = Sh::ROWS, KPW = Sh::KPW, KPB = Sh::KPB, REC = Sh::REC;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int N = d.N, K = d.K, b = blockIdx.y;
+  const int first = blockIdx.x * KPB;
+  for (int l = J; l < K; ++l) {
+    const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
+    const double* src = recs + ((size_t)b * N + qs) * REC;
+    double* dst = lds + (l - J) * REC;
+    for (int e = threadIdx.x; e < REC; e += 256) dst[e] = src[e];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kn = lane / ROWS, r = lane - kn * ROWS;
+  if (kn >= KPW) return;
+  const int i = first + wave * KPW + kn;
+  const bool lam = r < NX;
+
+  int lstart = J;
+  {
+    const int mask = (1 << J) - 1;
+    if ((i & mask) == 0) lstart = (i == 0) ? K : __builtin_ctz(i);
+    else if ((i & mask) == mask) lstart = trailing_ones(i);
+    if (lstart > K - 1) lstart = K - 1;
+  }
+
+  double E[NX], Ca[NX], Cb[NX];
+  double zz = 0.0;
+#pragma unroll
+  for (int c = 0; c < NX; ++c) { E[c] = 0.0; Ca[c] = 0.0; Cb[c] = 0.0; }
+  double* zp = z + ((size_t)b * N + i) * ROWS + r;
+
+  for (int l = J; l < K; ++l) {
+    if (l < lstart) continue;
+    const int half = 1 << l, T = 2 << l;
+    const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+    int a, bb;
+    outer_columns(base, l, N, a, bb);
+    const bool left = i <= s;
+    const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+    const bool active = !lam || calc_lambda;
+    const double* rc = lds + (l - J) * REC;
+    const double* fa = rc;
+    const double* fb = rc + NX * NX;
+    const double* zsep = rc + 2 * NX * NX;
+
+    if (l == lstart) {  // pick the knot up where the level-by-level kernels left it
+      load_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
+      if (left) { if (a >= 0) load_row<NX>(Fblk(F, d, b, a, i) + r * NX, Ca); }
+      else      { if (bb >= 0) load_row<NX>(Fblk(F, d, b, bb, i) + r * NX, Cb); }
+      zz = *zp;
+    } else if (KEEP && active) {
+      store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);  // column l is final for this knot
+    }
+
+    if (active) {
+      if (a >= 0) {
+        double acc[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc[c] = left ? Ca[c] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+#pragma unroll
+          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fa[k * NX + c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Ca[c] = acc[c];
+      }
+      if (bb >= 0) {
+        double acc[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc[c] = left ? 0.0 : Cb[c];
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+#pragma unroll
+          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fb[k * NX + c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Cb[c] = acc[c];
+      }
+#pragma unroll
+      for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], zsep[k], zz);
+    } else if (i == s + 1) {  // lambda rows of knot s+1 receive the separator's results
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        if (a >= 0) Ca[c] = fa[r * NX + c];
+        if (bb >= 0) Cb[c] = fb[r * NX + c];
+      }
+      zz = zsep[r];
+    } else {  // lambda rows not yet eliminated: the created column starts as zero
+#pragma unroll
+      for (int c = 0; c < NX; ++c) { if (left) Cb[c] = 0.0; else Ca[c] = 0.0; }
+    }
+
+    // rotate into the roles of level l+1: a left child's right outer column is column l+1
+    const bool left_child = (base & T) == 0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      if (left_child) { E[c] = Cb[c]; Cb[c] = 0.0; }
+      else            { E[c] = Ca[c]; Ca[c] = 0.0; }
+    }
+  }
+  *zp = zz;
 }
 
 }  // namespace ndlqr

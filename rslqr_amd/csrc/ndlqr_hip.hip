@@ -46,8 +46,8 @@ int ndlqr_hip_device_count(void) {
 
 // ------------------------------------------------------------------------------ context
 
-enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_LEVEL, SLOT_COUNT };
-static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "level"};
+enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_BOUNDARY, SLOT_APPLY, SLOT_BOTTOM, SLOT_COUNT };
+static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom"};
 
 struct PendingEvent {
   int slot;
@@ -65,7 +65,9 @@ struct NdlqrHipCtx {
   double* rhs;
   double* F;
   double* z;
+  double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
+  int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;
   bool timing_pending;
   double last_ms;
@@ -80,6 +82,7 @@ struct NdlqrHipCtx {
 static size_t bytes_AB(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.n * d.w; }
 static size_t bytes_QR(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.w; }
 static size_t bytes_z(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.rows; }
+static size_t bytes_rec(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * (2 * d.n * d.n + d.n); }
 static size_t bytes_F(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.K * d.N * d.fb; }
 
 NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch, int device) {
@@ -108,7 +111,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.K = 0; while ((1 << d.K) < nhorizon) ++d.K;
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
-  c->AB = c->QR = c->rhs = c->F = c->z = nullptr; c->info = nullptr;
+  c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
+  c->fuse_level = -1;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
@@ -116,7 +120,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
             hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess &&
             hipMalloc(&c->AB, bytes_AB(d)) == hipSuccess && hipMalloc(&c->QR, bytes_QR(d)) == hipSuccess &&
             hipMalloc(&c->rhs, bytes_z(d)) == hipSuccess && hipMalloc(&c->z, bytes_z(d)) == hipSuccess &&
-            hipMalloc(&c->F, bytes_F(d)) == hipSuccess &&
+            hipMalloc(&c->F, bytes_F(d)) == hipSuccess && hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
             hipMalloc(&c->info, sizeof(int) * (size_t)batch) == hipSuccess;
   if (ok) {
     // Structural zeros of F are never written by the kernels; zero once so that the factor
@@ -141,7 +145,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
-  (void)hipFree(c->z); (void)hipFree(c->info);
+  (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->info);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -249,10 +253,12 @@ static int launch_generic(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
-// Size-specialised launch sequence: generic leaf kernel, then per level one separator kernel
-// (a wavefront per separator) and one Schur kernel (a wavefront per KPW knots).
-template <int NX, int NU, bool STRICT>
-static int launch_small(NdlqrHipCtx* c) {
+// Size-specialised launch sequence. Levels below J: one separator + one Schur launch each.
+// Levels J..K-1 ("boundary-first"): separator + Schur on the two boundary knots of every subtree
+// (tiny grids), then ONE apply_small pass that takes every knot through all those levels in
+// registers. J = K disables the second form (pure level-by-level streaming).
+template <int NX, int NU, bool STRICT, bool KEEP>
+static int launch_small(NdlqrHipCtx* c, int J) {
   const ndlqr::Dims& d = c->d;
   using Sh = ndlqr::SchurShape<NX, NU>;
   {
@@ -264,13 +270,25 @@ static int launch_small(NdlqrHipCtx* c) {
     {
       ScopedSlot t(c, SLOT_SEP);
       hipLaunchKernelGGL((ndlqr::separator_small<NX, NU, STRICT>), dim3(d.N >> (l + 1), d.batch), dim3(64),
-                         0, c->stream, d, l, c->AB, c->F, c->z, c->info);
+                         0, c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
     }
-    {
+    if (l < J) {
       ScopedSlot t(c, SLOT_SCHUR);
-      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT>), dim3(d.N / Sh::KPB, d.batch), dim3(256), 0,
-                         c->stream, d, l, c->F, c->z);
+      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT, false>), dim3(d.N / Sh::KPB, d.batch), dim3(256),
+                         0, c->stream, d, l, c->F, c->z, c->rec);
+    } else if (l < d.K - 1) {
+      ScopedSlot t(c, SLOT_BOUNDARY);
+      const int nsub = d.N >> (l + 1);
+      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT, true>),
+                         dim3((nsub + Sh::WAVES - 1) / Sh::WAVES, d.batch), dim3(256), 0, c->stream, d, l,
+                         c->F, c->z, c->rec);
     }
+  }
+  if (J < d.K) {
+    ScopedSlot t(c, SLOT_APPLY);
+    const size_t lds = sizeof(double) * (size_t)(d.K - J) * Sh::REC;
+    hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
+                       c->stream, d, J, c->F, c->z, c->rec);
   }
   return NDLQR_OK;
 }
@@ -278,10 +296,18 @@ static int launch_small(NdlqrHipCtx* c) {
 // returns true when (n, m, N) has a size-specialised instance and it was launched
 static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
   const ndlqr::Dims& d = c->d;
-#define NDLQR_SMALL_CASE(NX_, NU_)                                                        \
-  if (d.n == NX_ && d.m == NU_ && d.N >= ndlqr::SchurShape<NX_, NU_>::KPB) {              \
-    *err = strict ? launch_small<NX_, NU_, true>(c) : launch_small<NX_, NU_, false>(c);   \
-    return true;                                                                          \
+  const bool keep = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0;
+#define NDLQR_SMALL_CASE(NX_, NU_)                                                                  \
+  if (d.n == NX_ && d.m == NU_ && d.N >= ndlqr::SchurShape<NX_, NU_>::KPB) {                        \
+    /* apply_small needs all KPB knots of a workgroup inside one level-J subtree: 2^(J+1) >= KPB */ \
+    int Jmin = 0;                                                                                   \
+    while ((2 << Jmin) < ndlqr::SchurShape<NX_, NU_>::KPB) ++Jmin;                                  \
+    int J = c->fuse_level >= 0 ? c->fuse_level : 3;                                                 \
+    if (J < Jmin) J = Jmin;                                                                         \
+    if (J > d.K) J = d.K;                                                                           \
+    if (strict) *err = keep ? launch_small<NX_, NU_, true, true>(c, J) : launch_small<NX_, NU_, true, false>(c, J);   \
+    else        *err = keep ? launch_small<NX_, NU_, false, true>(c, J) : launch_small<NX_, NU_, false, false>(c, J); \
+    return true;                                                                                    \
   }
   NDLQR_SMALL_CASE(12, 4)
   NDLQR_SMALL_CASE(6, 3)
@@ -376,8 +402,19 @@ int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
   return NDLQR_OK;
 }
 
+int ndlqr_hip_set_fuse_level(NdlqrHipCtx* c, int J) {
+  if (!c) return NDLQR_ERR_INVALID;
+  c->fuse_level = J;
+  return NDLQR_OK;
+}
+
 int ndlqr_hip_download_factors(NdlqrHipCtx* c, int p, double* fact) {
   if (!c || !fact || p < 0 || p >= c->d.batch) return NDLQR_ERR_INVALID;
+  if (!(c->flags & (NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_GENERIC))) {
+    g_last_error = "factor download needs NDLQR_FLAG_KEEP_FACT set before the solve";
+    fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+    return NDLQR_ERR_INVALID;
+  }
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   const size_t count = (size_t)d.K * d.N * d.fb;

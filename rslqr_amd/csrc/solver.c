@@ -239,7 +239,9 @@ int ndlqr_Solve(NdLqrSolver* solver) {
     return NDLQR_ERR_NO_DEVICE;
   }
   NdlqrHipCtx* ctx = (NdlqrHipCtx*)ndlqr_BatchDeviceContext(bs);
-  ndlqr_hip_set_flags(ctx, ndlqr_hip_get_flags(ctx) | NDLQR_FLAG_PROFILE);
+  /* a single solver keeps the whole factorisation on the device, like the reference keeps it in
+   * solver->fact (ndlqr_SyncFactorsToHost copies it out on demand) */
+  ndlqr_hip_set_flags(ctx, ndlqr_hip_get_flags(ctx) | NDLQR_FLAG_PROFILE | NDLQR_FLAG_KEEP_FACT);
   ndlqr_hip_profile_reset(ctx);
   int err = ndlqr_batch_upload_from_mirrors(bs, solver->data, solver->diagonals, solver->soln->data);
   if (err) return err;

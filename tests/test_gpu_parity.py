@@ -32,13 +32,20 @@ SHAPES = [(6, 3, 8), (6, 3, 16), (6, 3, 64), (12, 4, 8), (12, 4, 16), (12, 4, 64
           (3, 1, 2), (1, 1, 4), (7, 9, 16)]
 
 
-@pytest.mark.parametrize("n,m,N", SHAPES)
-@pytest.mark.parametrize("flags", ["generic", "default"])
+@pytest.mark.parametrize("n,m,N", SHAPES + [(12, 4, 256), (6, 3, 128)])
+@pytest.mark.parametrize("flags", ["generic", "default", "J2", "J4", "J5", "stream"])
 def test_batch_strict_is_bit_exact(ndlqr, oracle, n, m, N, flags):
-    batch = 5
+    """Strict FP: solution AND complete factor array identical to the oracle, for the generic
+    kernels, the default specialised path and several fuse levels J of the boundary-first path
+    (J = 99: pure level-by-level streaming)."""
+    batch = 3 if N >= 128 else 5
     probs = [synth(ndlqr, n, m, N, 100 + p) for p in range(batch)]
-    fl = ndlqr.FLAG_STRICT_FP | (ndlqr.FLAG_GENERIC if flags == "generic" else 0)
+    fl = ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT | (ndlqr.FLAG_GENERIC if flags == "generic" else 0)
     bs = ndlqr.BatchSolver(n, m, N, batch, flags=fl)
+    if flags[0] == "J":
+        bs.set_fuse_level(int(flags[1:]))
+    elif flags == "stream":
+        bs.set_fuse_level(99)
     bs.initialize_flat(*stack(probs))
     assert bs.solve() == 0
     sol = bs.solutions()
@@ -69,6 +76,11 @@ def test_batch_fast_within_tolerance(ndlqr, oracle, n, m, N, flags):
     # a second solve on the resident inputs gives the same answer (no state leaks between solves)
     assert bs.solve() == 0
     assert np.array_equal(bs.solutions(), sol)
+    with pytest.raises(RuntimeError):  # factors are only materialised with NDLQR_FLAG_KEEP_FACT
+        if flags != "generic":
+            bs.factors(0)
+        else:
+            raise RuntimeError("generic path always keeps the factors")
     bs.close()
 
 
