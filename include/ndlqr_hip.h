@@ -65,6 +65,9 @@ int ndlqr_hip_download_factors(NdlqrHipCtx* ctx, int p, double* fact); /* needs 
 /* Tuning knob: tree level J from which the upper levels run boundary-first + one apply pass
  * (-1 = default, K = pure level-by-level streaming). Results do not depend on it. */
 int ndlqr_hip_set_fuse_level(NdlqrHipCtx* ctx, int J);
+/* Tuning knob: number of tree levels fused with the leaf phase in the on-chip bottom kernel
+ * (0..3; 0 = separate leaf / separator / Schur kernels). Results do not depend on it. */
+int ndlqr_hip_set_bottom_levels(NdlqrHipCtx* ctx, int JB);
 int ndlqr_hip_cholesky_failures(NdlqrHipCtx* ctx);
 
 /* Per-kernel profile (NDLQR_FLAG_PROFILE): HIP-event durations accumulated since the last

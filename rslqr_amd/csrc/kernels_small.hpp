@@ -188,11 +188,182 @@ __global__ __launch_bounds__(64) void separator_small(Dims d, int l, const doubl
   }
 }
 
+// ------------------------------------------------------------------------------------- separator, 2 per wave
+// Same mathematics as separator_small, organised for instruction count: TWO separators per
+// wavefront (one per 32-lane half), so every vector instruction of the inner products, the
+// Cholesky and the substitutions serves two separators; the factor L is broadcast through LDS
+// (row-major copy for the transposed sweep, transposed copy for the forward sweep) instead of
+// v_readlane pairs. Per half: lanes 0..NX-1 own row i of S-bar, lanes NX..2NX-1 row i of f_a;
+// in the solves lane c < 2NX owns one right-hand-side column, lane 2NX the rhs vector.
+// STRICT keeps the reference's operations (sqrt, divisions) and order; the fast mode replaces
+// the per-column divisions by one reciprocal square root (results within the stated tolerance).
+//   grid (ceil(nsep / 2), batch), block 64.
+template <int NX, int NU, bool STRICT>
+__global__ __launch_bounds__(64) void separator_pair(Dims d, int l, const double* __restrict__ AB,
+                                                     double* F, double* z, double* __restrict__ rec,
+                                                     int* __restrict__ info) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX;
+  static_assert(2 * NX + 1 <= 32, "2 NX + 1 right-hand-side columns must fit a half wavefront");
+  struct alignas(16) Slot {
+    double E[W * NX];    // state+input rows of E(s)
+    double A[W * NX];    // state+input rows of F(s, a)
+    double Fm[2][NN];    // f_a, f_bb row-major [k][c]
+    double L[NN];        // Cholesky factor, row-major
+    double Lt[NN];       // its transpose
+    double zxu[W];       // state+input entries of z(s)
+    double zs[NX];       // z_sep
+    double piv[NX];      // pivot broadcast / reciprocal diagonal
+  };
+  __shared__ Slot slots[2];
+  const int N = d.N, b = blockIdx.y, lane = threadIdx.x;
+  const int h = lane >> 5, hl = lane & 31;
+  const int nsep = N >> (l + 1);
+  const int q = 2 * blockIdx.x + h;
+  const bool live = q < nsep;  // the last block may carry a single separator
+  const int qq = live ? q : nsep - 1;
+  const int half = 1 << l, base = qq * (2 << l), s = base + half - 1;
+  int a, bb;
+  outer_columns(base, l, N, a, bb);
+  Slot& sl = slots[h];
+
+  // ---- stage the operands every lane of the half needs
+  {
+    const double* Es = Fblk(F, d, b, l, s) + NN;
+    const double* Fas = (a >= 0 ? Fblk(F, d, b, a, s) : Fblk(F, d, b, l, s)) + NN;
+    for (int e = hl; e < W * NX / 2; e += 32) {
+      reinterpret_cast<double2*>(sl.E)[e] = reinterpret_cast<const double2*>(Es)[e];
+      reinterpret_cast<double2*>(sl.A)[e] = reinterpret_cast<const double2*>(Fas)[e];
+    }
+    if (hl < W) sl.zxu[hl] = z[((size_t)b * N + s) * ROWS + NX + hl];
+  }
+  double* zs1 = z + ((size_t)b * N + s + 1) * ROWS;
+  const int grp = hl / NX, i = hl - grp * NX;  // grp 0: S-bar rows, 1: f_a rows, 2: idle in P1
+  double ab[W];
+  {
+    const double* arow = AB + (((size_t)b * N + s) * NX + i) * W;
+#pragma unroll
+    for (int k = 0; k < W; ++k) ab[k] = (grp < 2) ? arow[k] : 0.0;
+  }
+  double e1[NX];  // group 0: state row i of E(s+1); group 1: state row i of F(s+1, bb)
+  {
+    const int col = (grp == 0 || bb < 0) ? l : bb;
+    load_row<NX>(Fblk(F, d, b, col, s + 1) + (NX + i) * NX, e1);
+  }
+  const double zl_old = zs1[i], zx_next = zs1[NX + i];
+  __syncthreads();
+
+  // ---- P1: row i of S-bar (group 0) / f_a (group 1)
+  double acc[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) acc[j] = 0.0;
+  const double* M = (grp == 1) ? sl.A : sl.E;
+#pragma unroll
+  for (int k = 0; k < W; ++k)
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
+  if (grp == 0) {
+    double accz = -zl_old;
+#pragma unroll
+    for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], sl.zxu[k], accz);
+    sl.zs[i] = accz - zx_next;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = acc[j] - e1[j];
+  } else if (grp == 1) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      sl.Fm[0][i * NX + j] = acc[j];
+      sl.Fm[1][i * NX + j] = -e1[j];  // f_bb = -(state rows of F(s+1, bb))
+    }
+  }
+
+  // ---- P2: left-looking Cholesky, rows in the registers of group 0, finished entries published
+  //      to LDS (L and L') as soon as they are final
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v = mad<STRICT>(-acc[k], sl.L[j * NX + k], v);
+    if (grp == 0 && i >= j) acc[j] = v;
+    if (grp == 0 && i == j) sl.piv[j] = v;
+    __syncthreads();
+    const double pivot = sl.piv[j];
+    if (!(pivot > 0.0)) ok = false;
+    if constexpr (STRICT) {
+      const double root = sqrt(pivot);
+      if (grp == 0 && i >= j) acc[j] = acc[j] / root;
+    } else {
+      const double rinv = rsqrt(pivot);
+      if (grp == 0 && i >= j) acc[j] = acc[j] * rinv;
+      if (grp == 0 && i == j) sl.piv[j] = rinv;  // reciprocal of L(j,j) for the solves
+    }
+    if (grp == 0 && i >= j) {
+      sl.L[i * NX + j] = acc[j];
+      sl.Lt[j * NX + i] = acc[j];
+    }
+    __syncthreads();
+  }
+  if (!ok && hl == 0 && live) atomicAdd(info + b, 1);
+
+  // ---- P3: one right-hand-side column per lane: L y = x (reads L'), then L' x = y (reads L)
+  const int which = hl / NX, col = hl - which * NX;
+  double x[NX];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) x[k] = (hl == 2 * NX) ? sl.zs[k] : (which < 2 ? sl.Fm[which][k * NX + col] : 0.0);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    if constexpr (STRICT) x[j] = x[j] / sl.L[j * NX + j]; else x[j] = x[j] * sl.piv[j];
+#pragma unroll
+    for (int r = j + 1; r < NX; ++r) x[r] = mad<STRICT>(-sl.Lt[j * NX + r], x[j], x[r]);
+  }
+#pragma unroll
+  for (int j = NX - 1; j >= 0; --j) {
+    if constexpr (STRICT) x[j] = x[j] / sl.L[j * NX + j]; else x[j] = x[j] * sl.piv[j];
+#pragma unroll
+    for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-sl.L[j * NX + r], x[j], x[r]);
+  }
+  // back to row-major in LDS so that the global stores are whole 16-byte-aligned rows
+  __syncthreads();
+  if (hl == 2 * NX) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) sl.zs[k] = x[k];
+  } else if (which < 2) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) sl.Fm[which][k * NX + col] = x[k];
+  }
+  __syncthreads();
+
+  // ---- store: factor of S-bar, f_a, f_bb (lambda rows of knot s+1) and the record f_a|f_bb|z_sep
+  if (live) {
+    double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
+    if (grp == 0) {
+      store_row<NX>(Fblk(F, d, b, l, s + 1) + i * NX, acc);
+      if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) { zs1[k] = sl.zs[k]; myrec[2 * NN + k] = sl.zs[k]; }
+      }
+    }
+    if (grp < 2) {
+      const int colidx = grp == 0 ? a : bb;
+      double row[NX];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) row[c] = sl.Fm[grp][i * NX + c];
+      if (colidx >= 0) {
+        store_row<NX>(Fblk(F, d, b, colidx, s + 1) + i * NX, row);
+        store_row<NX>(myrec + grp * NN + i * NX, row);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------- Schur update
 template <int NX, int NU>
 struct SchurShape {
   static constexpr int ROWS = 2 * NX + NU;
-  static constexpr int KPW = 64 / ROWS;      // knots per wavefront
+  // knots per wavefront: two, i.e. exactly one level-0 subtree, so that the separator record is
+  // wave-uniform at every level (scalar loads). Wider packing for ROWS <= 16 is left for later.
+  static constexpr int KPW = 2;
+  static_assert(2 * ROWS <= 64, "two knots (2 * (2 NX + NU) rows) must fit a wavefront");
   static constexpr int WAVES = 4;
   static constexpr int KPB = KPW * WAVES;    // knots per workgroup
   static constexpr int NREC = KPB / 2;       // subtrees a workgroup can span (level 0)
@@ -209,48 +380,30 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
   using Sh = SchurShape<NX, NU>;
   constexpr int ROWS = Sh::ROWS, KPW = Sh::KPW, KPB = Sh::KPB, REC = Sh::REC, WAVES = Sh::WAVES;
   static_assert(KPW >= 2 && (KPB & (KPB - 1)) == 0, "knots per workgroup must be a power of two");
-  constexpr int NRECS = BOUNDARY ? WAVES : Sh::NREC;
-  __shared__ __attribute__((aligned(16))) double rec[NRECS][REC];
   const int N = d.N, b = blockIdx.y;
   const int half = 1 << l, T = 2 << l;
-  const int first = BOUNDARY ? 0 : blockIdx.x * KPB;
-  const int nrec = BOUNDARY ? WAVES : ((T >= KPB) ? 1 : KPB / T);
   const int nsub = N >> (l + 1);
-
-  // cooperative load of the separator records every knot of this workgroup needs
-  for (int q = 0; q < nrec; ++q) {
-    int qs;
-    if (BOUNDARY) {
-      const int sub = blockIdx.x * WAVES + q;
-      if (sub >= nsub) break;
-      qs = sub * T + half - 1;
-    } else {
-      qs = (((first + q * T) >> (l + 1)) << (l + 1)) + half - 1;
-    }
-    const double* src = recs + ((size_t)b * N + qs) * REC;
-    for (int e = threadIdx.x; e < REC; e += 256) rec[q][e] = src[e];
-  }
-  __syncthreads();
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kn = lane / ROWS, r = lane - kn * ROWS;
-  int i, q;
+  int i;
   if (BOUNDARY) {
     const int sub = blockIdx.x * WAVES + wave;
     if (sub >= nsub || kn >= 2) return;
     i = sub * T + (kn == 0 ? 0 : T - 1);
-    q = wave;
   } else {
     if (kn >= KPW) return;
-    i = first + wave * KPW + kn;
-    q = (T >= KPB) ? 0 : (i - first) / T;
+    i = blockIdx.x * KPB + wave * KPW + kn;
   }
   const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
   int a, bb;
   outer_columns(base, l, N, a, bb);
-  const double* fa = rec[q];
-  const double* fb = rec[q] + NX * NX;
-  const double* zsep = rec[q] + 2 * NX * NX;
+  // All knots of a wavefront sit in the same level-l subtree (KPW consecutive, aligned knots),
+  // so the separator record address is wave-uniform: scalar loads, SGPR operands in the FMAs.
+  const int qs = __builtin_amdgcn_readfirstlane(s);
+  const double* rcd = recs + ((size_t)b * N + qs) * REC;
+  const double* fa = rcd;
+  const double* fb = rcd + NX * NX;
+  const double* zsep = rcd + 2 * NX * NX;
   const bool left = i <= s;
   const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
 
@@ -426,6 +579,285 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
     }
   }
   *zp = zz;
+}
+
+// ------------------------------------------------------------------------------------- bottom
+// Leaf phase + tree levels 0..JB-1 in ONE launch, everything on chip: a workgroup owns 2^JB
+// consecutive knots, each wavefront two of them (lane = (knot, row)) with its rows of E, of the
+// two outer columns and its rhs entry in registers from the leaf computation to the hand-off.
+// Per level: the knots next to a separator publish the rows the separator needs in LDS; every
+// wavefront computes the separator of its own subtree (redundantly for l > 0 -- no result
+// broadcast, no idle waves), updates its two knots and rotates the column roles (see
+// apply_small). Written back: column JB and the live outer column of every knot plus its rhs
+// block -- what separator_*(JB) / schur / apply expect -- and, with KEEP, the finished columns
+// 0..JB-1. Arithmetic and order per element are those of leaf_generic + separator_small +
+// schur_small run level by level.
+//   grid (N >> JB, batch), block 32 << JB threads. Requires N > 2^JB.
+template <int NX, int NU, bool STRICT, bool KEEP, int JB>
+__global__ __launch_bounds__(32 << JB) void bottom_small(Dims d, const double* __restrict__ AB,
+                                                         const double* __restrict__ QR,
+                                                         const double* __restrict__ rhs, double* F,
+                                                         double* z, int* __restrict__ info) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX;
+  constexpr int NK = 1 << JB, NWAVE = NK / 2;
+  static_assert(2 * ROWS <= 64 && 3 * NX <= 64, "two knots per wavefront, three lane groups of NX");
+  struct alignas(16) Xchg {   // what a separator reads from its two neighbours
+    double Exu[W * NX];       // state+input rows of E(s)
+    double Axu[W * NX];       // state+input rows of the left outer column of knot s
+    double E1x[NN];           // state rows of E(s+1)
+    double B1x[NN];           // state rows of the right outer column of knot s+1
+    double zxu[W];            // z(s) state+input
+    double z1[2 * NX];        // z(s+1) lambda | state
+  };
+  struct alignas(16) Priv {   // per wavefront: staged inputs, solved right-hand sides
+    double ab[2][NX * W];     // [A | B] of the wavefront's two knots
+    double Fm[2][NN];         // f_a, f_bb row-major [k][c]
+    double zs[NX];
+  };
+  __shared__ Xchg xs[NK / 2];
+  __shared__ Priv pv[NWAVE];
+
+  const int N = d.N, b = blockIdx.y;
+  const int wgbase = blockIdx.x * NK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kn = lane / ROWS, r = lane - kn * ROWS;
+  const bool has_knot = kn < 2;
+  const int i = wgbase + 2 * wave + (has_knot ? kn : 1);  // idle lanes shadow knot 1 (no stores)
+  const bool lam = r < NX;
+  Priv& me = pv[wave];
+
+  // ---- stage [A | B] of my two knots (contiguous in memory)
+  {
+    const double2* src = reinterpret_cast<const double2*>(AB + ((size_t)b * N + wgbase + 2 * wave) * NX * W);
+    double2* dst = reinterpret_cast<double2*>(&me.ab[0][0]);
+    for (int e = lane; e < NX * W; e += 64) dst[e] = src[e];
+  }
+  __syncthreads();
+
+  // ---- leaf phase in registers (ndlqr_SolveLeaf): own block O, block P towards the previous knot
+  double E[NX], Ca[NX], Cb[NX], zz;
+  {
+    const double* abk = me.ab[has_knot ? kn : 1];
+    const double* qr = QR + ((size_t)b * N + i) * W;
+    const double* r0 = rhs + ((size_t)b * N + i) * ROWS;
+    const bool last = (i == N - 1);
+    double sc = 1.0;
+    if (!lam) {
+      const double qv = qr[r - NX];
+      sc = qv / sqrt(qv);
+      if (has_knot && !(qv > 0.0) && !(last && r >= 2 * NX)) atomicAdd(info + b, 1);
+    }
+    double O[NX], P[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      double o;
+      if (lam) o = (i == 0) ? -abk[c * W + r] : 0.0;
+      else if (i == 0 && r < 2 * NX) o = 0.0;
+      else o = (abk[c * W + (r - NX)] / sc) / sc;
+      O[c] = last ? 0.0 : o;
+      P[c] = (!lam && r < 2 * NX && c == r - NX) ? (-1.0 / sc) / sc : 0.0;
+    }
+    const bool even = (i & 1) == 0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      E[c] = even ? O[c] : P[c];
+      Ca[c] = (even && i > 0) ? P[c] : 0.0;
+      Cb[c] = even ? 0.0 : O[c];
+    }
+    const double rv = r0[r];
+    if (i == 0) {
+      if (lam) zz = mad<STRICT>(-qr[r], rv, -r0[NX + r]);
+      else if (r < 2 * NX) zz = -r0[r - NX];
+      else zz = (rv / sc) / sc;
+    } else {
+      if (lam) zz = rv;
+      else if (r < 2 * NX || !last) zz = (rv / sc) / sc;
+      else zz = rv;
+    }
+  }
+
+  // ---- levels 0 .. JB-1
+#pragma unroll
+  for (int l = 0; l < JB; ++l) {
+    const int half = 1 << l, T = 2 << l;
+    const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+    int a, bb;
+    outer_columns(base, l, N, a, bb);
+    const int sub = (base - wgbase) >> (l + 1);
+    Xchg& xc = xs[sub];
+    const bool left = i <= s;
+    const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+    const bool active = !lam || calc_lambda;
+
+    // publish what the separator needs from knots s and s+1
+    if (has_knot && i == s && !lam) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) { xc.Exu[(r - NX) * NX + c] = E[c]; xc.Axu[(r - NX) * NX + c] = Ca[c]; }
+      xc.zxu[r - NX] = zz;
+    }
+    if (has_knot && i == s + 1) {
+      if (lam) xc.z1[r] = zz;
+      else if (r < 2 * NX) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) { xc.E1x[(r - NX) * NX + c] = E[c]; xc.B1x[(r - NX) * NX + c] = Cb[c]; }
+        xc.z1[NX + (r - NX)] = zz;
+      }
+    }
+    __syncthreads();
+
+    // separator of my subtree (same code path as separator_small, operands from LDS)
+    {
+      const int grp = lane / NX, gi = lane - grp * NX;
+      double ab[W];
+      {
+        const double* arow = AB + (((size_t)b * N + s) * NX + gi) * W;
+#pragma unroll
+        for (int k = 0; k < W; ++k) ab[k] = (grp < 2) ? arow[k] : 0.0;
+      }
+      double acc[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) acc[j] = 0.0;
+      const double* M = (grp == 1) ? xc.Axu : xc.Exu;
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
+      double accz = 0.0;
+      if (grp == 0) {
+        accz = -xc.z1[gi];
+#pragma unroll
+        for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], xc.zxu[k], accz);
+        accz = accz - xc.z1[NX + gi];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) acc[j] = acc[j] - xc.E1x[gi * NX + j];
+      } else if (grp == 2) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) acc[j] = -xc.B1x[gi * NX + j];
+      }
+      double Lr[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Lr[j] = acc[j];
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        if (ok) {
+          double v = Lr[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) v = mad<STRICT>(-Lr[k], readlane_f64(Lr[k], j), v);
+          if (gi >= j) Lr[j] = v;
+          const double pivot = readlane_f64(Lr[j], j);
+          if (!(pivot > 0.0)) {
+            ok = false;
+          } else {
+            const double root = sqrt(pivot);
+            if (gi >= j) Lr[j] = Lr[j] / root;
+          }
+        }
+      }
+      const bool owner = (s + 1 - wgbase) / 2 == wave;  // the wavefront that holds knot s+1
+      if (!ok && lane == 0 && owner) atomicAdd(info + b, 1);
+      if (grp == 0) me.zs[gi] = accz;
+      if (grp == 1 || grp == 2) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) me.Fm[grp - 1][gi * NX + j] = acc[j];
+      }
+      __syncthreads();
+      const int which = lane / NX, col = lane - which * NX;
+      double x[NX];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) x[k] = (lane == 2 * NX) ? me.zs[k] : (which < 2 ? me.Fm[which][k * NX + col] : 0.0);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        x[j] = x[j] / readlane_f64(Lr[j], j);
+#pragma unroll
+        for (int rr = j + 1; rr < NX; ++rr) x[rr] = mad<STRICT>(-readlane_f64(Lr[j], rr), x[j], x[rr]);
+      }
+#pragma unroll
+      for (int j = NX - 1; j >= 0; --j) {
+        x[j] = x[j] / readlane_f64(Lr[j], j);
+#pragma unroll
+        for (int rr = 0; rr < j; ++rr) x[rr] = mad<STRICT>(-readlane_f64(Lr[rr], j), x[j], x[rr]);
+      }
+      __syncthreads();
+      if (lane == 2 * NX) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) me.zs[k] = x[k];
+      } else if (which < 2) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) me.Fm[which][k * NX + col] = x[k];
+      }
+      if (KEEP && owner && grp == 0) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lr);
+      __syncthreads();
+    }
+
+    // Schur update of my two knots, then rotate the column roles
+    const double* fa = me.Fm[0];
+    const double* fb = me.Fm[1];
+    if (KEEP && has_knot && active) store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
+    if (active) {
+      if (a >= 0) {
+        double acc[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc[c] = left ? Ca[c] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+#pragma unroll
+          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fa[k * NX + c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Ca[c] = acc[c];
+      }
+      if (bb >= 0) {
+        double acc[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc[c] = left ? 0.0 : Cb[c];
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+#pragma unroll
+          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fb[k * NX + c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Cb[c] = acc[c];
+      }
+#pragma unroll
+      for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], me.zs[k], zz);
+    } else if (i == s + 1) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        if (a >= 0) Ca[c] = fa[r * NX + c];
+        if (bb >= 0) Cb[c] = fb[r * NX + c];
+      }
+      zz = me.zs[r];
+    } else {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) { if (left) Cb[c] = 0.0; else Ca[c] = 0.0; }
+    }
+    const bool left_child = (base & T) == 0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      if (left_child) { E[c] = Cb[c]; Cb[c] = 0.0; }
+      else            { E[c] = Ca[c]; Ca[c] = 0.0; }
+    }
+    __syncthreads();  // xs / pv are reused by the next level
+  }
+
+  // ---- hand-off: column JB, the live outer column at level JB, the rhs block
+  if (has_knot) {
+    const int l = JB;
+    const int base = (i >> (l + 1)) << (l + 1), s = base + (1 << l) - 1;
+    int a, bb;
+    outer_columns(base, l, N, a, bb);
+    const bool calc_lambda = (i == 0) || (i & ((1 << l) - 1)) != 0;
+    // lambda rows of column JB that are still structural zeros / hold a Cholesky factor written
+    // by a later separator are not touched (same rule as the level kernels)
+    const bool real_row = !lam || calc_lambda || ((i & ((1 << l) - 1)) == 0 && false);
+    if (real_row || lam) {
+      // E: every row is meaningful here except lambda rows not yet eliminated (zeros) -- writing
+      // the zeros is harmless and keeps re-solves free of stale data
+      store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
+    }
+    if (i <= s) { if (a >= 0) store_row<NX>(Fblk(F, d, b, a, i) + r * NX, Ca); }
+    else        { if (bb >= 0) store_row<NX>(Fblk(F, d, b, bb, i) + r * NX, Cb); }
+    z[((size_t)b * N + i) * ROWS + r] = zz;
+  }
 }
 
 }  // namespace ndlqr

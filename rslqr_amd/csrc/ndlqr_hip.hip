@@ -67,6 +67,8 @@ struct NdlqrHipCtx {
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
+  int sep_variant; // 0 = separator_pair (two per wave), 1 = separator_small (one per wave)
+  int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;
   bool timing_pending;
@@ -113,6 +115,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
   c->fuse_level = -1;
+  c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
+  c->sep_variant = getenv("NDLQR_SEP_VARIANT") ? atoi(getenv("NDLQR_SEP_VARIANT")) : 0;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
@@ -257,20 +261,43 @@ static int launch_generic(NdlqrHipCtx* c) {
 // Levels J..K-1 ("boundary-first"): separator + Schur on the two boundary knots of every subtree
 // (tiny grids), then ONE apply_small pass that takes every knot through all those levels in
 // registers. J = K disables the second form (pure level-by-level streaming).
+template <int NX, int NU, bool STRICT, bool KEEP, int JB>
+static void launch_bottom(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  ScopedSlot t(c, SLOT_BOTTOM);
+  hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), 0,
+                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+}
+
 template <int NX, int NU, bool STRICT, bool KEEP>
 static int launch_small(NdlqrHipCtx* c, int J) {
   const ndlqr::Dims& d = c->d;
   using Sh = ndlqr::SchurShape<NX, NU>;
-  {
-    ScopedSlot t(c, SLOT_LEAF);
-    hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
-                       c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+  // leaf + levels 0..JB-1 fused on chip when the horizon is long enough, else the leaf kernel
+  int JB = c->bottom_levels;
+  if (JB > 3) JB = 3;
+  while (JB > 0 && d.K <= JB) --JB;
+  if (JB > J) JB = J;
+  switch (JB) {
+    case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c); break;
+    case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c); break;
+    case 1: launch_bottom<NX, NU, STRICT, KEEP, 1>(c); break;
+    default: {
+      ScopedSlot t(c, SLOT_LEAF);
+      hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
+                         c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+    }
   }
-  for (int l = 0; l < d.K; ++l) {
+  for (int l = JB; l < d.K; ++l) {
     {
       ScopedSlot t(c, SLOT_SEP);
-      hipLaunchKernelGGL((ndlqr::separator_small<NX, NU, STRICT>), dim3(d.N >> (l + 1), d.batch), dim3(64),
-                         0, c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
+      const int nsep = d.N >> (l + 1);
+      if (c->sep_variant == 0)
+        hipLaunchKernelGGL((ndlqr::separator_pair<NX, NU, STRICT>), dim3((nsep + 1) / 2, d.batch), dim3(64), 0,
+                           c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
+      else
+        hipLaunchKernelGGL((ndlqr::separator_small<NX, NU, STRICT>), dim3(nsep, d.batch), dim3(64), 0,
+                           c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
     }
     if (l < J) {
       ScopedSlot t(c, SLOT_SCHUR);
@@ -405,6 +432,12 @@ int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
 int ndlqr_hip_set_fuse_level(NdlqrHipCtx* c, int J) {
   if (!c) return NDLQR_ERR_INVALID;
   c->fuse_level = J;
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_set_bottom_levels(NdlqrHipCtx* c, int JB) {
+  if (!c || JB < 0) return NDLQR_ERR_INVALID;
+  c->bottom_levels = JB;
   return NDLQR_OK;
 }
 

@@ -33,7 +33,8 @@ SHAPES = [(6, 3, 8), (6, 3, 16), (6, 3, 64), (12, 4, 8), (12, 4, 16), (12, 4, 64
 
 
 @pytest.mark.parametrize("n,m,N", SHAPES + [(12, 4, 256), (6, 3, 128)])
-@pytest.mark.parametrize("flags", ["generic", "default", "J2", "J4", "J5", "stream"])
+@pytest.mark.parametrize("flags", ["generic", "default", "J2", "J4", "J5", "stream", "B0J3", "B1J2", "B2J2", "B3J3",
+                                   "B3J9"])
 def test_batch_strict_is_bit_exact(ndlqr, oracle, n, m, N, flags):
     """Strict FP: solution AND complete factor array identical to the oracle, for the generic
     kernels, the default specialised path and several fuse levels J of the boundary-first path
@@ -44,6 +45,9 @@ def test_batch_strict_is_bit_exact(ndlqr, oracle, n, m, N, flags):
     bs = ndlqr.BatchSolver(n, m, N, batch, flags=fl)
     if flags[0] == "J":
         bs.set_fuse_level(int(flags[1:]))
+    elif flags[0] == "B":  # bottom levels / fuse level
+        bs.set_bottom_levels(int(flags[1]))
+        bs.set_fuse_level(int(flags[3:]))
     elif flags == "stream":
         bs.set_fuse_level(99)
     bs.initialize_flat(*stack(probs))
