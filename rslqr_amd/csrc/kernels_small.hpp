@@ -356,6 +356,174 @@ __global__ __launch_bounds__(64) void separator_pair(Dims d, int l, const double
   }
 }
 
+// ------------------------------------------------------------------------------------- separator core
+// Shared by separator_one and bottom_small: the level-l separator of one subtree computed by ONE
+// wavefront from operands already in LDS. Written for instruction count: no data-dependent
+// branches (a non-positive pivot only raises a flag; NaNs then propagate like in the reference),
+// the 2 NX + 1 right-hand-side columns live in a 32-wide LDS panel so that no lane needs a
+// select; L stays in the registers of lanes 0..NX-1 and is broadcast with v_readlane.
+template <int NX, int NU>
+struct alignas(16) SepIn {      // what a separator reads from its two neighbours
+  double Exu[(NX + NU) * NX];   // state+input rows of E(s)
+  double Axu[(NX + NU) * NX];   // state+input rows of the left outer column of knot s
+  double E1x[NX * NX];          // state rows of E(s+1)
+  double B1x[NX * NX];          // state rows of the right outer column of knot s+1
+  double zxu[NX + NU];          // z(s) state+input
+  double z1[2 * NX];            // z(s+1) lambda | state
+};
+template <int NX>
+struct alignas(16) SepOut {
+  static constexpr int LD = 32;  // panel row length: [f_a (NX) | f_bb (NX) | z_sep | pad]
+  double X[NX * LD];             // right-hand sides in, solutions out; row k, column c
+  double rdiag[NX];              // fast mode: 1 / L(j,j)
+};
+
+// abrow: row gi = lane % NX of [A_s | B_s] (global). Lrow: on return, row gi of the factor for
+// lanes < NX (KEEPL: entries above the diagonal keep their S-bar values, like the reference's
+// in-place factorisation). Returns true when a pivot was not positive. Ends with the solved
+// panel visible to the whole workgroup (it issues __syncthreads()).
+template <int NX, int NU, bool STRICT, bool KEEPL>
+__device__ __forceinline__ bool separator_core(const int lane, const double* __restrict__ abrow,
+                                               const SepIn<NX, NU>& in, SepOut<NX>& out,
+                                               double (&Lrow)[NX]) {
+  constexpr int W = NX + NU, LD = SepOut<NX>::LD;
+  static_assert(2 * NX + 1 <= LD && 2 * NX <= 64, "panel too narrow");
+  const int grp = lane / NX, gi = lane - grp * NX;
+  double ab[W];  // every lane loads a (valid) row: no exec-masked branches around the loads
+  load_row<W>(abrow, ab);
+
+  // P1: row gi of S-bar (group 0) / of f_a (group 1)
+  double acc[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) acc[j] = 0.0;
+  const double* M = (grp == 1) ? in.Axu : in.Exu;
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
+  }
+  if (grp == 0) {
+    double accz = -in.z1[gi];
+#pragma unroll
+    for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], in.zxu[k], accz);
+    out.X[gi * LD + 2 * NX] = accz - in.z1[NX + gi];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = acc[j] - in.E1x[gi * NX + j];
+  } else if (grp == 1) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      out.X[gi * LD + j] = acc[j];
+      out.X[gi * LD + NX + j] = -in.B1x[gi * NX + j];  // f_bb = -(state rows of F(s+1, bb))
+    }
+  }
+
+  // P2: left-looking Cholesky on the registers of group 0 (every lane runs it; rows of other
+  // groups are don't-cares), row j broadcast with v_readlane; finished columns go to LDS.
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v = mad<STRICT>(-acc[k], readlane_f64(acc[k], j), v);
+    if constexpr (KEEPL) { if (gi >= j) acc[j] = v; } else { acc[j] = v; }
+    const double pivot = readlane_f64(acc[j], j);
+    bad = bad || !(pivot > 0.0);
+    if constexpr (STRICT) {
+      const double root = sqrt(pivot);
+      if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] / root; } else { acc[j] = acc[j] / root; }
+    } else {
+      const double rinv = rsqrt(pivot);
+      if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] * rinv; } else { acc[j] = acc[j] * rinv; }
+      if (lane == 0) out.rdiag[j] = rinv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) Lrow[j] = acc[j];
+  __syncthreads();
+
+  // P3: one right-hand-side column per lane (lanes >= LD repeat a column: same values)
+  const int col = lane & (LD - 1);
+  double x[NX];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) x[k] = out.X[k * LD + col];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
+#pragma unroll
+    for (int r = j + 1; r < NX; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[j], r), x[j], x[r]);
+  }
+#pragma unroll
+  for (int j = NX - 1; j >= 0; --j) {
+    if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
+#pragma unroll
+    for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[r], j), x[j], x[r]);
+  }
+  __syncthreads();
+  if (lane < LD) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) out.X[k * LD + col] = x[k];
+  }
+  __syncthreads();
+  return bad;
+}
+
+// One wavefront per separator: stage the operands (whole rows, 16-byte loads), run the core,
+// store the record f_a | f_bb | z_sep and the lambda rows of knot s+1.
+//   grid (N >> (l+1), batch), block 64.
+template <int NX, int NU, bool STRICT, bool KEEP>
+__global__ __launch_bounds__(64, 4) void separator_one(Dims d, int l, const double* __restrict__ AB,
+                                                    double* F, double* z, double* __restrict__ rec,
+                                                    int* __restrict__ info) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, LD = SepOut<NX>::LD;
+  __shared__ SepIn<NX, NU> in;
+  __shared__ SepOut<NX> out;
+  const int N = d.N, b = blockIdx.y, lane = threadIdx.x;
+  const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
+  int a, bb;
+  outer_columns(base, l, N, a, bb);
+  {
+    const double2* Es = reinterpret_cast<const double2*>(Fblk(F, d, b, l, s) + NN);
+    const double2* Fas = reinterpret_cast<const double2*>(Fblk(F, d, b, a >= 0 ? a : l, s) + NN);
+    const double2* E1 = reinterpret_cast<const double2*>(Fblk(F, d, b, l, s + 1) + NN);
+    const double2* B1 = reinterpret_cast<const double2*>(Fblk(F, d, b, bb >= 0 ? bb : l, s + 1) + NN);
+    for (int e = lane; e < W * NX / 2; e += 64) {
+      reinterpret_cast<double2*>(in.Exu)[e] = Es[e];
+      reinterpret_cast<double2*>(in.Axu)[e] = Fas[e];
+    }
+    for (int e = lane; e < NN / 2; e += 64) {
+      reinterpret_cast<double2*>(in.E1x)[e] = E1[e];
+      reinterpret_cast<double2*>(in.B1x)[e] = B1[e];
+    }
+    const double* zs = z + ((size_t)b * N + s) * ROWS;
+    if (lane < W) in.zxu[lane] = zs[NX + lane];
+    if (lane < 2 * NX) in.z1[lane] = zs[ROWS + lane];
+  }
+  __syncthreads();
+  double Lrow[NX];
+  const int gi = lane % NX;
+  const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, AB + (((size_t)b * N + s) * NX + gi) * W, in, out, Lrow);
+  if (bad && lane == 0) atomicAdd(info + b, 1);
+
+  // stores: rows of the solved panel
+  double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
+  const int grp = lane / NX;
+  if (grp < 2) {
+    const int colidx = grp == 0 ? a : bb;
+    if (colidx >= 0) {
+      double row[NX];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) row[c] = out.X[gi * LD + grp * NX + c];
+      store_row<NX>(myrec + grp * NN + gi * NX, row);
+      store_row<NX>(Fblk(F, d, b, colidx, s + 1) + gi * NX, row);
+    }
+  } else if (grp == 2) {
+    const double v = out.X[gi * LD + 2 * NX];
+    myrec[2 * NN + gi] = v;
+    z[((size_t)b * N + s + 1) * ROWS + gi] = v;
+  }
+  if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
+}
+
 // ------------------------------------------------------------------------------------- Schur update
 template <int NX, int NU>
 struct SchurShape {
@@ -594,28 +762,20 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
 // schur_small run level by level.
 //   grid (N >> JB, batch), block 32 << JB threads. Requires N > 2^JB.
 template <int NX, int NU, bool STRICT, bool KEEP, int JB>
-__global__ __launch_bounds__(32 << JB) void bottom_small(Dims d, const double* __restrict__ AB,
+__global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double* __restrict__ AB,
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
                                                          double* z, int* __restrict__ info) {
-  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX;
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU;
   constexpr int NK = 1 << JB, NWAVE = NK / 2;
   static_assert(2 * ROWS <= 64 && 3 * NX <= 64, "two knots per wavefront, three lane groups of NX");
-  struct alignas(16) Xchg {   // what a separator reads from its two neighbours
-    double Exu[W * NX];       // state+input rows of E(s)
-    double Axu[W * NX];       // state+input rows of the left outer column of knot s
-    double E1x[NN];           // state rows of E(s+1)
-    double B1x[NN];           // state rows of the right outer column of knot s+1
-    double zxu[W];            // z(s) state+input
-    double z1[2 * NX];        // z(s+1) lambda | state
+  struct alignas(16) Priv {   // per wavefront
+    double ab[2][NX * W];     // [A | B] of the wavefront's two knots (leaf phase)
+    SepOut<NX> so;            // separator panel / factor of the wavefront's subtree
   };
-  struct alignas(16) Priv {   // per wavefront: staged inputs, solved right-hand sides
-    double ab[2][NX * W];     // [A | B] of the wavefront's two knots
-    double Fm[2][NN];         // f_a, f_bb row-major [k][c]
-    double zs[NX];
-  };
-  __shared__ Xchg xs[NK / 2];
+  __shared__ SepIn<NX, NU> xs[NK / 2];
   __shared__ Priv pv[NWAVE];
+  constexpr int LD = SepOut<NX>::LD;
 
   const int N = d.N, b = blockIdx.y;
   const int wgbase = blockIdx.x * NK;
@@ -684,7 +844,7 @@ __global__ __launch_bounds__(32 << JB) void bottom_small(Dims d, const double* _
     int a, bb;
     outer_columns(base, l, N, a, bb);
     const int sub = (base - wgbase) >> (l + 1);
-    Xchg& xc = xs[sub];
+    SepIn<NX, NU>& xc = xs[sub];
     const bool left = i <= s;
     const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
     const bool active = !lam || calc_lambda;
@@ -705,94 +865,21 @@ __global__ __launch_bounds__(32 << JB) void bottom_small(Dims d, const double* _
     }
     __syncthreads();
 
-    // separator of my subtree (same code path as separator_small, operands from LDS)
+    // separator of my subtree (every wavefront of the subtree computes it: no result broadcast)
     {
-      const int grp = lane / NX, gi = lane - grp * NX;
-      double ab[W];
-      {
-        const double* arow = AB + (((size_t)b * N + s) * NX + gi) * W;
-#pragma unroll
-        for (int k = 0; k < W; ++k) ab[k] = (grp < 2) ? arow[k] : 0.0;
-      }
-      double acc[NX];
-#pragma unroll
-      for (int j = 0; j < NX; ++j) acc[j] = 0.0;
-      const double* M = (grp == 1) ? xc.Axu : xc.Exu;
-#pragma unroll
-      for (int k = 0; k < W; ++k)
-#pragma unroll
-        for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
-      double accz = 0.0;
-      if (grp == 0) {
-        accz = -xc.z1[gi];
-#pragma unroll
-        for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], xc.zxu[k], accz);
-        accz = accz - xc.z1[NX + gi];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) acc[j] = acc[j] - xc.E1x[gi * NX + j];
-      } else if (grp == 2) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) acc[j] = -xc.B1x[gi * NX + j];
-      }
-      double Lr[NX];
-#pragma unroll
-      for (int j = 0; j < NX; ++j) Lr[j] = acc[j];
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < NX; ++j) {
-        if (ok) {
-          double v = Lr[j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) v = mad<STRICT>(-Lr[k], readlane_f64(Lr[k], j), v);
-          if (gi >= j) Lr[j] = v;
-          const double pivot = readlane_f64(Lr[j], j);
-          if (!(pivot > 0.0)) {
-            ok = false;
-          } else {
-            const double root = sqrt(pivot);
-            if (gi >= j) Lr[j] = Lr[j] / root;
-          }
-        }
-      }
+      double Lrow[NX];
+      const int gi = lane % NX;
+      const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, AB + (((size_t)b * N + s) * NX + gi) * W, xc,
+                                                            me.so, Lrow);
       const bool owner = (s + 1 - wgbase) / 2 == wave;  // the wavefront that holds knot s+1
-      if (!ok && lane == 0 && owner) atomicAdd(info + b, 1);
-      if (grp == 0) me.zs[gi] = accz;
-      if (grp == 1 || grp == 2) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) me.Fm[grp - 1][gi * NX + j] = acc[j];
-      }
-      __syncthreads();
-      const int which = lane / NX, col = lane - which * NX;
-      double x[NX];
-#pragma unroll
-      for (int k = 0; k < NX; ++k) x[k] = (lane == 2 * NX) ? me.zs[k] : (which < 2 ? me.Fm[which][k * NX + col] : 0.0);
-#pragma unroll
-      for (int j = 0; j < NX; ++j) {
-        x[j] = x[j] / readlane_f64(Lr[j], j);
-#pragma unroll
-        for (int rr = j + 1; rr < NX; ++rr) x[rr] = mad<STRICT>(-readlane_f64(Lr[j], rr), x[j], x[rr]);
-      }
-#pragma unroll
-      for (int j = NX - 1; j >= 0; --j) {
-        x[j] = x[j] / readlane_f64(Lr[j], j);
-#pragma unroll
-        for (int rr = 0; rr < j; ++rr) x[rr] = mad<STRICT>(-readlane_f64(Lr[rr], j), x[j], x[rr]);
-      }
-      __syncthreads();
-      if (lane == 2 * NX) {
-#pragma unroll
-        for (int k = 0; k < NX; ++k) me.zs[k] = x[k];
-      } else if (which < 2) {
-#pragma unroll
-        for (int k = 0; k < NX; ++k) me.Fm[which][k * NX + col] = x[k];
-      }
-      if (KEEP && owner && grp == 0) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lr);
-      __syncthreads();
+      if (bad && lane == 0 && owner) atomicAdd(info + b, 1);
+      if (KEEP && owner && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
     }
 
     // Schur update of my two knots, then rotate the column roles
-    const double* fa = me.Fm[0];
-    const double* fb = me.Fm[1];
+    const double* fa = me.so.X;           // f_a(k, c)  = X[k * LD + c]
+    const double* fb = me.so.X + NX;      // f_bb(k, c) = X[k * LD + NX + c]
+    const double* zsp = me.so.X + 2 * NX; // z_sep(k)   = X[k * LD + 2 NX]
     if (KEEP && has_knot && active) store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
     if (active) {
       if (a >= 0) {
@@ -802,7 +889,7 @@ __global__ __launch_bounds__(32 << JB) void bottom_small(Dims d, const double* _
 #pragma unroll
         for (int k = 0; k < NX; ++k)
 #pragma unroll
-          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fa[k * NX + c], acc[c]);
+          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fa[k * LD + c], acc[c]);
 #pragma unroll
         for (int c = 0; c < NX; ++c) Ca[c] = acc[c];
       }
@@ -813,19 +900,19 @@ __global__ __launch_bounds__(32 << JB) void bottom_small(Dims d, const double* _
 #pragma unroll
         for (int k = 0; k < NX; ++k)
 #pragma unroll
-          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fb[k * NX + c], acc[c]);
+          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fb[k * LD + c], acc[c]);
 #pragma unroll
         for (int c = 0; c < NX; ++c) Cb[c] = acc[c];
       }
 #pragma unroll
-      for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], me.zs[k], zz);
+      for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], zsp[k * LD], zz);
     } else if (i == s + 1) {
 #pragma unroll
       for (int c = 0; c < NX; ++c) {
-        if (a >= 0) Ca[c] = fa[r * NX + c];
-        if (bb >= 0) Cb[c] = fb[r * NX + c];
+        if (a >= 0) Ca[c] = fa[r * LD + c];
+        if (bb >= 0) Cb[c] = fb[r * LD + c];
       }
-      zz = me.zs[r];
+      zz = zsp[r * LD];
     } else {
 #pragma unroll
       for (int c = 0; c < NX; ++c) { if (left) Cb[c] = 0.0; else Ca[c] = 0.0; }

@@ -67,7 +67,7 @@ struct NdlqrHipCtx {
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
-  int sep_variant; // 0 = separator_pair (two per wave), 1 = separator_small (one per wave)
+  int sep_variant; // 0 = separator_one (lean core), 1 = separator_small, 2 = separator_pair
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;
@@ -293,6 +293,9 @@ static int launch_small(NdlqrHipCtx* c, int J) {
       ScopedSlot t(c, SLOT_SEP);
       const int nsep = d.N >> (l + 1);
       if (c->sep_variant == 0)
+        hipLaunchKernelGGL((ndlqr::separator_one<NX, NU, STRICT, KEEP>), dim3(nsep, d.batch), dim3(64), 0,
+                           c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
+      else if (c->sep_variant == 2)
         hipLaunchKernelGGL((ndlqr::separator_pair<NX, NU, STRICT>), dim3((nsep + 1) / 2, d.batch), dim3(64), 0,
                            c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
       else
