@@ -199,17 +199,38 @@ def main():
         total_solves = batch * world * args.steps
         value = total_solves / elapsed_max
         leaf_b, level_b = model_b_bytes(n, m, N)
-        # dominant kernel = whichever per-level slot carries the time
-        dom = max((k for k in prof if k != "leaf"), key=lambda k: prof[k][0])
-        if dom == "level":
-            dom_ms, dom_launches = prof["level"]
-        else:  # generic path: separator + schur pair covers one level
-            dom_ms = prof["separator"][0] + prof["schur"][0]
-            dom_launches = prof["schur"][1]
+        # Dominant kernel = the slot with the largest HIP-event time. Its algorithmic bytes are the
+        # SURVEY 8(d) model-(B) bytes of exactly the phases it covers:
+        #   bottom          leaf phase + levels 0..JB-1            (1 launch per step)
+        #   apply           Schur/solution sweep of levels J..K-1  (1 launch per step)
+        #   separator+schur one level each (generic / level-by-level path)
+        K = len(level_b)
+        used = {k: v for k, v in prof.items() if v[1] > 0}
+        dom = max(used, key=lambda k: used[k][0])
+        JB = int(os.environ.get("NDLQR_BOTTOM_LEVELS", "2"))
+        if dom == "bottom":
+            covered = leaf_b + sum(level_b[:JB])
+            dom_ms, dom_launches = used["bottom"]
+        elif dom == "apply":
+            covered = sum(level_b[JB:])
+            dom_ms, dom_launches = used["apply"]
+        else:
+            dom_ms = sum(used[k][0] for k in ("separator", "schur") if k in used)
+            dom_launches = used.get("schur", used.get("separator"))[1]
+            covered = sum(level_b) / K
             dom = "separator+schur"
         avg_ms = dom_ms / max(dom_launches, 1)
-        bytes_per_launch = sum(level_b) * batch / len(level_b)
+        bytes_per_launch = covered * batch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # measured HBM bytes per launch of that kernel: committed PMC summary of the same config
+        # (rocprofv3 cannot run inside this process; profiles/r01_traffic.json says how it was taken)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if (n, m, N, batch, args.flags) == (12, 4, 256, 1024, 0) and dom in tj["kernels"]:
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         whole_solve_gbs = (leaf_b + sum(level_b)) * value / world / 1e9
         result = {
             "metric": "LQR solves/sec (nx=%d,nu=%d,N=%d,batch=%d per GPU)" % (n, m, N, batch),
@@ -223,7 +244,7 @@ def main():
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "flags": args.flags, "cholesky_failures": fails_max},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": dom_launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_solve_model_b_gbs_per_gpu": whole_solve_gbs,

@@ -436,6 +436,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
       if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] * rinv; } else { acc[j] = acc[j] * rinv; }
       if (lane == 0) out.rdiag[j] = rinv;
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the row-j broadcasts (SGPRs) local to their column
   }
 #pragma unroll
   for (int j = 0; j < NX; ++j) Lrow[j] = acc[j];
@@ -451,12 +452,14 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
     if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
 #pragma unroll
     for (int r = j + 1; r < NX; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[j], r), x[j], x[r]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int j = NX - 1; j >= 0; --j) {
     if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
 #pragma unroll
     for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[r], j), x[j], x[r]);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   if (lane < LD) {
@@ -801,21 +804,27 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     const double* qr = QR + ((size_t)b * N + i) * W;
     const double* r0 = rhs + ((size_t)b * N + i) * ROWS;
     const bool last = (i == N - 1);
-    double sc = 1.0;
+    // Row scaling by the diagonal Q (state rows) / R (input rows). STRICT reproduces the
+    // reference's two divisions by L = q / sqrt(q) of its dense Cholesky solve; the fast mode
+    // multiplies by one reciprocal (L * L == q up to rounding).
+    double sc = 1.0, rq = 1.0;
     if (!lam) {
       const double qv = qr[r - NX];
-      sc = qv / sqrt(qv);
+      if constexpr (STRICT) sc = qv / sqrt(qv); else rq = 1.0 / qv;
       if (has_knot && !(qv > 0.0) && !(last && r >= 2 * NX)) atomicAdd(info + b, 1);
     }
+    auto scale = [&](double v) -> double {
+      if constexpr (STRICT) return (v / sc) / sc; else return v * rq;
+    };
     double O[NX], P[NX];
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
       double o;
       if (lam) o = (i == 0) ? -abk[c * W + r] : 0.0;
       else if (i == 0 && r < 2 * NX) o = 0.0;
-      else o = (abk[c * W + (r - NX)] / sc) / sc;
+      else o = scale(abk[c * W + (r - NX)]);
       O[c] = last ? 0.0 : o;
-      P[c] = (!lam && r < 2 * NX && c == r - NX) ? (-1.0 / sc) / sc : 0.0;
+      P[c] = (!lam && r < 2 * NX && c == r - NX) ? scale(-1.0) : 0.0;
     }
     const bool even = (i & 1) == 0;
 #pragma unroll
@@ -828,10 +837,10 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     if (i == 0) {
       if (lam) zz = mad<STRICT>(-qr[r], rv, -r0[NX + r]);
       else if (r < 2 * NX) zz = -r0[r - NX];
-      else zz = (rv / sc) / sc;
+      else zz = scale(rv);
     } else {
       if (lam) zz = rv;
-      else if (r < 2 * NX || !last) zz = (rv / sc) / sc;
+      else if (r < 2 * NX || !last) zz = scale(rv);
       else zz = rv;
     }
   }

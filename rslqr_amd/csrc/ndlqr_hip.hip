@@ -332,7 +332,7 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
     /* apply_small needs all KPB knots of a workgroup inside one level-J subtree: 2^(J+1) >= KPB */ \
     int Jmin = 0;                                                                                   \
     while ((2 << Jmin) < ndlqr::SchurShape<NX_, NU_>::KPB) ++Jmin;                                  \
-    int J = c->fuse_level >= 0 ? c->fuse_level : 3;                                                 \
+    int J = c->fuse_level >= 0 ? c->fuse_level : 2;                                                 \
     if (J < Jmin) J = Jmin;                                                                         \
     if (J > d.K) J = d.K;                                                                           \
     if (strict) *err = keep ? launch_small<NX_, NU_, true, true>(c, J) : launch_small<NX_, NU_, true, false>(c, J);   \
