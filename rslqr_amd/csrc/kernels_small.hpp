@@ -21,6 +21,14 @@
 
 namespace ndlqr {
 
+// Orders LDS accesses of ONE wavefront: the DS unit executes a wavefront's operations in order,
+// so a compiler-level barrier plus draining the LDS counter is enough (no s_barrier).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+}
+
 // value of `v` in lane `src` (src must be wave-uniform): two v_readlane_b32
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -378,10 +386,12 @@ struct alignas(16) SepOut {
   double rdiag[NX];              // fast mode: 1 / L(j,j)
 };
 
+// The core is run by ONE whole wavefront; its LDS traffic is only ordered within that wavefront
+// (wave_lds_sync), the caller provides the workgroup barriers around it.
 // abrow: row gi = lane % NX of [A_s | B_s] (global). Lrow: on return, row gi of the factor for
 // lanes < NX (KEEPL: entries above the diagonal keep their S-bar values, like the reference's
-// in-place factorisation). Returns true when a pivot was not positive. Ends with the solved
-// panel visible to the whole workgroup (it issues __syncthreads()).
+// in-place factorisation). Returns true when a pivot was not positive. The caller issues the
+// workgroup barrier that makes the solved panel visible to other wavefronts.
 template <int NX, int NU, bool STRICT, bool KEEPL>
 __device__ __forceinline__ bool separator_core(const int lane, const double* __restrict__ abrow,
                                                const SepIn<NX, NU>& in, SepOut<NX>& out,
@@ -440,7 +450,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
   }
 #pragma unroll
   for (int j = 0; j < NX; ++j) Lrow[j] = acc[j];
-  __syncthreads();
+  wave_lds_sync();
 
   // P3: one right-hand-side column per lane (lanes >= LD repeat a column: same values)
   const int col = lane & (LD - 1);
@@ -461,12 +471,12 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
     for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[r], j), x[j], x[r]);
     __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
+  wave_lds_sync();
   if (lane < LD) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) out.X[k * LD + col] = x[k];
   }
-  __syncthreads();
+  wave_lds_sync();
   return bad;
 }
 
@@ -505,6 +515,7 @@ __global__ __launch_bounds__(64, 4) void separator_one(Dims d, int l, const doub
   double Lrow[NX];
   const int gi = lane % NX;
   const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, AB + (((size_t)b * N + s) * NX + gi) * W, in, out, Lrow);
+  __syncthreads();
   if (bad && lane == 0) atomicAdd(info + b, 1);
 
   // stores: rows of the solved panel
@@ -774,9 +785,9 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
   static_assert(2 * ROWS <= 64 && 3 * NX <= 64, "two knots per wavefront, three lane groups of NX");
   struct alignas(16) Priv {   // per wavefront
     double ab[2][NX * W];     // [A | B] of the wavefront's two knots (leaf phase)
-    SepOut<NX> so;            // separator panel / factor of the wavefront's subtree
   };
-  __shared__ SepIn<NX, NU> xs[NK / 2];
+  __shared__ SepIn<NX, NU> xs[NK / 2];   // per subtree of the current level: separator operands
+  __shared__ SepOut<NX> so[NK / 2];      // per subtree: solved right-hand sides
   __shared__ Priv pv[NWAVE];
   constexpr int LD = SepOut<NX>::LD;
 
@@ -849,14 +860,19 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
 #pragma unroll
   for (int l = 0; l < JB; ++l) {
     const int half = 1 << l, T = 2 << l;
-    const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+    // both knots of a wavefront sit in the same subtree at every level: tree quantities are
+    // wave-uniform (scalar registers, scalar branches)
+    const int i0 = __builtin_amdgcn_readfirstlane(wgbase + 2 * wave);
+    const int base = (i0 >> (l + 1)) << (l + 1), s = base + half - 1;
     int a, bb;
     outer_columns(base, l, N, a, bb);
     const int sub = (base - wgbase) >> (l + 1);
     SepIn<NX, NU>& xc = xs[sub];
-    const bool left = i <= s;
+    SepOut<NX>& sout = so[sub];
+    const bool left = (l == 0) ? (i == i0) : (i0 <= s);
     const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
     const bool active = !lam || calc_lambda;
+    const bool owner = (s + 1 - wgbase) / 2 == wave;  // the wavefront that holds knot s+1
 
     // publish what the separator needs from knots s and s+1
     if (has_knot && i == s && !lam) {
@@ -874,21 +890,22 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     }
     __syncthreads();
 
-    // separator of my subtree (every wavefront of the subtree computes it: no result broadcast)
-    {
+    // separator of the subtree: computed once, by the wavefront that holds knot s+1; the other
+    // wavefronts of the subtree wait at the barrier (their issue slots go to other workgroups)
+    if (owner) {
       double Lrow[NX];
       const int gi = lane % NX;
       const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, AB + (((size_t)b * N + s) * NX + gi) * W, xc,
-                                                            me.so, Lrow);
-      const bool owner = (s + 1 - wgbase) / 2 == wave;  // the wavefront that holds knot s+1
-      if (bad && lane == 0 && owner) atomicAdd(info + b, 1);
-      if (KEEP && owner && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
+                                                            sout, Lrow);
+      if (bad && lane == 0) atomicAdd(info + b, 1);
+      if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
     }
+    __syncthreads();
 
     // Schur update of my two knots, then rotate the column roles
-    const double* fa = me.so.X;           // f_a(k, c)  = X[k * LD + c]
-    const double* fb = me.so.X + NX;      // f_bb(k, c) = X[k * LD + NX + c]
-    const double* zsp = me.so.X + 2 * NX; // z_sep(k)   = X[k * LD + 2 NX]
+    const double* fa = sout.X;           // f_a(k, c)  = X[k * LD + c]
+    const double* fb = sout.X + NX;      // f_bb(k, c) = X[k * LD + NX + c]
+    const double* zsp = sout.X + 2 * NX; // z_sep(k)   = X[k * LD + 2 NX]
     if (KEEP && has_knot && active) store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
     if (active) {
       if (a >= 0) {
