@@ -538,6 +538,53 @@ __global__ __launch_bounds__(64, 4) void separator_one(Dims d, int l, const doub
   if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
 }
 
+// ------------------------------------------------------------------------------------- row update helpers
+// One knot row through one level, in place (used by bottom_small and apply_small):
+//   Ca <- (left ? Ca : 0) - E f_a,  Cb <- (left ? 0 : Cb) - E f_bb,  zz <- zz - E z_sep.
+// A row that must not change this level (a lambda row that is not eliminated yet) takes part with
+// E = 0: x + (-0 * f) == x bit for bit, so no lane needs a select around the FMAs and the created
+// column of such a row comes out as the required zero. f(k, c) = f[k * LDF + c].
+template <int NX, int LDF, bool STRICT>
+__device__ __forceinline__ void row_update(double (&E)[NX], double (&Ca)[NX], double (&Cb)[NX], double& zz,
+                                           const double* fa, const double* fb, const double* zsp,
+                                           const int zstride, const bool has_a, const bool has_b,
+                                           const bool left, const bool active) {
+#pragma unroll
+  for (int c = 0; c < NX; ++c) {
+    E[c] = active ? E[c] : 0.0;
+    Ca[c] = left ? Ca[c] : 0.0;   // the column a right-half knot gets created this level
+    Cb[c] = left ? 0.0 : Cb[c];   // the column a left-half knot gets created this level
+  }
+  if (has_a) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) Ca[c] = mad<STRICT>(-E[k], fa[k * LDF + c], Ca[c]);
+  }
+  if (has_b) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) Cb[c] = mad<STRICT>(-E[k], fb[k * LDF + c], Cb[c]);
+  }
+#pragma unroll
+  for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], zsp[k * zstride], zz);
+}
+
+// Column roles of level l+1: a left child's right outer column is column l+1 (it becomes E),
+// a right child's left outer column is. `left_child` must be wave-uniform (scalar branch).
+template <int NX>
+__device__ __forceinline__ void rotate_roles(double (&E)[NX], double (&Ca)[NX], double (&Cb)[NX],
+                                             const bool left_child) {
+  if (left_child) {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) { E[c] = Cb[c]; Cb[c] = 0.0; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) { E[c] = Ca[c]; Ca[c] = 0.0; }
+  }
+}
+
 // ------------------------------------------------------------------------------------- Schur update
 template <int NX, int NU>
 struct SchurShape {
@@ -715,50 +762,18 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
       store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);  // column l is final for this knot
     }
 
-    if (active) {
-      if (a >= 0) {
-        double acc[NX];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) acc[c] = left ? Ca[c] : 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k)
-#pragma unroll
-          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fa[k * NX + c], acc[c]);
-#pragma unroll
-        for (int c = 0; c < NX; ++c) Ca[c] = acc[c];
-      }
-      if (bb >= 0) {
-        double acc[NX];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) acc[c] = left ? 0.0 : Cb[c];
-#pragma unroll
-        for (int k = 0; k < NX; ++k)
-#pragma unroll
-          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fb[k * NX + c], acc[c]);
-#pragma unroll
-        for (int c = 0; c < NX; ++c) Cb[c] = acc[c];
-      }
-#pragma unroll
-      for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], zsep[k], zz);
-    } else if (i == s + 1) {  // lambda rows of knot s+1 receive the separator's results
+    // for l >= J >= 1 both knots of a wavefront sit in the same half of the same subtree
+    const bool left_u = __builtin_amdgcn_readfirstlane((int)left) != 0;
+    row_update<NX, NX, STRICT>(E, Ca, Cb, zz, fa, fb, zsep, 1, a >= 0, bb >= 0, left_u, active);
+    if (!active && i == s + 1) {  // lambda rows of knot s+1 receive the separator's results
 #pragma unroll
       for (int c = 0; c < NX; ++c) {
         if (a >= 0) Ca[c] = fa[r * NX + c];
         if (bb >= 0) Cb[c] = fb[r * NX + c];
       }
       zz = zsep[r];
-    } else {  // lambda rows not yet eliminated: the created column starts as zero
-#pragma unroll
-      for (int c = 0; c < NX; ++c) { if (left) Cb[c] = 0.0; else Ca[c] = 0.0; }
     }
-
-    // rotate into the roles of level l+1: a left child's right outer column is column l+1
-    const bool left_child = (base & T) == 0;
-#pragma unroll
-    for (int c = 0; c < NX; ++c) {
-      if (left_child) { E[c] = Cb[c]; Cb[c] = 0.0; }
-      else            { E[c] = Ca[c]; Ca[c] = 0.0; }
-    }
+    rotate_roles<NX>(E, Ca, Cb, __builtin_amdgcn_readfirstlane((int)((base & T) == 0)) != 0);
   }
   *zp = zz;
 }
@@ -907,48 +922,16 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     const double* fb = sout.X + NX;      // f_bb(k, c) = X[k * LD + NX + c]
     const double* zsp = sout.X + 2 * NX; // z_sep(k)   = X[k * LD + 2 NX]
     if (KEEP && has_knot && active) store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
-    if (active) {
-      if (a >= 0) {
-        double acc[NX];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) acc[c] = left ? Ca[c] : 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k)
-#pragma unroll
-          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fa[k * LD + c], acc[c]);
-#pragma unroll
-        for (int c = 0; c < NX; ++c) Ca[c] = acc[c];
-      }
-      if (bb >= 0) {
-        double acc[NX];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) acc[c] = left ? 0.0 : Cb[c];
-#pragma unroll
-        for (int k = 0; k < NX; ++k)
-#pragma unroll
-          for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fb[k * LD + c], acc[c]);
-#pragma unroll
-        for (int c = 0; c < NX; ++c) Cb[c] = acc[c];
-      }
-#pragma unroll
-      for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], zsp[k * LD], zz);
-    } else if (i == s + 1) {
+    row_update<NX, LD, STRICT>(E, Ca, Cb, zz, fa, fb, zsp, LD, a >= 0, bb >= 0, left, active);
+    if (!active && i == s + 1) {  // lambda rows of knot s+1 receive the separator's results
 #pragma unroll
       for (int c = 0; c < NX; ++c) {
         if (a >= 0) Ca[c] = fa[r * LD + c];
         if (bb >= 0) Cb[c] = fb[r * LD + c];
       }
       zz = zsp[r * LD];
-    } else {
-#pragma unroll
-      for (int c = 0; c < NX; ++c) { if (left) Cb[c] = 0.0; else Ca[c] = 0.0; }
     }
-    const bool left_child = (base & T) == 0;
-#pragma unroll
-    for (int c = 0; c < NX; ++c) {
-      if (left_child) { E[c] = Cb[c]; Cb[c] = 0.0; }
-      else            { E[c] = Ca[c]; Ca[c] = 0.0; }
-    }
+    rotate_roles<NX>(E, Ca, Cb, (base & T) == 0);
     __syncthreads();  // xs / pv are reused by the next level
   }
 
@@ -971,6 +954,159 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     else        { if (bb >= 0) store_row<NX>(Fblk(F, d, b, bb, i) + r * NX, Cb); }
     z[((size_t)b * N + i) * ROWS + r] = zz;
   }
+}
+
+// ------------------------------------------------------------------------------------- apply, 2 rows per lane
+// apply_small with a register tile of TWO rows per lane (rows p and p + HALF of the same knot):
+// every f value fetched from LDS feeds two FMAs, halving the LDS-broadcast traffic that bounds
+// apply_small. Lane = (knot, row pair), 64 / HALF knots per wavefront, 2 wavefronts per
+// workgroup. Same per-element operations and order as apply_small.
+//   grid (N / KPB2, batch), block 128, dynamic LDS = (K - J) * REC doubles; needs 2^(J+1) >= KPB2.
+template <int NX, int NU>
+struct Apply2Shape {
+  static constexpr int ROWS = 2 * NX + NU;
+  static constexpr int HALF = (ROWS + 1) / 2;   // row pairs per knot
+  static constexpr int KPW = 64 / HALF;         // knots per wavefront
+  static constexpr int WAVES = 2;
+  static constexpr int KPB2 = (KPW >= 4 ? 4 : (KPW >= 2 ? 2 : 1)) * WAVES;  // power of two
+  static constexpr int KPWU = KPB2 / WAVES;     // knots per wavefront actually used
+};
+
+template <int NX, int NU, bool STRICT, bool KEEP>
+__global__ __launch_bounds__(128) void apply2_small(Dims d, int J, double* F, double* z,
+                                                    const double* __restrict__ recs) {
+  using Sh = SchurShape<NX, NU>;
+  using A2 = Apply2Shape<NX, NU>;
+  constexpr int ROWS = A2::ROWS, HALF = A2::HALF, KPB = A2::KPB2, KPWU = A2::KPWU, REC = Sh::REC;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int N = d.N, K = d.K, b = blockIdx.y;
+  const int first = blockIdx.x * KPB;
+  for (int l = J; l < K; ++l) {
+    const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
+    const double* src = recs + ((size_t)b * N + qs) * REC;
+    double* dst = lds + (l - J) * REC;
+    for (int e = threadIdx.x; e < REC; e += 128) dst[e] = src[e];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kn = lane / HALF, p = lane - kn * HALF;
+  if (kn >= KPWU) return;
+  const int i = first + wave * KPWU + kn;
+  const int rr[2] = {p, p + HALF};
+  const bool rowok[2] = {true, p + HALF < ROWS};
+
+  int lstart = J;
+  {
+    const int mask = (1 << J) - 1;
+    if ((i & mask) == 0) lstart = (i == 0) ? K : __builtin_ctz(i);
+    else if ((i & mask) == mask) lstart = trailing_ones(i);
+    if (lstart > K - 1) lstart = K - 1;
+  }
+
+  double E[2][NX], Ca[2][NX], Cb[2][NX], zz[2] = {0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < NX; ++c) { E[t][c] = 0.0; Ca[t][c] = 0.0; Cb[t][c] = 0.0; }
+  double* zp = z + ((size_t)b * N + i) * ROWS;
+
+  for (int l = J; l < K; ++l) {
+    if (l < lstart) continue;
+    const int half = 1 << l, T = 2 << l;
+    const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+    int a, bb;
+    outer_columns(base, l, N, a, bb);
+    const bool left = i <= s;
+    const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+    const double* rc = lds + (l - J) * REC;
+    const double* fa = rc;
+    const double* fb = rc + NX * NX;
+    const double* zsep = rc + 2 * NX * NX;
+    bool active[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) active[t] = rowok[t] && (rr[t] >= NX || calc_lambda);
+
+    if (l == lstart) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (!rowok[t]) continue;
+        load_row<NX>(Fblk(F, d, b, l, i) + rr[t] * NX, E[t]);
+        if (left) { if (a >= 0) load_row<NX>(Fblk(F, d, b, a, i) + rr[t] * NX, Ca[t]); }
+        else      { if (bb >= 0) load_row<NX>(Fblk(F, d, b, bb, i) + rr[t] * NX, Cb[t]); }
+        zz[t] = zp[rr[t]];
+      }
+    } else if (KEEP) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (active[t]) store_row<NX>(Fblk(F, d, b, l, i) + rr[t] * NX, E[t]);
+    }
+
+    // Rows that must not change this level (lambda rows not yet eliminated) take part with a
+    // zero E row: acc + (-0 * f) leaves them bit-for-bit unchanged, so both rows of the tile run
+    // the same in-place FMAs and every f value read from LDS feeds two of them.
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        if (!active[t]) E[t][c] = 0.0;
+        if (!left) Ca[t][c] = 0.0;   // created this level
+        else Cb[t][c] = 0.0;
+      }
+    if (a >= 0) {
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          const double f = fa[k * NX + c];
+          Ca[0][c] = mad<STRICT>(-E[0][k], f, Ca[0][c]);
+          Ca[1][c] = mad<STRICT>(-E[1][k], f, Ca[1][c]);
+        }
+        asm volatile("" ::: "memory");  // keep the LDS reads of row k next to their FMAs (registers)
+      }
+    }
+    if (bb >= 0) {
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          const double f = fb[k * NX + c];
+          Cb[0][c] = mad<STRICT>(-E[0][k], f, Cb[0][c]);
+          Cb[1][c] = mad<STRICT>(-E[1][k], f, Cb[1][c]);
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const double f = zsep[k];
+      zz[0] = mad<STRICT>(-E[0][k], f, zz[0]);
+      zz[1] = mad<STRICT>(-E[1][k], f, zz[1]);
+    }
+    // lambda rows of knot s+1 receive the separator's results
+    if (i == s + 1) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (active[t] || !rowok[t]) continue;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          if (a >= 0) Ca[t][c] = fa[rr[t] * NX + c];
+          if (bb >= 0) Cb[t][c] = fb[rr[t] * NX + c];
+        }
+        zz[t] = zsep[rr[t]];
+      }
+    }
+    const bool left_child = (base & T) == 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        if (left_child) { E[t][c] = Cb[t][c]; Cb[t][c] = 0.0; }
+        else            { E[t][c] = Ca[t][c]; Ca[t][c] = 0.0; }
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) if (rowok[t]) zp[rr[t]] = zz[t];
 }
 
 }  // namespace ndlqr

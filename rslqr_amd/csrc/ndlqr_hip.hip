@@ -67,6 +67,7 @@ struct NdlqrHipCtx {
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
+  int apply_variant; // 0 = apply2_small (two rows per lane), 1 = apply_small
   int sep_variant; // 0 = separator_one (lean core), 1 = separator_small, 2 = separator_pair
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
@@ -116,6 +117,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
   c->fuse_level = -1;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
+  c->apply_variant = getenv("NDLQR_APPLY_VARIANT") ? atoi(getenv("NDLQR_APPLY_VARIANT")) : 0;
   c->sep_variant = getenv("NDLQR_SEP_VARIANT") ? atoi(getenv("NDLQR_SEP_VARIANT")) : 0;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
@@ -317,8 +319,14 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   if (J < d.K) {
     ScopedSlot t(c, SLOT_APPLY);
     const size_t lds = sizeof(double) * (size_t)(d.K - J) * Sh::REC;
-    hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
-                       c->stream, d, J, c->F, c->z, c->rec);
+    using A2 = ndlqr::Apply2Shape<NX, NU>;
+    if (c->apply_variant == 0 && (2 << J) >= A2::KPB2 && d.N >= A2::KPB2) {
+      hipLaunchKernelGGL((ndlqr::apply2_small<NX, NU, STRICT, KEEP>), dim3(d.N / A2::KPB2, d.batch), dim3(128), lds,
+                         c->stream, d, J, c->F, c->z, c->rec);
+    } else {
+      hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
+                         c->stream, d, J, c->F, c->z, c->rec);
+    }
   }
   return NDLQR_OK;
 }
