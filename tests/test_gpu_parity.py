@@ -129,3 +129,58 @@ def test_json_fixture_through_dropin_api(ndlqr, oracle, fname):
     assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
     L.ndlqr_FreeLQRProblem(prob)
     L.ndlqr_FreeNdLqrSolver(solver)
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(64, 16, 32, 2), (32, 8, 64, 2), (20, 20, 16, 3)])
+def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
+    """Shapes without a specialised instance (config 5 family, nx=64 nu=16) run the runtime-sized
+    kernels: strict mode bit-exact, fast mode within tolerance."""
+    probs = [synth(ndlqr, n, m, N, 900 + p) for p in range(batch)]
+    for strict in (True, False):
+        bs = ndlqr.BatchSolver(n, m, N, batch, flags=(ndlqr.FLAG_STRICT_FP if strict else 0) | ndlqr.FLAG_KEEP_FACT)
+        bs.initialize_flat(*stack(probs))
+        assert bs.solve() == 0
+        sol = bs.solutions()
+        for p, prob in enumerate(probs):
+            z, fact, _, fails = oracle.solve(prob, 8, want_fact=True)
+            ref = z[: prob.nvars]
+            if strict:
+                assert np.array_equal(sol[p], ref)
+                assert np.array_equal(bs.factors(p), fact)
+            else:
+                assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+        bs.close()
+
+
+def test_non_spd_block_is_reported(ndlqr):
+    """A non-positive R entry: the reference's Cholesky fails silently (src/linalg.c:80-85,
+    src/solve.c:189); here the solve returns NDLQR_ERR_NOT_SPD and counts the failure."""
+    n, m, N = 12, 4, 16
+    g = ndlqr.generate_synthetic(n, m, N, 5)
+    g["R"][3, 1] = -1.0
+    for flags in (0, ndlqr.FLAG_GENERIC):
+        bs = ndlqr.BatchSolver(n, m, N, 1, flags=flags)
+        bs.initialize_flat(*[g[k][None] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+        assert bs.solve() == -3
+        assert bs.cholesky_failures() >= 1
+        bs.close()
+
+
+def test_env_variants_agree(ndlqr, oracle):
+    """Kernel variants selectable for A/B timing give the same strict-mode bits."""
+    import subprocess, sys, json
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import rslqr_amd as R\n"
+        "bs = R.BatchSolver(12, 4, 64, 3, flags=R.FLAG_STRICT_FP); bs.initialize_synthetic(77)\n"
+        "assert bs.solve() == 0; print(json.dumps(bs.solutions().tolist()))\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for env in ({}, {"NDLQR_APPLY_VARIANT": "1"}, {"NDLQR_SEP_VARIANT": "1"}, {"NDLQR_SEP_VARIANT": "2"},
+                {"NDLQR_BOTTOM_LEVELS": "0"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
