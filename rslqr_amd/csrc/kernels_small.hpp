@@ -382,7 +382,9 @@ struct alignas(16) SepIn {      // what a separator reads from its two neighbour
 template <int NX>
 struct alignas(16) SepOut {
   static constexpr int LD = 32;  // panel row length: [f_a (NX) | f_bb (NX) | z_sep | pad]
+  static constexpr int LS = NX + 1;  // padded row length of the S-bar / L matrix (bank spread)
   double X[NX * LD];             // right-hand sides in, solutions out; row k, column c
+  double S[NX * LS];             // S-bar, factored in place to L (row-major, padded)
   double rdiag[NX];              // fast mode: 1 / L(j,j)
 };
 
@@ -480,11 +482,120 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
   return bad;
 }
 
+// LDS-resident variant of the core: S-bar / L and the right-hand-side panel live in LDS and the
+// column loops of the Cholesky and of the two substitutions are ROLLED over the (wave-uniform)
+// pivot index j, with the row loops unrolled under scalar `r > j` tests. Every multiply-add is
+// then one VALU instruction fed by LDS reads (the L entry is an LDS broadcast, addressed with an
+// immediate offset from one base register), nothing is broadcast through v_readlane, and the
+// working set in registers is a handful of values -- high occupancy, short code. Same operations
+// in the same order as separator_core.
+template <int NX, int NU, bool STRICT, bool KEEPL>
+__device__ __forceinline__ bool separator_core_lds(const int lane, const double* __restrict__ abrow,
+                                                   const SepIn<NX, NU>& in, SepOut<NX>& out,
+                                                   double (&Lrow)[NX]) {
+  constexpr int W = NX + NU, LD = SepOut<NX>::LD, LS = SepOut<NX>::LS;
+  const int grp = lane / NX, gi = lane - grp * NX;
+  double ab[W];
+  load_row<W>(abrow, ab);
+
+  // P1 (registers): row gi of S-bar (group 0) / of f_a (group 1)
+  {
+    double acc[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = 0.0;
+    const double* M = (grp == 1) ? in.Axu : in.Exu;
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
+    if (grp == 0) {
+      double accz = -in.z1[gi];
+#pragma unroll
+      for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], in.zxu[k], accz);
+      out.X[gi * LD + 2 * NX] = accz - in.z1[NX + gi];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) out.S[gi * LS + j] = acc[j] - in.E1x[gi * NX + j];
+    } else if (grp == 1) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        out.X[gi * LD + j] = acc[j];
+        out.X[gi * LD + NX + j] = -in.B1x[gi * NX + j];
+      }
+    }
+  }
+  wave_lds_sync();
+
+  // P2: left-looking Cholesky in LDS. Lane i < NX owns row i; lanes >= NX shadow row gi (they
+  // compute the same values and do not store).
+  bool bad = false;
+  const bool rowlane = lane < NX;
+  double* myrow = out.S + gi * LS;
+#pragma unroll 1
+  for (int j = 0; j < NX; ++j) {
+    const double* rowj = out.S + j * LS;
+    double v = myrow[j];
+#pragma unroll
+    for (int k = 0; k < NX - 1; ++k)
+      if (k < j) v = mad<STRICT>(-myrow[k], rowj[k], v);
+    const bool below = gi >= j;
+    if (rowlane && (below || !KEEPL)) myrow[j] = v;
+    wave_lds_sync();
+    const double pivot = rowj[j];
+    bad = bad || !(pivot > 0.0);
+    double w;
+    if constexpr (STRICT) {
+      w = v / sqrt(pivot);
+    } else {
+      const double rinv = rsqrt(pivot);
+      w = v * rinv;
+      if (lane == 0) out.rdiag[j] = rinv;
+    }
+    if (rowlane && (below || !KEEPL)) myrow[j] = w;
+    wave_lds_sync();
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) Lrow[j] = myrow[j];
+
+  // P3: one right-hand-side column per lane, the column itself stays in the LDS panel
+  const int col = lane & (LD - 1);
+  double* xc = out.X + col;
+  const bool colane = lane < LD;  // lanes >= LD shadow a column (same values, no stores)
+#pragma unroll 1
+  for (int j = 0; j < NX; ++j) {
+    double xj = xc[j * LD];
+    if constexpr (STRICT) xj = xj / out.S[j * LS + j]; else xj = xj * out.rdiag[j];
+    if (colane) xc[j * LD] = xj;
+    const double* colj = out.S + j;  // L(r, j) = S[r * LS + j]
+#pragma unroll
+    for (int r = 1; r < NX; ++r)
+      if (r > j) {
+        const double t = mad<STRICT>(-colj[r * LS], xj, xc[r * LD]);
+        if (colane) xc[r * LD] = t;
+      }
+    wave_lds_sync();
+  }
+#pragma unroll 1
+  for (int j = NX - 1; j >= 0; --j) {
+    double xj = xc[j * LD];
+    if constexpr (STRICT) xj = xj / out.S[j * LS + j]; else xj = xj * out.rdiag[j];
+    if (colane) xc[j * LD] = xj;
+    const double* rowj = out.S + j * LS;  // L(j, r)
+#pragma unroll
+    for (int r = 0; r < NX - 1; ++r)
+      if (r < j) {
+        const double t = mad<STRICT>(-rowj[r], xj, xc[r * LD]);
+        if (colane) xc[r * LD] = t;
+      }
+    wave_lds_sync();
+  }
+  return bad;
+}
+
 // One wavefront per separator: stage the operands (whole rows, 16-byte loads), run the core,
 // store the record f_a | f_bb | z_sep and the lambda rows of knot s+1.
 //   grid (N >> (l+1), batch), block 64.
-template <int NX, int NU, bool STRICT, bool KEEP>
-__global__ __launch_bounds__(64, 4) void separator_one(Dims d, int l, const double* __restrict__ AB,
+template <int NX, int NU, bool STRICT, bool KEEP, int CORE>
+__global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double* __restrict__ AB,
                                                     double* F, double* z, double* __restrict__ rec,
                                                     int* __restrict__ info) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, LD = SepOut<NX>::LD;
@@ -514,7 +625,9 @@ __global__ __launch_bounds__(64, 4) void separator_one(Dims d, int l, const doub
   __syncthreads();
   double Lrow[NX];
   const int gi = lane % NX;
-  const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, AB + (((size_t)b * N + s) * NX + gi) * W, in, out, Lrow);
+  const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
+  const bool bad = CORE == 0 ? separator_core_lds<NX, NU, STRICT, KEEP>(lane, abrow, in, out, Lrow)
+                             : separator_core<NX, NU, STRICT, KEEP>(lane, abrow, in, out, Lrow);
   __syncthreads();
   if (bad && lane == 0) atomicAdd(info + b, 1);
 
@@ -790,7 +903,7 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
 // 0..JB-1. Arithmetic and order per element are those of leaf_generic + separator_small +
 // schur_small run level by level.
 //   grid (N >> JB, batch), block 32 << JB threads. Requires N > 2^JB.
-template <int NX, int NU, bool STRICT, bool KEEP, int JB>
+template <int NX, int NU, bool STRICT, bool KEEP, int JB, int CORE>
 __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double* __restrict__ AB,
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
@@ -910,8 +1023,9 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     if (owner) {
       double Lrow[NX];
       const int gi = lane % NX;
-      const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, AB + (((size_t)b * N + s) * NX + gi) * W, xc,
-                                                            sout, Lrow);
+      const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
+      const bool bad = CORE == 0 ? separator_core_lds<NX, NU, STRICT, KEEP>(lane, abrow, xc, sout, Lrow)
+                                 : separator_core<NX, NU, STRICT, KEEP>(lane, abrow, xc, sout, Lrow);
       if (bad && lane == 0) atomicAdd(info + b, 1);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
     }

@@ -177,7 +177,7 @@ def test_env_variants_agree(ndlqr, oracle):
         % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     outs = []
     for env in ({}, {"NDLQR_APPLY_VARIANT": "1"}, {"NDLQR_SEP_VARIANT": "1"}, {"NDLQR_SEP_VARIANT": "2"},
-                {"NDLQR_BOTTOM_LEVELS": "0"}):
+                {"NDLQR_SEP_VARIANT": "4"}, {"NDLQR_BOTTOM_LEVELS": "0"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
