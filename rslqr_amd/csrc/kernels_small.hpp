@@ -728,9 +728,10 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kn = lane / ROWS, r = lane - kn * ROWS;
   int i;
+  const bool idle_lane = kn >= 2;  // lanes beyond two knots only help staging the record
   if (BOUNDARY) {
     const int sub = blockIdx.x * WAVES + wave;
-    if (sub >= nsub || kn >= 2) return;
+    if (sub >= nsub) return;
     i = sub * T + (kn == 0 ? 0 : T - 1);
   } else {
     if (kn >= KPW) return;
@@ -740,9 +741,21 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
   int a, bb;
   outer_columns(base, l, N, a, bb);
   // All knots of a wavefront sit in the same level-l subtree (KPW consecutive, aligned knots),
-  // so the separator record address is wave-uniform: scalar loads, SGPR operands in the FMAs.
+  // so the separator record address is wave-uniform.
+  //   full-level mode: scalar loads, SGPR operands in the FMAs (many wavefronts hide the latency);
+  //   boundary mode  : few wavefronts, latency-bound -> each wavefront stages its record in LDS
+  //                    with one round of vector loads and reads it back as broadcasts.
   const int qs = __builtin_amdgcn_readfirstlane(s);
   const double* rcd = recs + ((size_t)b * N + qs) * REC;
+  __shared__ __attribute__((aligned(16))) double recl[BOUNDARY ? WAVES : 1][BOUNDARY ? REC : 2];
+  if constexpr (BOUNDARY) {
+    double* dst = recl[wave];
+    for (int e = lane; e < REC / 2; e += 64)
+      reinterpret_cast<double2*>(dst)[e] = reinterpret_cast<const double2*>(rcd)[e];
+    wave_lds_sync();
+    rcd = dst;
+    if (idle_lane) return;
+  }
   const double* fa = rcd;
   const double* fb = rcd + NX * NX;
   const double* zsep = rcd + 2 * NX * NX;
