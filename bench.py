@@ -47,6 +47,21 @@ def model_b_bytes(n, m, N):
     return 8 * leaves, levels
 
 
+def model_flops(n, m, N):
+    """SURVEY.md 8(d) algorithmic flops per solve (dense reference schedule): leaves + per level
+    P1 4n^2(n+m) per product, P2 n^3/3, P3 2n^3 per solve, P4 2*Fb*n per block update, plus the
+    rhs sweep (w = 1)."""
+    K = int(np.log2(N))
+    Fb = (2 * n + m) * n
+    fl = N * (n ** 3 / 3 + m ** 3 / 3 + 4 * n ** 3 + 2 * m * m * n)
+    for l in range(K):
+        L = 1 << (K - l - 1)
+        fl += L * (K - l) * 4 * n * n * (n + m) + L * n ** 3 / 3 + L * (K - l - 1) * 2 * n ** 3
+        fl += N * (K - l - 1) * 2 * Fb * n
+        fl += L * (4 * n * (n + m) + 2 * n * n) + N * 2 * Fb
+    return fl
+
+
 def live_bytes(n, m, N):
     """Bytes the kernels of this build actually have to move per solve (DESIGN.md "live
     columns"): inputs + rhs once, per level read E + read/write one outer column + write the
@@ -249,6 +264,13 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "whole_solve_model_b_gbs_per_gpu": whole_solve_gbs,
                          "live_column_bytes_per_solve": live_bytes(n, m, N),
+                         # the kernels are fp64 VALU-issue bound after the traffic reduction: the
+                         # compute roof next to the (contractual) HBM one. Algorithmic flops of
+                         # the dense reference schedule; structural zeros are skipped at run time.
+                         "fp64": {"algorithmic_flops_per_solve": model_flops(n, m, N),
+                                  "achieved_tflops": model_flops(n, m, N) * value / world / 1e12,
+                                  "peak_tflops": 78.6,
+                                  "frac": model_flops(n, m, N) * value / world / 1e12 / 78.6},
                          "model_b_bytes_per_solve": leaf_b + sum(level_b)},
             "kernel_ms": {k: {"total_ms": v[0], "launches": v[1]} for k, v in prof.items() if v[1]},
         }

@@ -1,21 +1,19 @@
 // kernels_small.hpp -- size-specialised kernels for small (nstates, ninputs): one factor-block
-// ROW per lane, several knots per 64-wide wavefront, separator right-hand sides staged in LDS.
+// ROW per lane, two knots per 64-wide wavefront, separator math by one wavefront per separator.
 //
 // Same arithmetic (and, with STRICT, the same operation order) as kernels_generic.hpp; see that
-// file for the mapping to the reference functions. What changes is the work distribution:
+// file for the mapping to the reference functions and DESIGN.md section 2 for the schedule:
 //
-//   separator_small  one wavefront per level-l separator s. Lanes are split in groups of NX:
-//                    group 0 lane i owns row i of S-bar (and entry i of the rhs), group 1 row i of
-//                    the left outer right-hand side f_a, group 2 row i of f_bb. The operands
-//                    that every lane needs (state/input rows of knot s) are staged in LDS and
-//                    read as broadcasts; A_s, B_s rows stay in registers. The Cholesky runs on
-//                    group 0's registers with v_readlane broadcasts of row j; the triangular
-//                    solves run one right-hand-side column per lane with L(i,j) as a scalar.
-//   schur_small      one wavefront per KPW = 64/ROWS consecutive knots, lane = (knot, row).
-//                    Each lane keeps its row of E (column l) in registers and updates its row
-//                    of the two live outer columns and its rhs entry; f_a, f_bb, z_sep of the
-//                    enclosing subtree are read from LDS as broadcasts (ds_read_b128).
-//                    Global traffic is whole rows (NX doubles, 16-byte vector loads/stores).
+//   bottom_small     leaf phase + tree levels 0..JB-1 fused on chip (registers + LDS exchange)
+//   separator_core   S-bar, f_a, f_bb, z_sep of one separator by one wavefront (device function)
+//   separator_one    standalone separator kernel for the upper levels
+//   schur_small      Schur update of all knots of a level, or (BOUNDARY) of the first and last
+//                    knot of every subtree only
+//   apply_small      every knot through all upper levels in registers, one pass
+//
+// Variants that were measured and dropped (numbers in DESIGN.md section 4): two separators per
+// wavefront with L broadcast from LDS, an LDS-resident Cholesky/substitution with rolled pivot
+// loops, and an apply kernel with two rows per lane -- each lost to latency at low occupancy.
 #pragma once
 #include "kernels_common.hpp"
 
@@ -61,309 +59,6 @@ __device__ __forceinline__ void store_row(double* __restrict__ p, const double (
   }
 }
 
-// ------------------------------------------------------------------------------------- separator
-template <int NX, int NU, bool STRICT>
-__global__ __launch_bounds__(64) void separator_small(Dims d, int l, const double* __restrict__ AB,
-                                                      double* F, double* z, double* __restrict__ rec,
-                                                      int* __restrict__ info) {
-  constexpr int W = NX + NU, ROWS = 2 * NX + NU;
-  static_assert(3 * NX <= 64, "three lane groups of NX must fit a wavefront");
-  __shared__ __attribute__((aligned(16))) double shE[W * NX];   // state+input rows of E(s)
-  __shared__ __attribute__((aligned(16))) double shA[W * NX];   // state+input rows of F(s, a)
-  __shared__ __attribute__((aligned(16))) double shF[2][NX * NX];  // f_a, f_bb (row-major)
-  __shared__ __attribute__((aligned(16))) double shz[W + NX];   // z(s) state+input | z_sep
-  const int N = d.N, b = blockIdx.y, lane = threadIdx.x;
-  const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
-  int a, bb;
-  outer_columns(base, l, N, a, bb);
-
-  const double* Es = Fblk(F, d, b, l, s);
-  const double* Fas = a >= 0 ? Fblk(F, d, b, a, s) : Es;
-  const double* zs = z + ((size_t)b * N + s) * ROWS;
-  double* zs1 = z + ((size_t)b * N + s + 1) * ROWS;
-  for (int e = lane; e < W * NX; e += 64) {
-    shE[e] = Es[NX * NX + e];
-    shA[e] = Fas[NX * NX + e];
-  }
-  if (lane < W) shz[lane] = zs[NX + lane];
-  __syncthreads();
-
-  const int grp = lane / NX, i = lane - grp * NX;
-  // row i of [A_s | B_s]
-  double ab[W];
-  {
-    const double* arow = AB + (((size_t)b * N + s) * NX + i) * W;
-#pragma unroll
-    for (int k = 0; k < W; ++k) ab[k] = (grp < 2) ? arow[k] : 0.0;
-  }
-  // ---- P1: row i of S-bar (group 0) / of f_a (group 1): sum_k ab[k] * M[k][:]
-  double acc[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) acc[j] = 0.0;
-  const double* M = (grp == 1) ? shA : shE;
-#pragma unroll
-  for (int k = 0; k < W; ++k)
-#pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
-  double accz = 0.0;
-  if (grp == 0) {
-    accz = -zs1[i];  // beta = -1 on the old lambda entry of the rhs
-#pragma unroll
-    for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], shz[k], accz);
-    accz = accz - zs1[NX + i];
-    const double* e1 = Fblk(F, d, b, l, s + 1) + (NX + i) * NX;  // state row i of E(s+1)
-#pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = acc[j] - e1[j];
-  } else if (grp == 2 && bb >= 0) {
-    const double* b1 = Fblk(F, d, b, bb, s + 1) + (NX + i) * NX;  // f_bb = -(state rows of F(s+1,bb))
-#pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = -b1[j];
-  }
-
-  // ---- P2: Cholesky of S-bar on group 0's registers (left-looking, column by column).
-  // Every lane runs the code (no divergence); only group 0's Lr is meaningful. Entries above
-  // the diagonal keep their S-bar values, exactly like the reference's in-place factorisation.
-  double Lr[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) Lr[j] = acc[j];
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    if (ok) {
-      double v = Lr[j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v = mad<STRICT>(-Lr[k], readlane_f64(Lr[k], j), v);
-      if (i >= j) Lr[j] = v;
-      const double pivot = readlane_f64(Lr[j], j);
-      if (!(pivot > 0.0)) {
-        ok = false;
-      } else {
-        const double root = sqrt(pivot);
-        if (i >= j) Lr[j] = Lr[j] / root;
-      }
-    }
-  }
-  if (!ok && lane == 0) atomicAdd(info + b, 1);
-
-  // ---- hand the right-hand sides over to one-column-per-lane form through LDS
-  if (grp == 0) shz[W + i] = accz;
-  if (grp == 1 || grp == 2) {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) shF[grp - 1][i * NX + j] = acc[j];
-  }
-  __syncthreads();
-  // lanes [0,NX): columns of f_a; [NX,2NX): columns of f_bb; lane 2NX: the rhs vector
-  const int which = lane / NX, col = lane - which * NX;
-  const bool has_col = (which == 0 && a >= 0) || (which == 1 && bb >= 0) || (lane == 2 * NX);
-  double x[NX];
-#pragma unroll
-  for (int k = 0; k < NX; ++k)
-    x[k] = (lane == 2 * NX) ? shz[W + k] : (which < 2 ? shF[which][k * NX + col] : 0.0);
-
-  // ---- P3: L y = x, then L' x = y; L(i,j) = register j of lane i in group 0 (scalar broadcast)
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    x[j] = x[j] / readlane_f64(Lr[j], j);
-#pragma unroll
-    for (int r = j + 1; r < NX; ++r) x[r] = mad<STRICT>(-readlane_f64(Lr[j], r), x[j], x[r]);
-  }
-#pragma unroll
-  for (int j = NX - 1; j >= 0; --j) {
-    x[j] = x[j] / readlane_f64(Lr[j], j);
-#pragma unroll
-    for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-readlane_f64(Lr[r], j), x[j], x[r]);
-  }
-
-  // ---- store: factor of S-bar (rows), f_a / f_bb (columns), z_sep; the three right-hand
-  //      sides also go, contiguously, into this separator's record rec[b][s] = f_a | f_bb | z_sep
-  //      (what the Schur / apply kernels stage in LDS)
-  double* myrec = rec + ((size_t)b * N + s) * (2 * NX * NX + NX);
-  if (grp == 0) {
-    double* outS = Fblk(F, d, b, l, s + 1) + i * NX;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) outS[j] = Lr[j];
-  }
-  if (has_col) {
-    if (lane == 2 * NX) {
-#pragma unroll
-      for (int k = 0; k < NX; ++k) { zs1[k] = x[k]; myrec[2 * NX * NX + k] = x[k]; }
-    } else {
-      double* out = Fblk(F, d, b, which == 0 ? a : bb, s + 1) + col;
-      double* out2 = myrec + which * NX * NX + col;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) { out[k * NX] = x[k]; out2[k * NX] = x[k]; }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------- separator, 2 per wave
-// Same mathematics as separator_small, organised for instruction count: TWO separators per
-// wavefront (one per 32-lane half), so every vector instruction of the inner products, the
-// Cholesky and the substitutions serves two separators; the factor L is broadcast through LDS
-// (row-major copy for the transposed sweep, transposed copy for the forward sweep) instead of
-// v_readlane pairs. Per half: lanes 0..NX-1 own row i of S-bar, lanes NX..2NX-1 row i of f_a;
-// in the solves lane c < 2NX owns one right-hand-side column, lane 2NX the rhs vector.
-// STRICT keeps the reference's operations (sqrt, divisions) and order; the fast mode replaces
-// the per-column divisions by one reciprocal square root (results within the stated tolerance).
-//   grid (ceil(nsep / 2), batch), block 64.
-template <int NX, int NU, bool STRICT>
-__global__ __launch_bounds__(64) void separator_pair(Dims d, int l, const double* __restrict__ AB,
-                                                     double* F, double* z, double* __restrict__ rec,
-                                                     int* __restrict__ info) {
-  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX;
-  static_assert(2 * NX + 1 <= 32, "2 NX + 1 right-hand-side columns must fit a half wavefront");
-  struct alignas(16) Slot {
-    double E[W * NX];    // state+input rows of E(s)
-    double A[W * NX];    // state+input rows of F(s, a)
-    double Fm[2][NN];    // f_a, f_bb row-major [k][c]
-    double L[NN];        // Cholesky factor, row-major
-    double Lt[NN];       // its transpose
-    double zxu[W];       // state+input entries of z(s)
-    double zs[NX];       // z_sep
-    double piv[NX];      // pivot broadcast / reciprocal diagonal
-  };
-  __shared__ Slot slots[2];
-  const int N = d.N, b = blockIdx.y, lane = threadIdx.x;
-  const int h = lane >> 5, hl = lane & 31;
-  const int nsep = N >> (l + 1);
-  const int q = 2 * blockIdx.x + h;
-  const bool live = q < nsep;  // the last block may carry a single separator
-  const int qq = live ? q : nsep - 1;
-  const int half = 1 << l, base = qq * (2 << l), s = base + half - 1;
-  int a, bb;
-  outer_columns(base, l, N, a, bb);
-  Slot& sl = slots[h];
-
-  // ---- stage the operands every lane of the half needs
-  {
-    const double* Es = Fblk(F, d, b, l, s) + NN;
-    const double* Fas = (a >= 0 ? Fblk(F, d, b, a, s) : Fblk(F, d, b, l, s)) + NN;
-    for (int e = hl; e < W * NX / 2; e += 32) {
-      reinterpret_cast<double2*>(sl.E)[e] = reinterpret_cast<const double2*>(Es)[e];
-      reinterpret_cast<double2*>(sl.A)[e] = reinterpret_cast<const double2*>(Fas)[e];
-    }
-    if (hl < W) sl.zxu[hl] = z[((size_t)b * N + s) * ROWS + NX + hl];
-  }
-  double* zs1 = z + ((size_t)b * N + s + 1) * ROWS;
-  const int grp = hl / NX, i = hl - grp * NX;  // grp 0: S-bar rows, 1: f_a rows, 2: idle in P1
-  double ab[W];
-  {
-    const double* arow = AB + (((size_t)b * N + s) * NX + i) * W;
-#pragma unroll
-    for (int k = 0; k < W; ++k) ab[k] = (grp < 2) ? arow[k] : 0.0;
-  }
-  double e1[NX];  // group 0: state row i of E(s+1); group 1: state row i of F(s+1, bb)
-  {
-    const int col = (grp == 0 || bb < 0) ? l : bb;
-    load_row<NX>(Fblk(F, d, b, col, s + 1) + (NX + i) * NX, e1);
-  }
-  const double zl_old = zs1[i], zx_next = zs1[NX + i];
-  __syncthreads();
-
-  // ---- P1: row i of S-bar (group 0) / f_a (group 1)
-  double acc[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) acc[j] = 0.0;
-  const double* M = (grp == 1) ? sl.A : sl.E;
-#pragma unroll
-  for (int k = 0; k < W; ++k)
-#pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
-  if (grp == 0) {
-    double accz = -zl_old;
-#pragma unroll
-    for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], sl.zxu[k], accz);
-    sl.zs[i] = accz - zx_next;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = acc[j] - e1[j];
-  } else if (grp == 1) {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      sl.Fm[0][i * NX + j] = acc[j];
-      sl.Fm[1][i * NX + j] = -e1[j];  // f_bb = -(state rows of F(s+1, bb))
-    }
-  }
-
-  // ---- P2: left-looking Cholesky, rows in the registers of group 0, finished entries published
-  //      to LDS (L and L') as soon as they are final
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    double v = acc[j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) v = mad<STRICT>(-acc[k], sl.L[j * NX + k], v);
-    if (grp == 0 && i >= j) acc[j] = v;
-    if (grp == 0 && i == j) sl.piv[j] = v;
-    __syncthreads();
-    const double pivot = sl.piv[j];
-    if (!(pivot > 0.0)) ok = false;
-    if constexpr (STRICT) {
-      const double root = sqrt(pivot);
-      if (grp == 0 && i >= j) acc[j] = acc[j] / root;
-    } else {
-      const double rinv = rsqrt(pivot);
-      if (grp == 0 && i >= j) acc[j] = acc[j] * rinv;
-      if (grp == 0 && i == j) sl.piv[j] = rinv;  // reciprocal of L(j,j) for the solves
-    }
-    if (grp == 0 && i >= j) {
-      sl.L[i * NX + j] = acc[j];
-      sl.Lt[j * NX + i] = acc[j];
-    }
-    __syncthreads();
-  }
-  if (!ok && hl == 0 && live) atomicAdd(info + b, 1);
-
-  // ---- P3: one right-hand-side column per lane: L y = x (reads L'), then L' x = y (reads L)
-  const int which = hl / NX, col = hl - which * NX;
-  double x[NX];
-#pragma unroll
-  for (int k = 0; k < NX; ++k) x[k] = (hl == 2 * NX) ? sl.zs[k] : (which < 2 ? sl.Fm[which][k * NX + col] : 0.0);
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    if constexpr (STRICT) x[j] = x[j] / sl.L[j * NX + j]; else x[j] = x[j] * sl.piv[j];
-#pragma unroll
-    for (int r = j + 1; r < NX; ++r) x[r] = mad<STRICT>(-sl.Lt[j * NX + r], x[j], x[r]);
-  }
-#pragma unroll
-  for (int j = NX - 1; j >= 0; --j) {
-    if constexpr (STRICT) x[j] = x[j] / sl.L[j * NX + j]; else x[j] = x[j] * sl.piv[j];
-#pragma unroll
-    for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-sl.L[j * NX + r], x[j], x[r]);
-  }
-  // back to row-major in LDS so that the global stores are whole 16-byte-aligned rows
-  __syncthreads();
-  if (hl == 2 * NX) {
-#pragma unroll
-    for (int k = 0; k < NX; ++k) sl.zs[k] = x[k];
-  } else if (which < 2) {
-#pragma unroll
-    for (int k = 0; k < NX; ++k) sl.Fm[which][k * NX + col] = x[k];
-  }
-  __syncthreads();
-
-  // ---- store: factor of S-bar, f_a, f_bb (lambda rows of knot s+1) and the record f_a|f_bb|z_sep
-  if (live) {
-    double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
-    if (grp == 0) {
-      store_row<NX>(Fblk(F, d, b, l, s + 1) + i * NX, acc);
-      if (i == 0) {
-#pragma unroll
-        for (int k = 0; k < NX; ++k) { zs1[k] = sl.zs[k]; myrec[2 * NN + k] = sl.zs[k]; }
-      }
-    }
-    if (grp < 2) {
-      const int colidx = grp == 0 ? a : bb;
-      double row[NX];
-#pragma unroll
-      for (int c = 0; c < NX; ++c) row[c] = sl.Fm[grp][i * NX + c];
-      if (colidx >= 0) {
-        store_row<NX>(Fblk(F, d, b, colidx, s + 1) + i * NX, row);
-        store_row<NX>(myrec + grp * NN + i * NX, row);
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------- separator core
 // Shared by separator_one and bottom_small: the level-l separator of one subtree computed by ONE
 // wavefront from operands already in LDS. Written for instruction count: no data-dependent
@@ -382,9 +77,7 @@ struct alignas(16) SepIn {      // what a separator reads from its two neighbour
 template <int NX>
 struct alignas(16) SepOut {
   static constexpr int LD = 32;  // panel row length: [f_a (NX) | f_bb (NX) | z_sep | pad]
-  static constexpr int LS = NX + 1;  // padded row length of the S-bar / L matrix (bank spread)
   double X[NX * LD];             // right-hand sides in, solutions out; row k, column c
-  double S[NX * LS];             // S-bar, factored in place to L (row-major, padded)
   double rdiag[NX];              // fast mode: 1 / L(j,j)
 };
 
@@ -482,119 +175,10 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
   return bad;
 }
 
-// LDS-resident variant of the core: S-bar / L and the right-hand-side panel live in LDS and the
-// column loops of the Cholesky and of the two substitutions are ROLLED over the (wave-uniform)
-// pivot index j, with the row loops unrolled under scalar `r > j` tests. Every multiply-add is
-// then one VALU instruction fed by LDS reads (the L entry is an LDS broadcast, addressed with an
-// immediate offset from one base register), nothing is broadcast through v_readlane, and the
-// working set in registers is a handful of values -- high occupancy, short code. Same operations
-// in the same order as separator_core.
-template <int NX, int NU, bool STRICT, bool KEEPL>
-__device__ __forceinline__ bool separator_core_lds(const int lane, const double* __restrict__ abrow,
-                                                   const SepIn<NX, NU>& in, SepOut<NX>& out,
-                                                   double (&Lrow)[NX]) {
-  constexpr int W = NX + NU, LD = SepOut<NX>::LD, LS = SepOut<NX>::LS;
-  const int grp = lane / NX, gi = lane - grp * NX;
-  double ab[W];
-  load_row<W>(abrow, ab);
-
-  // P1 (registers): row gi of S-bar (group 0) / of f_a (group 1)
-  {
-    double acc[NX];
-#pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = 0.0;
-    const double* M = (grp == 1) ? in.Axu : in.Exu;
-#pragma unroll
-    for (int k = 0; k < W; ++k)
-#pragma unroll
-      for (int j = 0; j < NX; ++j) acc[j] = mad<STRICT>(ab[k], M[k * NX + j], acc[j]);
-    if (grp == 0) {
-      double accz = -in.z1[gi];
-#pragma unroll
-      for (int k = 0; k < W; ++k) accz = mad<STRICT>(ab[k], in.zxu[k], accz);
-      out.X[gi * LD + 2 * NX] = accz - in.z1[NX + gi];
-#pragma unroll
-      for (int j = 0; j < NX; ++j) out.S[gi * LS + j] = acc[j] - in.E1x[gi * NX + j];
-    } else if (grp == 1) {
-#pragma unroll
-      for (int j = 0; j < NX; ++j) {
-        out.X[gi * LD + j] = acc[j];
-        out.X[gi * LD + NX + j] = -in.B1x[gi * NX + j];
-      }
-    }
-  }
-  wave_lds_sync();
-
-  // P2: left-looking Cholesky in LDS. Lane i < NX owns row i; lanes >= NX shadow row gi (they
-  // compute the same values and do not store).
-  bool bad = false;
-  const bool rowlane = lane < NX;
-  double* myrow = out.S + gi * LS;
-#pragma unroll 1
-  for (int j = 0; j < NX; ++j) {
-    const double* rowj = out.S + j * LS;
-    double v = myrow[j];
-#pragma unroll
-    for (int k = 0; k < NX - 1; ++k)
-      if (k < j) v = mad<STRICT>(-myrow[k], rowj[k], v);
-    const bool below = gi >= j;
-    if (rowlane && (below || !KEEPL)) myrow[j] = v;
-    wave_lds_sync();
-    const double pivot = rowj[j];
-    bad = bad || !(pivot > 0.0);
-    double w;
-    if constexpr (STRICT) {
-      w = v / sqrt(pivot);
-    } else {
-      const double rinv = rsqrt(pivot);
-      w = v * rinv;
-      if (lane == 0) out.rdiag[j] = rinv;
-    }
-    if (rowlane && (below || !KEEPL)) myrow[j] = w;
-    wave_lds_sync();
-  }
-#pragma unroll
-  for (int j = 0; j < NX; ++j) Lrow[j] = myrow[j];
-
-  // P3: one right-hand-side column per lane, the column itself stays in the LDS panel
-  const int col = lane & (LD - 1);
-  double* xc = out.X + col;
-  const bool colane = lane < LD;  // lanes >= LD shadow a column (same values, no stores)
-#pragma unroll 1
-  for (int j = 0; j < NX; ++j) {
-    double xj = xc[j * LD];
-    if constexpr (STRICT) xj = xj / out.S[j * LS + j]; else xj = xj * out.rdiag[j];
-    if (colane) xc[j * LD] = xj;
-    const double* colj = out.S + j;  // L(r, j) = S[r * LS + j]
-#pragma unroll
-    for (int r = 1; r < NX; ++r)
-      if (r > j) {
-        const double t = mad<STRICT>(-colj[r * LS], xj, xc[r * LD]);
-        if (colane) xc[r * LD] = t;
-      }
-    wave_lds_sync();
-  }
-#pragma unroll 1
-  for (int j = NX - 1; j >= 0; --j) {
-    double xj = xc[j * LD];
-    if constexpr (STRICT) xj = xj / out.S[j * LS + j]; else xj = xj * out.rdiag[j];
-    if (colane) xc[j * LD] = xj;
-    const double* rowj = out.S + j * LS;  // L(j, r)
-#pragma unroll
-    for (int r = 0; r < NX - 1; ++r)
-      if (r < j) {
-        const double t = mad<STRICT>(-rowj[r], xj, xc[r * LD]);
-        if (colane) xc[r * LD] = t;
-      }
-    wave_lds_sync();
-  }
-  return bad;
-}
-
 // One wavefront per separator: stage the operands (whole rows, 16-byte loads), run the core,
 // store the record f_a | f_bb | z_sep and the lambda rows of knot s+1.
 //   grid (N >> (l+1), batch), block 64.
-template <int NX, int NU, bool STRICT, bool KEEP, int CORE>
+template <int NX, int NU, bool STRICT, bool KEEP>
 __global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double* __restrict__ AB,
                                                     double* F, double* z, double* __restrict__ rec,
                                                     int* __restrict__ info) {
@@ -626,8 +210,7 @@ __global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double*
   double Lrow[NX];
   const int gi = lane % NX;
   const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
-  const bool bad = CORE == 0 ? separator_core_lds<NX, NU, STRICT, KEEP>(lane, abrow, in, out, Lrow)
-                             : separator_core<NX, NU, STRICT, KEEP>(lane, abrow, in, out, Lrow);
+  const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, abrow, in, out, Lrow);
   __syncthreads();
   if (bad && lane == 0) atomicAdd(info + b, 1);
 
@@ -821,7 +404,7 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
 
 // ------------------------------------------------------------------------------------- apply
 // All upper levels J..K-1 for every knot in ONE pass (DESIGN.md "boundary-first"): once the
-// separator records of those levels exist (separator_small on the boundary knots, which
+// separator records of those levels exist (separator_one on the boundary knots, which
 // schur_small<BOUNDARY> keeps up to date), a knot's updates at successive levels only involve its
 // own rows: E (column l), the two live outer columns and its rhs entry stay in registers and
 // rotate from level to level; only the rhs (and, with KEEP, the finished columns) go back to HBM.
@@ -913,10 +496,10 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
 // broadcast, no idle waves), updates its two knots and rotates the column roles (see
 // apply_small). Written back: column JB and the live outer column of every knot plus its rhs
 // block -- what separator_*(JB) / schur / apply expect -- and, with KEEP, the finished columns
-// 0..JB-1. Arithmetic and order per element are those of leaf_generic + separator_small +
+// 0..JB-1. Arithmetic and order per element are those of leaf_generic + separator_one +
 // schur_small run level by level.
 //   grid (N >> JB, batch), block 32 << JB threads. Requires N > 2^JB.
-template <int NX, int NU, bool STRICT, bool KEEP, int JB, int CORE>
+template <int NX, int NU, bool STRICT, bool KEEP, int JB>
 __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double* __restrict__ AB,
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
@@ -1037,8 +620,7 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       double Lrow[NX];
       const int gi = lane % NX;
       const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
-      const bool bad = CORE == 0 ? separator_core_lds<NX, NU, STRICT, KEEP>(lane, abrow, xc, sout, Lrow)
-                                 : separator_core<NX, NU, STRICT, KEEP>(lane, abrow, xc, sout, Lrow);
+      const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, abrow, xc, sout, Lrow);
       if (bad && lane == 0) atomicAdd(info + b, 1);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
     }
@@ -1081,159 +663,6 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     else        { if (bb >= 0) store_row<NX>(Fblk(F, d, b, bb, i) + r * NX, Cb); }
     z[((size_t)b * N + i) * ROWS + r] = zz;
   }
-}
-
-// ------------------------------------------------------------------------------------- apply, 2 rows per lane
-// apply_small with a register tile of TWO rows per lane (rows p and p + HALF of the same knot):
-// every f value fetched from LDS feeds two FMAs, halving the LDS-broadcast traffic that bounds
-// apply_small. Lane = (knot, row pair), 64 / HALF knots per wavefront, 2 wavefronts per
-// workgroup. Same per-element operations and order as apply_small.
-//   grid (N / KPB2, batch), block 128, dynamic LDS = (K - J) * REC doubles; needs 2^(J+1) >= KPB2.
-template <int NX, int NU>
-struct Apply2Shape {
-  static constexpr int ROWS = 2 * NX + NU;
-  static constexpr int HALF = (ROWS + 1) / 2;   // row pairs per knot
-  static constexpr int KPW = 64 / HALF;         // knots per wavefront
-  static constexpr int WAVES = 2;
-  static constexpr int KPB2 = (KPW >= 4 ? 4 : (KPW >= 2 ? 2 : 1)) * WAVES;  // power of two
-  static constexpr int KPWU = KPB2 / WAVES;     // knots per wavefront actually used
-};
-
-template <int NX, int NU, bool STRICT, bool KEEP>
-__global__ __launch_bounds__(128) void apply2_small(Dims d, int J, double* F, double* z,
-                                                    const double* __restrict__ recs) {
-  using Sh = SchurShape<NX, NU>;
-  using A2 = Apply2Shape<NX, NU>;
-  constexpr int ROWS = A2::ROWS, HALF = A2::HALF, KPB = A2::KPB2, KPWU = A2::KPWU, REC = Sh::REC;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int N = d.N, K = d.K, b = blockIdx.y;
-  const int first = blockIdx.x * KPB;
-  for (int l = J; l < K; ++l) {
-    const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
-    const double* src = recs + ((size_t)b * N + qs) * REC;
-    double* dst = lds + (l - J) * REC;
-    for (int e = threadIdx.x; e < REC; e += 128) dst[e] = src[e];
-  }
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int kn = lane / HALF, p = lane - kn * HALF;
-  if (kn >= KPWU) return;
-  const int i = first + wave * KPWU + kn;
-  const int rr[2] = {p, p + HALF};
-  const bool rowok[2] = {true, p + HALF < ROWS};
-
-  int lstart = J;
-  {
-    const int mask = (1 << J) - 1;
-    if ((i & mask) == 0) lstart = (i == 0) ? K : __builtin_ctz(i);
-    else if ((i & mask) == mask) lstart = trailing_ones(i);
-    if (lstart > K - 1) lstart = K - 1;
-  }
-
-  double E[2][NX], Ca[2][NX], Cb[2][NX], zz[2] = {0.0, 0.0};
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int c = 0; c < NX; ++c) { E[t][c] = 0.0; Ca[t][c] = 0.0; Cb[t][c] = 0.0; }
-  double* zp = z + ((size_t)b * N + i) * ROWS;
-
-  for (int l = J; l < K; ++l) {
-    if (l < lstart) continue;
-    const int half = 1 << l, T = 2 << l;
-    const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
-    int a, bb;
-    outer_columns(base, l, N, a, bb);
-    const bool left = i <= s;
-    const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
-    const double* rc = lds + (l - J) * REC;
-    const double* fa = rc;
-    const double* fb = rc + NX * NX;
-    const double* zsep = rc + 2 * NX * NX;
-    bool active[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) active[t] = rowok[t] && (rr[t] >= NX || calc_lambda);
-
-    if (l == lstart) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (!rowok[t]) continue;
-        load_row<NX>(Fblk(F, d, b, l, i) + rr[t] * NX, E[t]);
-        if (left) { if (a >= 0) load_row<NX>(Fblk(F, d, b, a, i) + rr[t] * NX, Ca[t]); }
-        else      { if (bb >= 0) load_row<NX>(Fblk(F, d, b, bb, i) + rr[t] * NX, Cb[t]); }
-        zz[t] = zp[rr[t]];
-      }
-    } else if (KEEP) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (active[t]) store_row<NX>(Fblk(F, d, b, l, i) + rr[t] * NX, E[t]);
-    }
-
-    // Rows that must not change this level (lambda rows not yet eliminated) take part with a
-    // zero E row: acc + (-0 * f) leaves them bit-for-bit unchanged, so both rows of the tile run
-    // the same in-place FMAs and every f value read from LDS feeds two of them.
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int c = 0; c < NX; ++c) {
-        if (!active[t]) E[t][c] = 0.0;
-        if (!left) Ca[t][c] = 0.0;   // created this level
-        else Cb[t][c] = 0.0;
-      }
-    if (a >= 0) {
-#pragma unroll
-      for (int k = 0; k < NX; ++k) {
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-          const double f = fa[k * NX + c];
-          Ca[0][c] = mad<STRICT>(-E[0][k], f, Ca[0][c]);
-          Ca[1][c] = mad<STRICT>(-E[1][k], f, Ca[1][c]);
-        }
-        asm volatile("" ::: "memory");  // keep the LDS reads of row k next to their FMAs (registers)
-      }
-    }
-    if (bb >= 0) {
-#pragma unroll
-      for (int k = 0; k < NX; ++k) {
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-          const double f = fb[k * NX + c];
-          Cb[0][c] = mad<STRICT>(-E[0][k], f, Cb[0][c]);
-          Cb[1][c] = mad<STRICT>(-E[1][k], f, Cb[1][c]);
-        }
-        asm volatile("" ::: "memory");
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NX; ++k) {
-      const double f = zsep[k];
-      zz[0] = mad<STRICT>(-E[0][k], f, zz[0]);
-      zz[1] = mad<STRICT>(-E[1][k], f, zz[1]);
-    }
-    // lambda rows of knot s+1 receive the separator's results
-    if (i == s + 1) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (active[t] || !rowok[t]) continue;
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-          if (a >= 0) Ca[t][c] = fa[rr[t] * NX + c];
-          if (bb >= 0) Cb[t][c] = fb[rr[t] * NX + c];
-        }
-        zz[t] = zsep[rr[t]];
-      }
-    }
-    const bool left_child = (base & T) == 0;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int c = 0; c < NX; ++c) {
-        if (left_child) { E[t][c] = Cb[t][c]; Cb[t][c] = 0.0; }
-        else            { E[t][c] = Ca[t][c]; Ca[t][c] = 0.0; }
-      }
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) if (rowok[t]) zp[rr[t]] = zz[t];
 }
 
 }  // namespace ndlqr

@@ -67,10 +67,6 @@ struct NdlqrHipCtx {
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
-  int apply_variant; // 0 = apply_small (default), 1 = apply2_small (two rows per lane; not faster: 2 waves/SIMD)
-  int sep_variant; // 0 = register core (separator_one / bottom_small; default), 4 = LDS-resident core
-                   // (same kernels; measured slower: latency of the per-column LDS round trips),
-                   // 1 = separator_small, 2 = separator_pair (standalone separators only)
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;
@@ -119,8 +115,6 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
   c->fuse_level = -1;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
-  c->apply_variant = getenv("NDLQR_APPLY_VARIANT") ? atoi(getenv("NDLQR_APPLY_VARIANT")) : 0;
-  c->sep_variant = getenv("NDLQR_SEP_VARIANT") ? atoi(getenv("NDLQR_SEP_VARIANT")) : 0;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
@@ -269,12 +263,8 @@ template <int NX, int NU, bool STRICT, bool KEEP, int JB>
 static void launch_bottom(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   ScopedSlot t(c, SLOT_BOTTOM);
-  if (c->sep_variant == 4)
-    hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB, 0>), dim3(d.N >> JB, d.batch), dim3(32 << JB),
-                       0, c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info);
-  else
-    hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB, 1>), dim3(d.N >> JB, d.batch), dim3(32 << JB),
-                       0, c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+  hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), 0,
+                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info);
 }
 
 template <int NX, int NU, bool STRICT, bool KEEP>
@@ -300,18 +290,8 @@ static int launch_small(NdlqrHipCtx* c, int J) {
     {
       ScopedSlot t(c, SLOT_SEP);
       const int nsep = d.N >> (l + 1);
-      if (c->sep_variant == 4)
-        hipLaunchKernelGGL((ndlqr::separator_one<NX, NU, STRICT, KEEP, 0>), dim3(nsep, d.batch), dim3(64), 0,
-                           c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
-      else if (c->sep_variant == 0)
-        hipLaunchKernelGGL((ndlqr::separator_one<NX, NU, STRICT, KEEP, 1>), dim3(nsep, d.batch), dim3(64), 0,
-                           c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
-      else if (c->sep_variant == 2)
-        hipLaunchKernelGGL((ndlqr::separator_pair<NX, NU, STRICT>), dim3((nsep + 1) / 2, d.batch), dim3(64), 0,
-                           c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
-      else
-        hipLaunchKernelGGL((ndlqr::separator_small<NX, NU, STRICT>), dim3(nsep, d.batch), dim3(64), 0,
-                           c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
+      hipLaunchKernelGGL((ndlqr::separator_one<NX, NU, STRICT, KEEP>), dim3(nsep, d.batch), dim3(64), 0, c->stream,
+                         d, l, c->AB, c->F, c->z, c->rec, c->info);
     }
     if (l < J) {
       ScopedSlot t(c, SLOT_SCHUR);
@@ -328,14 +308,8 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   if (J < d.K) {
     ScopedSlot t(c, SLOT_APPLY);
     const size_t lds = sizeof(double) * (size_t)(d.K - J) * Sh::REC;
-    using A2 = ndlqr::Apply2Shape<NX, NU>;
-    if (c->apply_variant == 1 && (2 << J) >= A2::KPB2 && d.N >= A2::KPB2) {
-      hipLaunchKernelGGL((ndlqr::apply2_small<NX, NU, STRICT, KEEP>), dim3(d.N / A2::KPB2, d.batch), dim3(128), lds,
-                         c->stream, d, J, c->F, c->z, c->rec);
-    } else {
-      hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
-                         c->stream, d, J, c->F, c->z, c->rec);
-    }
+    hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
+                       c->stream, d, J, c->F, c->z, c->rec);
   }
   return NDLQR_OK;
 }

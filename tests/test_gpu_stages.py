@@ -129,3 +129,19 @@ def test_stage_functions_replay_reference_tests(ndlqr, oracle):
             for blk, tag in ((lam, "y"), (st, "x"), (inp, "u")):
                 assert np.linalg.norm(blk - load_json_matrix(SAMPLE, "E%d%d%s" % (i, upper, tag))) < TOL
     L.ndlqr_FreeNdLqrSolver(solver)
+
+
+def test_c_example_compiles_and_runs(ndlqr, tmp_path):
+    """examples/solve_json.c = the reference's canonical caller, compiled with plain gcc against
+    include/ndlqr.h and linked to librslqr_amd.so (drop-in at the source level)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "solve_json")
+    libdir = os.path.dirname(ndlqr.library_path())
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "solve_json.c"), "-L" + libdir, "-lrslqr_amd",
+                    "-Wl,-rpath," + libdir, "-lm", "-o", exe], check=True)
+    for fname, tol in (("lqr_prob.json", 1e-8), ("lqr_prob_256.json", 1e-6)):
+        out = subprocess.run([exe, os.path.join(GOLDEN, fname)], check=True, capture_output=True, text=True).stdout
+        line = [l for l in out.splitlines() if "||x - soln||_2" in l][0]
+        assert float(line.split("=")[1].split()[0]) < tol, out
