@@ -21,7 +21,7 @@ ARCH = "gfx950"
 
 C_SOURCES = ["containers.c", "synth.c", "json.c", "batch.c", "solver.c", "linalg.c", "stages.c"]
 HIP_SOURCES = ["ndlqr_hip.hip"]
-HIP_DEPS = ["kernels_common.hpp", "kernels_generic.hpp", "kernels_small.hpp"]
+HIP_DEPS = ["kernels_common.hpp", "kernels_generic.hpp", "kernels_small.hpp", "kernels_mfma.hpp"]
 
 
 def _hipcc():

@@ -20,6 +20,7 @@
 #include "kernels_common.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_small.hpp"
+#include "kernels_mfma.hpp"
 
 // ------------------------------------------------------------------------------ errors
 
@@ -67,6 +68,7 @@ struct NdlqrHipCtx {
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
+  bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;
@@ -114,6 +116,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
   c->fuse_level = -1;
+  c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
@@ -247,9 +250,22 @@ static int launch_generic(NdlqrHipCtx* c) {
     }
     {
       ScopedSlot t(c, SLOT_SCHUR);
-      const long work = (long)d.N * d.rows * d.n;
-      hipLaunchKernelGGL((ndlqr::schur_generic<STRICT>), dim3((unsigned)((work + 255) / 256), d.batch),
-                         dim3(256), 0, c->stream, d, l, c->F, c->z);
+      // block sizes that fill 16x16 MFMA tiles: Schur update on the fp64 matrix cores (fast mode)
+      const bool mfma = !STRICT && d.n % 16 == 0 && d.rows % 16 == 0 && d.n <= 64 && !c->no_mfma;
+      const size_t flds = sizeof(double) * (size_t)d.n * (d.n + 16);
+      if (mfma && d.n == 64)
+        hipLaunchKernelGGL((ndlqr::schur_mfma<4>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+      else if (mfma && d.n == 48)
+        hipLaunchKernelGGL((ndlqr::schur_mfma<3>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+      else if (mfma && d.n == 32)
+        hipLaunchKernelGGL((ndlqr::schur_mfma<2>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+      else if (mfma && d.n == 16)
+        hipLaunchKernelGGL((ndlqr::schur_mfma<1>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+      else {
+        const long work = (long)d.N * d.rows * d.n;
+        hipLaunchKernelGGL((ndlqr::schur_generic<STRICT>), dim3((unsigned)((work + 255) / 256), d.batch),
+                           dim3(256), 0, c->stream, d, l, c->F, c->z);
+      }
     }
   }
   return NDLQR_OK;

@@ -131,10 +131,12 @@ def test_json_fixture_through_dropin_api(ndlqr, oracle, fname):
     L.ndlqr_FreeNdLqrSolver(solver)
 
 
-@pytest.mark.parametrize("n,m,N,batch", [(64, 16, 32, 2), (32, 8, 64, 2), (20, 20, 16, 3)])
+@pytest.mark.parametrize("n,m,N,batch", [(64, 16, 32, 2), (32, 8, 64, 2), (20, 20, 16, 3), (32, 16, 64, 2),
+                                         (16, 16, 128, 3), (48, 16, 16, 2)])
 def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
     """Shapes without a specialised instance (config 5 family, nx=64 nu=16) run the runtime-sized
-    kernels: strict mode bit-exact, fast mode within tolerance."""
+    kernels; where the blocks fill 16x16 tiles the fast mode puts the Schur update on
+    v_mfma_f64_16x16x4_f64 (kernels_mfma.hpp). Strict mode bit-exact, fast mode within tolerance."""
     probs = [synth(ndlqr, n, m, N, 900 + p) for p in range(batch)]
     for strict in (True, False):
         bs = ndlqr.BatchSolver(n, m, N, batch, flags=(ndlqr.FLAG_STRICT_FP if strict else 0) | ndlqr.FLAG_KEEP_FACT)
