@@ -112,10 +112,18 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
 }
 
 // ------------------------------------------------------------------------------------- separators
-// grid (N / 2^(l+1), batch), block 256, dynamic LDS = (3 n^2 + n) doubles.
-// For the level-l separator s of each subtree: S-bar, the two outer right-hand sides fa, fb and
+// grid (N / 2^(l+1), batch), block 256, dynamic LDS = (n (n+1) + n (2n+1)) doubles.
+// For the level-l separator s of each subtree: S-bar, the two outer right-hand sides f_a, f_bb and
 // the rhs vector; Cholesky; solves; results stored in the lambda rows of knot s+1.
-template <bool STRICT>
+// LDS: S-bar / L with rows padded to n+1 (lane i walks row i: no bank conflicts), and ONE panel
+// X[n][2n+1] = [f_a | f_bb | z_sep]. Cholesky (right-looking) and both substitutions are
+// "scale row/column j, then rank-1 update of the rest" with a wavefront per row and a lane per
+// column -- the whole workgroup works on every pivot, no integer division in the loops. Every
+// element receives its updates in the reference's order (k resp. j ascending; descending in the
+// transposed sweep), so the results equal the left-looking / column-by-column reference loops.
+// P1MFMA (fast mode, n a multiple of 16, n+m of 4): the inner products run on
+// v_mfma_f64_16x16x4_f64, one 16x16 tile of S-bar / f_a per wavefront.
+template <bool STRICT, bool P1MFMA>
 __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, double* F, double* z,
                                   int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -124,96 +132,123 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
   int a, bb;
   outer_columns(base, l, N, a, bb);
+  const int ns = n + 1, xs = 2 * n + 1, ncols = 2 * n + 1;
   double* S = sm;
-  double* fa = S + n * n;
-  double* fbm = fa + n * n;
-  double* zs = fbm + n * n;
+  double* X = S + n * ns;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
 
   const double* ab = AB + ((size_t)b * N + s) * n * w;
   const double* Es = Fblk(F, d, b, l, s);
   const double* Es1 = Fblk(F, d, b, l, s + 1);
-  const double* Fas = a >= 0 ? Fblk(F, d, b, a, s) : nullptr;
-  const double* Fbs1 = bb >= 0 ? Fblk(F, d, b, bb, s + 1) : nullptr;
+  const double* Fas = a >= 0 ? Fblk(F, d, b, a, s) : Es;
+  const double* Fbs1 = bb >= 0 ? Fblk(F, d, b, bb, s + 1) : Es1;
   const double* zsl = z + ((size_t)b * N + s) * d.rows;
   double* zs1 = z + ((size_t)b * N + s + 1) * d.rows;
 
   // ---- P1: inner products. Row i of A_s, B_s against the state / input rows of knot s,
   //      minus the state rows of knot s+1 (its coupling block is [-I; 0]).
-  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-    const int i = e / n, j = e - i * n;
-    const double* arow = ab + i * w;
-    double acc = 0.0;
-    for (int k = 0; k < n; ++k) acc = mad<STRICT>(arow[k], Es[(n + k) * n + j], acc);
-    for (int k = 0; k < m; ++k) acc = mad<STRICT>(arow[n + k], Es[(2 * n + k) * n + j], acc);
-    S[e] = acc - Es1[(n + i) * n + j];
-    if (a >= 0) {
-      double acc2 = 0.0;
-      for (int k = 0; k < n; ++k) acc2 = mad<STRICT>(arow[k], Fas[(n + k) * n + j], acc2);
-      for (int k = 0; k < m; ++k) acc2 = mad<STRICT>(arow[n + k], Fas[(2 * n + k) * n + j], acc2);
-      fa[e] = acc2;
+  if constexpr (P1MFMA) {
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    const int li = lane & 15, lk = lane >> 4;
+    const int tiles = n / 16, ksteps = w / 4;
+    for (int item = wave; item < 2 * tiles * tiles; item += nwave) {
+      const int mat = item / (tiles * tiles), rt = (item / tiles) % tiles, ct = item % tiles;
+      const double* Bsrc = (mat == 0 ? Es : Fas) + (size_t)n * n;  // rows n.. of the block
+      const double* Arow = ab + (size_t)(16 * rt + li) * w + lk;
+      const double* Bcol = Bsrc + (size_t)lk * n + 16 * ct + li;
+      acc4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int q = 0; q < ksteps; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Arow[4 * q], Bcol[(size_t)4 * q * n], acc, 0, 0, 0);
+      if (mat == 0) {
+        double* dst = S + (16 * rt + lk) * ns + 16 * ct + li;
+        const double* e1 = Es1 + (size_t)(n + 16 * rt + lk) * n + 16 * ct + li;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[4 * g * ns] = acc[g] - e1[4 * g * n];
+      } else {
+        double* dst = X + (16 * rt + lk) * xs + 16 * ct + li;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[4 * g * xs] = acc[g];
+      }
     }
-    if (bb >= 0) fbm[e] = -Fbs1[(n + i) * n + j];
+    for (int i = wave; i < n; i += nwave)
+      for (int c = lane; c < n; c += 64) X[i * xs + n + c] = -Fbs1[(size_t)(n + i) * n + c];
+  } else {
+    for (int i = wave; i < n; i += nwave) {
+      const double* arow = ab + i * w;
+      for (int j = lane; j < n; j += 64) {
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc = mad<STRICT>(arow[k], Es[(n + k) * n + j], acc);
+        for (int k = 0; k < m; ++k) acc = mad<STRICT>(arow[n + k], Es[(2 * n + k) * n + j], acc);
+        S[i * ns + j] = acc - Es1[(n + i) * n + j];
+        double acc2 = 0.0;
+        for (int k = 0; k < n; ++k) acc2 = mad<STRICT>(arow[k], Fas[(n + k) * n + j], acc2);
+        for (int k = 0; k < m; ++k) acc2 = mad<STRICT>(arow[n + k], Fas[(2 * n + k) * n + j], acc2);
+        X[i * xs + j] = acc2;
+        X[i * xs + n + j] = -Fbs1[(n + i) * n + j];
+      }
+    }
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double* arow = ab + i * w;
     double acc = -zs1[i];  // beta = -1 on the old lambda entry (nested_dissection.c:125)
     for (int k = 0; k < n; ++k) acc = mad<STRICT>(arow[k], zsl[n + k], acc);
     for (int k = 0; k < m; ++k) acc = mad<STRICT>(arow[n + k], zsl[2 * n + k], acc);
-    zs[i] = acc - zs1[n + i];
+    X[i * xs + 2 * n] = acc - zs1[n + i];
   }
   __syncthreads();
 
-  // ---- P2: left-looking lower Cholesky in LDS, column by column.
+  // ---- P2: lower Cholesky in LDS, right-looking: finish column j, then subtract its outer
+  //      product from the remaining lower triangle (wavefront per column c, lane per row i >= c).
   for (int j = 0; j < n; ++j) {
-    for (int i = j + threadIdx.x; i < n; i += blockDim.x) {
-      double acc = S[i * n + j];
-      for (int k = 0; k < j; ++k) acc = mad<STRICT>(-S[i * n + k], S[j * n + k], acc);
-      S[i * n + j] = acc;
-    }
-    __syncthreads();
-    const double pivot = S[j * n + j];
+    const double pivot = S[j * ns + j];
     if (!(pivot > 0.0)) {  // uniform: every thread reads the same LDS word
       if (threadIdx.x == 0) atomicAdd(info + b, 1);
       break;
     }
     const double root = sqrt(pivot);
     __syncthreads();
-    for (int i = j + threadIdx.x; i < n; i += blockDim.x) S[i * n + j] /= root;
+    for (int i = j + threadIdx.x; i < n; i += blockDim.x) S[i * ns + j] /= root;
+    __syncthreads();
+    for (int c = j + 1 + wave; c < n; c += nwave) {
+      const double lcj = S[c * ns + j];
+      for (int i = c + lane; i < n; i += 64) S[i * ns + c] = mad<STRICT>(-S[i * ns + j], lcj, S[i * ns + c]);
+    }
     __syncthreads();
   }
-  __syncthreads();
 
-  // ---- P3: forward then transposed substitution, one thread per right-hand-side column.
-  const int ncols = 2 * n + 1;
-  for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-    double* x;
-    int stride;
-    if (c < n) { if (a < 0) continue; x = fa + c; stride = n; }
-    else if (c < 2 * n) { if (bb < 0) continue; x = fbm + (c - n); stride = n; }
-    else { x = zs; stride = 1; }
-    for (int j = 0; j < n; ++j) {
-      const double xj = x[j * stride] / S[j * n + j];
-      x[j * stride] = xj;
-      for (int i = j + 1; i < n; ++i) x[i * stride] = mad<STRICT>(-S[i * n + j], xj, x[i * stride]);
+  // ---- P3: L Y = X (forward), then L' X = Y (transposed), all 2n+1 columns at once
+  for (int j = 0; j < n; ++j) {
+    const double piv = S[j * ns + j];
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
+    __syncthreads();
+    for (int i = j + 1 + wave; i < n; i += nwave) {
+      const double lij = S[i * ns + j];
+      for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lij, X[j * xs + c], X[i * xs + c]);
     }
-    for (int j = n - 1; j >= 0; --j) {
-      const double xj = x[j * stride] / S[j * n + j];
-      x[j * stride] = xj;
-      for (int i = 0; i < j; ++i) x[i * stride] = mad<STRICT>(-S[j * n + i], xj, x[i * stride]);
-    }
+    __syncthreads();
   }
-  __syncthreads();
+  for (int j = n - 1; j >= 0; --j) {
+    const double piv = S[j * ns + j];
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
+    __syncthreads();
+    for (int i = wave; i < j; i += nwave) {
+      const double lji = S[j * ns + i];
+      for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lji, X[j * xs + c], X[i * xs + c]);
+    }
+    __syncthreads();
+  }
 
   // ---- store into the lambda rows of knot s+1 (columns l, a, bb) and of the rhs
   double* outS = Fblk(F, d, b, l, s + 1);
   double* outa = a >= 0 ? Fblk(F, d, b, a, s + 1) : nullptr;
   double* outb = bb >= 0 ? Fblk(F, d, b, bb, s + 1) : nullptr;
-  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-    outS[e] = S[e];
-    if (outa) outa[e] = fa[e];
-    if (outb) outb[e] = fbm[e];
-  }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) zs1[i] = zs[i];
+  for (int i = wave; i < n; i += nwave)
+    for (int c = lane; c < n; c += 64) {
+      outS[i * n + c] = S[i * ns + c];
+      if (outa) outa[i * n + c] = X[i * xs + c];
+      if (outb) outb[i * n + c] = X[i * xs + n + c];
+    }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) zs1[i] = X[i * xs + 2 * n];
 }
 
 // ------------------------------------------------------------------------------------- Schur update

@@ -236,7 +236,7 @@ static int launch_generic(NdlqrHipCtx* c) {
     hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
                        c->AB, c->QR, c->rhs, c->F, c->z, c->info);
   }
-  const size_t lds = sizeof(double) * ((size_t)3 * d.n * d.n + d.n);
+  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (2 * d.n + 1));
   if (lds > 160 * 1024) {
     g_last_error = "nstates too large for the generic separator kernel's LDS staging";
     return NDLQR_ERR_INVALID;
@@ -245,8 +245,13 @@ static int launch_generic(NdlqrHipCtx* c) {
     const int nsub = d.N >> (l + 1);
     {
       ScopedSlot t(c, SLOT_SEP);
-      hipLaunchKernelGGL((ndlqr::separator_generic<STRICT>), dim3(nsub, d.batch), dim3(256), lds,
-                         c->stream, d, l, c->AB, c->F, c->z, c->info);
+      const bool p1mfma = !STRICT && d.n % 16 == 0 && d.w % 4 == 0 && !c->no_mfma;
+      if (p1mfma)
+        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, true>), dim3(nsub, d.batch), dim3(256), lds,
+                           c->stream, d, l, c->AB, c->F, c->z, c->info);
+      else
+        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, false>), dim3(nsub, d.batch), dim3(256), lds,
+                           c->stream, d, l, c->AB, c->F, c->z, c->info);
     }
     {
       ScopedSlot t(c, SLOT_SCHUR);
