@@ -173,10 +173,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback for the product path)", file=sys.stderr)
         sys.exit(2)
+    # Rehearsal hooks (not used by the driver): NDLQR_BENCH_SAME_DEVICE=1 puts every rank on GPU 0
+    # and NDLQR_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 control flow can be exercised
+    # on a one-GPU box.
+    if os.environ.get("NDLQR_BENCH_SAME_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("NDLQR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import rslqr_amd
     n, m, N, batch = args.nx, args.nu, args.horizon, args.batch
@@ -207,7 +216,8 @@ def main():
     fails = bs.cholesky_failures()
     prof = bs.profile()
 
-    elapsed_max, fails_max = sharding.max_over_ranks([elapsed, float(fails)], device="cuda")
+    elapsed_max, fails_max = sharding.max_over_ranks([elapsed, float(fails)],
+                                                     device="cuda" if backend == "nccl" else "cpu")
     fails_max = int(fails_max)
 
     if rank == 0:
@@ -251,7 +261,7 @@ def main():
             "metric": "LQR solves/sec (nx=%d,nu=%d,N=%d,batch=%d per GPU)" % (n, m, N, batch),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
-            "ms_per_solve": elapsed_max / args.steps * 1e3 / batch,
+            "ms_per_solve": 1e3 / value,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (seeded splitmix64 family of SURVEY.md 8d, time-varying A,B,Q,R)",
             "config": {"workload": "nx=%d nu=%d N=%d batch=%d per GPU, fp64, factor+solve per step"

@@ -312,6 +312,12 @@ int ndlqr_InitializeBatchFlat(NdLqrBatchSolver* bs, const double* A, const doubl
  * host, packed and uploaded. */
 int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0);
 int ndlqr_SolveBatch(NdLqrBatchSolver* bs);      /* launch + wait */
+/* Factor / solve split (MPC re-solves): replace q, r, d, x0 (flat layout as above) and run only
+ * the solution sweep against the factorisation cached by the last ndlqr_SolveBatch; needs
+ * NDLQR_FLAG_KEEP_FACT to have been set for that solve. A, B, Q, R are those of that solve. */
+int ndlqr_BatchSetRhsFlat(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
+                          const double* x0);
+int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs);
 int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs); /* enqueue on the solver's stream */
 int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
 int ndlqr_BatchNumVars(const NdLqrBatchSolver* bs);

@@ -55,6 +55,11 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* ctx, void** out5);
  * context's stream; HIP events bracket the sequence. */
 int ndlqr_hip_solve_async(NdlqrHipCtx* ctx);
 int ndlqr_hip_synchronize(NdlqrHipCtx* ctx);
+/* Factor / solve split: new right-hand side(s) against the factorisation cached by the last
+ * ndlqr_hip_solve_async with NDLQR_FLAG_KEEP_FACT (the reference's solution sweep,
+ * src/solve.c:137-182, alone). rhs layout as in ndlqr_hip_upload_inputs. */
+int ndlqr_hip_upload_rhs(NdlqrHipCtx* ctx, int p0, int count, const double* rhs);
+int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* ctx);
 double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
 
 /* D2H. soln: count*nvars doubles, nvars = (2n+m)N - m (src/solve.c:192-201).

@@ -212,6 +212,8 @@ def lib():
     proto("ndlqr_InitializeBatchFlat", ci, vp, dp, dp, dp, dp, dp, dp, dp, dp)
     proto("ndlqr_InitializeBatchSynthetic", ci, vp, cu64)
     proto("ndlqr_SolveBatch", ci, vp)
+    proto("ndlqr_BatchSetRhsFlat", ci, vp, dp, dp, dp, dp)
+    proto("ndlqr_SolveBatchRhsOnly", ci, vp)
     proto("ndlqr_SolveBatchAsync", ci, vp)
     proto("ndlqr_BatchSynchronize", ci, vp)
     proto("ndlqr_BatchNumVars", ci, vp)
@@ -315,6 +317,16 @@ class BatchSolver:
 
     def solve(self):
         return self.L.ndlqr_SolveBatch(self.h)
+
+    def set_rhs_flat(self, q, r, d, x0):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (q, r, d, x0)]
+        err = self.L.ndlqr_BatchSetRhsFlat(self.h, *[_ptr(a) for a in arrs])
+        if err:
+            raise RuntimeError("ndlqr_BatchSetRhsFlat failed: %d" % err)
+
+    def solve_rhs_only(self):
+        """Solution sweep against the cached factorisation (needs FLAG_KEEP_FACT on the solve)."""
+        return self.L.ndlqr_SolveBatchRhsOnly(self.h)
 
     def solve_async(self):
         return self.L.ndlqr_SolveBatchAsync(self.h)

@@ -206,6 +206,33 @@ int ndlqr_batch_upload_from_mirrors(NdLqrBatchSolver* bs, const NdData* data,
   return flush(bs, 0, 1);
 }
 
+int ndlqr_BatchSetRhsFlat(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
+                          const double* x0) {
+  if (!bs || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;
+  const size_t n = (size_t)bs->n, m = (size_t)bs->m, N = (size_t)bs->N;
+  int slot = 0, p0 = 0;
+  for (int p = 0; p < bs->batch; ++p) {
+    const double* qp = q + p * N * n; const double* rp = r + p * N * m;
+    const double* dp = d + p * N * n; const double* x0p = x0 + p * n;
+    for (size_t k = 0; k < N; ++k)
+      pack_rhs(bs, slot, (int)k, k == 0 ? x0p : dp + (k - 1) * n, qp + k * n, rp + k * m);
+    if (++slot == bs->chunk || p == bs->batch - 1) {
+      int err = ndlqr_hip_upload_rhs(bs->ctx, p0, slot, bs->hrhs);
+      if (err) return err;
+      p0 += slot;
+      slot = 0;
+    }
+  }
+  return NDLQR_OK;
+}
+
+int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs) {
+  if (!bs) return NDLQR_ERR_INVALID;
+  int err = ndlqr_hip_solve_rhs_async(bs->ctx);
+  if (err) return err;
+  return ndlqr_hip_synchronize(bs->ctx);
+}
+
 int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs) {
   return bs ? ndlqr_hip_solve_async(bs->ctx) : NDLQR_ERR_INVALID;
 }

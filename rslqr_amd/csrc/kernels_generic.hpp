@@ -304,6 +304,110 @@ __global__ void schur_generic(Dims d, int l, double* F, double* z) {
   }
 }
 
+// ------------------------------------------------------------------------------------- rhs-only sweep
+// Factor / solve split (the reference cannot separate them, docs/rslqr_usage.dox):
+// with the complete factor array kept on the device (NDLQR_FLAG_KEEP_FACT) a new right-hand side
+// only needs the reference's solution sweep (src/solve.c:137-182) -- per level: inner product
+// with the rhs, solve with the cached Cholesky factor of S-bar, propagate with column l of the
+// factorisation -- preceded by the rhs part of the leaf phase. Same operations and order as the
+// rhs column of the fused solve, so the results are identical to a full re-solve.
+template <bool STRICT>
+__global__ void rhs_leaf_generic(Dims d, const double* __restrict__ QR, const double* __restrict__ rhs,
+                                 double* __restrict__ z) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int n = d.n, w = d.w, rows = d.rows, N = d.N;
+  const double* qr = QR + ((size_t)b * N + k) * w;
+  const double* r0 = rhs + ((size_t)b * N + k) * rows;
+  double* zk = z + ((size_t)b * N + k) * rows;
+  const bool last = (k == N - 1);
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+    double v = r0[i];
+    if (k == 0 && i < n) {
+      v = mad<STRICT>(-qr[i], r0[i], -r0[n + i]);
+    } else if (k == 0 && i < 2 * n) {
+      v = -r0[i - n];
+    } else if (i >= n && (i < 2 * n || !last)) {
+      const double sc = qr[i - n] / sqrt(qr[i - n]);
+      v = (v / sc) / sc;
+    }
+    zk[i] = v;
+  }
+}
+
+// grid (N >> (l+1), batch), block 64 (one wavefront), dynamic LDS n (n+1) + n doubles: the cached
+// factor is staged in LDS first (whole rows, coalesced) so that the substitutions do not pay a
+// global-memory round trip per pivot.
+template <bool STRICT>
+__global__ void rhs_separator_generic(Dims d, int l, const double* __restrict__ AB,
+                                      const double* __restrict__ F, double* z) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = d.n, m = d.m, w = d.w, N = d.N, b = blockIdx.y;
+  const int ns = n + 1;
+  double* Ls = sm;
+  double* v = sm + n * ns;
+  const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
+  const double* ab = AB + ((size_t)b * N + s) * n * w;
+  const double* zsl = z + ((size_t)b * N + s) * d.rows;
+  double* zs1 = z + ((size_t)b * N + s + 1) * d.rows;
+  const double* L = Fblk(F, d, b, l, s + 1);  // lambda rows: Cholesky factor of S-bar, row-major
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    const int i = e / n, j = e - i * n;
+    Ls[i * ns + j] = L[e];
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double* arow = ab + i * w;
+    double acc = -zs1[i];
+    for (int k = 0; k < n; ++k) acc = mad<STRICT>(arow[k], zsl[n + k], acc);
+    for (int k = 0; k < m; ++k) acc = mad<STRICT>(arow[n + k], zsl[2 * n + k], acc);
+    v[i] = acc - zs1[n + i];
+  }
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    if (threadIdx.x == 0) v[j] = v[j] / Ls[j * ns + j];
+    __syncthreads();
+    const double vj = v[j];
+    for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) v[i] = mad<STRICT>(-Ls[i * ns + j], vj, v[i]);
+    __syncthreads();
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    if (threadIdx.x == 0) v[j] = v[j] / Ls[j * ns + j];
+    __syncthreads();
+    const double vj = v[j];
+    for (int i = threadIdx.x; i < j; i += blockDim.x) v[i] = mad<STRICT>(-Ls[j * ns + i], vj, v[i]);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) zs1[i] = v[i];
+}
+
+// grid (ceil(N*rows / 256), batch), block 256: z(i)[r] -= F(i, l)(r, :) . z_sep ; one thread per
+// row, whole-row 16-byte loads when the row length allows it.
+template <bool STRICT>
+__global__ void rhs_update_generic(Dims d, int l, const double* __restrict__ F, double* z) {
+  const int n = d.n, rows = d.rows, N = d.N, b = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * rows) return;
+  const int i = e / rows, r = e - i * rows;
+  const int half = 1 << l;
+  const int s = ((i >> (l + 1)) << (l + 1)) + half - 1;
+  const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+  if (r < n && !calc_lambda) return;
+  const double* Erow = Fblk(F, d, b, l, i) + (size_t)r * n;
+  const double* zsep = z + ((size_t)b * N + s + 1) * rows;
+  double* g = z + ((size_t)b * N + i) * rows + r;
+  double acc = *g;
+  if ((n & 1) == 0) {
+    const double2* E2 = reinterpret_cast<const double2*>(Erow);
+    for (int k = 0; k < n / 2; ++k) {
+      const double2 ev = E2[k];
+      acc = mad<STRICT>(-ev.x, zsep[2 * k], acc);
+      acc = mad<STRICT>(-ev.y, zsep[2 * k + 1], acc);
+    }
+  } else {
+    for (int k = 0; k < n; ++k) acc = mad<STRICT>(-Erow[k], zsep[k], acc);
+  }
+  *g = acc;
+}
+
 // ------------------------------------------------------------------------------------- dense helpers
 // Device versions of the reference's internal routines, one element / column per thread.
 // C = alpha*op(A)*op(B) + beta*C  (linalg_custom.c:20-43): beta first, then k ascending.

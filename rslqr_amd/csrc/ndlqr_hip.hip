@@ -75,6 +75,7 @@ struct NdlqrHipCtx {
   bool timing_pending;
   double last_ms;
   int last_failures;
+  bool fact_valid;   // the device holds a complete factorisation (last solve ran with KEEP_FACT)
   // profile
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
@@ -118,7 +119,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->fuse_level = -1;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
-  c->timing_pending = false; c->last_ms = 0; c->last_failures = 0;
+  c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -369,6 +370,56 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   if (!(c->flags & NDLQR_FLAG_GENERIC)) done = try_launch_small(c, strict, &err);
   if (!done) err = strict ? launch_generic<true>(c) : launch_generic<false>(c);
   if (err) return err;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+  c->timing_pending = true;
+  c->fact_valid = (c->flags & (NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_GENERIC)) != 0;
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
+  if (!c || !rhs || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t sz = (size_t)d.N * d.rows;
+  HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NDLQR_OK;
+}
+
+template <bool STRICT>
+static void launch_rhs_sweep(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  {
+    ScopedSlot t(c, SLOT_LEAF);
+    hipLaunchKernelGGL((ndlqr::rhs_leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(64), 0, c->stream, d, c->QR,
+                       c->rhs, c->z);
+  }
+  for (int l = 0; l < d.K; ++l) {
+    {
+      ScopedSlot t(c, SLOT_SEP);
+      hipLaunchKernelGGL((ndlqr::rhs_separator_generic<STRICT>), dim3(d.N >> (l + 1), d.batch), dim3(64),
+                         sizeof(double) * ((size_t)d.n * (d.n + 1) + d.n), c->stream, d, l, c->AB, c->F, c->z);
+    }
+    {
+      ScopedSlot t(c, SLOT_SCHUR);
+      const int work = d.N * d.rows;
+      hipLaunchKernelGGL((ndlqr::rhs_update_generic<STRICT>), dim3((work + 255) / 256, d.batch), dim3(256), 0,
+                         c->stream, d, l, c->F, c->z);
+    }
+  }
+}
+
+int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
+  if (!c) return NDLQR_ERR_INVALID;
+  if (!c->fact_valid) {
+    g_last_error = "rhs-only solve needs a previous solve with NDLQR_FLAG_KEEP_FACT (cached factorisation)";
+    fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+    return NDLQR_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  if (c->flags & NDLQR_FLAG_STRICT_FP) launch_rhs_sweep<true>(c); else launch_rhs_sweep<false>(c);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->timing_pending = true;

@@ -185,3 +185,36 @@ def test_env_variants_agree(ndlqr, oracle):
         outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+@pytest.mark.parametrize("n,m,N", [(12, 4, 64), (6, 3, 32), (5, 2, 16), (32, 16, 16)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
+    """Factor once (KEEP_FACT), then new q, r, d, x0 through the rhs-only sweep: must equal a full
+    solve of the problem with the new right-hand side (bit-exact in strict mode)."""
+    batch = 3
+    first = [synth(ndlqr, n, m, N, 300 + p) for p in range(batch)]
+    other = [synth(ndlqr, n, m, N, 700 + p) for p in range(batch)]
+    mixed = [Problem(n, m, N, f.A, f.B, f.Q, f.R, o.q, o.r, o.d, o.x0) for f, o in zip(first, other)]
+    fl = (ndlqr.FLAG_STRICT_FP if strict else 0) | ndlqr.FLAG_KEEP_FACT
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=fl)
+    bs.initialize_flat(*stack(first))
+    assert bs.solve() == 0
+    bs.set_rhs_flat(*[np.stack([getattr(p, k) for p in mixed]) for k in ("q", "r", "d", "x0")])
+    assert bs.solve_rhs_only() == 0
+    sol = bs.solutions()
+    for p, prob in enumerate(mixed):
+        z, _, _, _ = oracle.solve(prob, 1)
+        ref = z[: prob.nvars]
+        if strict:
+            assert np.array_equal(sol[p], ref)
+        else:
+            assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+    bs.close()
+    # without a cached factorisation the call is refused
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*stack(first))
+    assert bs.solve() == 0
+    if (n, m) in ((12, 4), (6, 3)):
+        assert bs.solve_rhs_only() == -1
+    bs.close()
