@@ -75,6 +75,11 @@ struct NdlqrHipCtx {
   bool timing_pending;
   double last_ms;
   int last_failures;
+  // the launch sequence captured as a hipGraph (replayed when nothing that shapes it changed)
+  hipGraphExec_t graph_exec;
+  unsigned graph_flags;
+  int graph_J, graph_JB;
+  hipStream_t graph_stream;
   bool fact_valid;   // the device holds a complete factorisation (last solve ran with KEEP_FACT)
   // profile
   std::vector<PendingEvent> pending;
@@ -120,6 +125,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
+  c->graph_exec = nullptr; c->graph_flags = 0; c->graph_J = c->graph_JB = -2; c->graph_stream = nullptr;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -148,6 +154,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
@@ -358,17 +365,46 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
   return false;
 }
 
-int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
-  if (!c) return NDLQR_ERR_INVALID;
-  HIP_TRY(hipSetDevice(c->device));
+// Enqueue leaf/bottom + per-level + apply launches on the context's stream.
+static int enqueue_solve(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int) * (size_t)d.batch, c->stream));
-  HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   const bool strict = (c->flags & NDLQR_FLAG_STRICT_FP) != 0;
   int err = NDLQR_OK;
   bool done = false;
   if (!(c->flags & NDLQR_FLAG_GENERIC)) done = try_launch_small(c, strict, &err);
   if (!done) err = strict ? launch_generic<true>(c) : launch_generic<false>(c);
+  return err;
+}
+
+int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
+  if (!c) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  int err = NDLQR_OK;
+  if (c->flags & NDLQR_FLAG_PROFILE) {
+    err = enqueue_solve(c);  // per-kernel events need eager launches
+  } else {
+    // The sequence is a fixed chain of up to 1 + 2K short launches: capture it once as a hipGraph
+    // and replay it (launch-bound single solves -- batch 1 -- gain the most).
+    const bool stale = !c->graph_exec || c->graph_flags != c->flags || c->graph_J != c->fuse_level ||
+                       c->graph_JB != c->bottom_levels || c->graph_stream != c->stream;
+    if (stale) {
+      if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      err = enqueue_solve(c);
+      hipError_t e = hipStreamEndCapture(c->stream, &graph);
+      if (err) { if (graph) (void)hipGraphDestroy(graph); return err; }
+      if (e != hipSuccess) return fail("hipStreamEndCapture", e);
+      e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) { c->graph_exec = nullptr; return fail("hipGraphInstantiate", e); }
+      c->graph_flags = c->flags; c->graph_J = c->fuse_level; c->graph_JB = c->bottom_levels;
+      c->graph_stream = c->stream;
+    }
+    HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+  }
   if (err) return err;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
