@@ -261,6 +261,11 @@ NdLqrProfile ndlqr_GetProfile(NdLqrSolver* solver);
 int ndlqr_Solve(NdLqrSolver* solver);
 Matrix ndlqr_GetSolution(NdLqrSolver* solver);
 int ndlqr_CopySolution(NdLqrSolver* solver, double* soln);
+/* additive: per-kernel HIP-event profiling of ndlqr_Solve (fills solver->profile like the
+ * reference's always-on profiler; default on). Off: the launch sequence is replayed as a captured
+ * hipGraph, which halves the latency of a single small solve; only t_total_ms / solve_time_ms are
+ * filled then. */
+int ndlqr_SetDeviceProfiling(NdLqrSolver* solver, int on);
 /* additive: copy the device factorisation into solver->fact->data (reference layout). */
 int ndlqr_SyncFactorsToHost(NdLqrSolver* solver);
 

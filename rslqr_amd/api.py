@@ -189,6 +189,7 @@ def lib():
     proto("ndlqr_GetSolution", Matrix, sp)
     proto("ndlqr_CopySolution", ci, sp, dp)
     proto("ndlqr_SyncFactorsToHost", ci, sp)
+    proto("ndlqr_SetDeviceProfiling", ci, sp, ci)
     # stage functions
     proto("ndlqr_SolveLeaf", ci, sp, ci)
     proto("ndlqr_SolveLeaves", ci, sp)

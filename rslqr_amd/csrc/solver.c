@@ -241,7 +241,10 @@ int ndlqr_Solve(NdLqrSolver* solver) {
   NdlqrHipCtx* ctx = (NdlqrHipCtx*)ndlqr_BatchDeviceContext(bs);
   /* a single solver keeps the whole factorisation on the device, like the reference keeps it in
    * solver->fact (ndlqr_SyncFactorsToHost copies it out on demand) */
-  ndlqr_hip_set_flags(ctx, ndlqr_hip_get_flags(ctx) | NDLQR_FLAG_PROFILE | NDLQR_FLAG_KEEP_FACT);
+  unsigned want = ndlqr_hip_get_flags(ctx) | NDLQR_FLAG_KEEP_FACT;
+  if (solver->linalg_time_ms < 0.0) want &= ~NDLQR_FLAG_PROFILE; else want |= NDLQR_FLAG_PROFILE;
+  const int profiling_off = solver->linalg_time_ms < 0.0;
+  ndlqr_hip_set_flags(ctx, want);
   ndlqr_hip_profile_reset(ctx);
   int err = ndlqr_batch_upload_from_mirrors(bs, solver->data, solver->diagonals, solver->soln->data);
   if (err) return err;
@@ -252,7 +255,7 @@ int ndlqr_Solve(NdLqrSolver* solver) {
   if (derr) return derr;
 
   solver->solve_time_ms = ndlqr_BatchSolveTimeMs(bs);
-  solver->linalg_time_ms = 0.0;
+  solver->linalg_time_ms = profiling_off ? -1.0 : 0.0;  /* < 0 marks "device profiling off" */
   ndlqr_ResetProfile(&solver->profile);
   /* Device kernels fuse the reference's phases differently: the leaf kernel maps to
    * t_leaves_ms; the per-level kernel (products + Cholesky + solves + Schur + rhs sweep)
@@ -280,6 +283,15 @@ int ndlqr_CopySolution(NdLqrSolver* solver, double* soln) {
   if (!solver) return -1;
   memcpy(soln, solver->soln->data, sizeof(double) * (size_t)solver->nvars);
   return solver->nvars;
+}
+
+int ndlqr_SetDeviceProfiling(NdLqrSolver* solver, int on) {
+  if (!solver) return -1;
+  /* linalg_time_ms is unused on the device path (the reference's global LA timer is compiled out
+   * by default, src/linalg_utils.h:4-12); its sign carries the switch so that the caller-visible
+   * struct layout stays the reference's. */
+  solver->linalg_time_ms = on ? 0.0 : -1.0;
+  return 0;
 }
 
 int ndlqr_SyncFactorsToHost(NdLqrSolver* solver) {

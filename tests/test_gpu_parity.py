@@ -111,6 +111,8 @@ def test_json_fixture_through_dropin_api(ndlqr, oracle, fname):
     assert np.linalg.norm(x - soln) < 1e-6  # the reference's own bar
     z, _, _, _ = oracle.solve(pyprob, 1)
     assert np.linalg.norm(x - z[:nvars]) / np.linalg.norm(z[:nvars]) <= REL_TOL
+    prof = L.ndlqr_GetProfile(solver)
+    assert prof.t_total_ms > 0 and prof.t_leaves_ms + prof.t_shur_ms > 0  # per-kernel events (default)
     view = L.ndlqr_GetSolution(solver)
     assert view.rows == nvars and view.cols == 1
     assert np.array_equal(view.numpy().ravel(), x)
@@ -122,6 +124,17 @@ def test_json_fixture_through_dropin_api(ndlqr, oracle, fname):
     assert L.ndlqr_Solve(solver) == 0
     L.ndlqr_CopySolution(solver, x.ctypes.data_as(C.POINTER(C.c_double)))
     assert np.linalg.norm(x - soln) < 1e-6
+    # hipGraph replay instead of per-kernel events: same answer
+    assert L.ndlqr_SetDeviceProfiling(solver, 0) == 0
+    prob2 = L.ndlqr_ReadLQRProblemJSONFile(path)
+    for _ in range(2):
+        assert L.ndlqr_InitializeWithLQRProblem(prob2, solver) == 0
+        assert L.ndlqr_Solve(solver) == 0
+        y = np.zeros(nvars)
+        L.ndlqr_CopySolution(solver, y.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.array_equal(y, x)
+    L.ndlqr_FreeLQRProblem(prob2)
+    assert solver.contents.solve_time_ms > 0
     # factor mirror on demand
     assert L.ndlqr_SyncFactorsToHost(solver) == 0
     _, fact, _, _ = oracle.solve(pyprob, 1, want_fact=True)
