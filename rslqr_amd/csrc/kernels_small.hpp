@@ -190,17 +190,22 @@ __global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double*
   int a, bb;
   outer_columns(base, l, N, a, bb);
   {
-    const double2* Es = reinterpret_cast<const double2*>(Fblk(F, d, b, l, s) + NN);
-    const double2* Fas = reinterpret_cast<const double2*>(Fblk(F, d, b, a >= 0 ? a : l, s) + NN);
-    const double2* E1 = reinterpret_cast<const double2*>(Fblk(F, d, b, l, s + 1) + NN);
-    const double2* B1 = reinterpret_cast<const double2*>(Fblk(F, d, b, bb >= 0 ? bb : l, s + 1) + NN);
-    for (int e = lane; e < W * NX / 2; e += 64) {
-      reinterpret_cast<double2*>(in.Exu)[e] = Es[e];
-      reinterpret_cast<double2*>(in.Axu)[e] = Fas[e];
-    }
-    for (int e = lane; e < NN / 2; e += 64) {
-      reinterpret_cast<double2*>(in.E1x)[e] = E1[e];
-      reinterpret_cast<double2*>(in.B1x)[e] = B1[e];
+    const double* Es = Fblk(F, d, b, l, s) + NN;
+    const double* Fas = Fblk(F, d, b, a >= 0 ? a : l, s) + NN;
+    const double* E1 = Fblk(F, d, b, l, s + 1) + NN;
+    const double* B1 = Fblk(F, d, b, bb >= 0 ? bb : l, s + 1) + NN;
+    if constexpr (NX % 2 == 0) {  // 16-byte copies (block and row offsets are even)
+      for (int e = lane; e < W * NX / 2; e += 64) {
+        reinterpret_cast<double2*>(in.Exu)[e] = reinterpret_cast<const double2*>(Es)[e];
+        reinterpret_cast<double2*>(in.Axu)[e] = reinterpret_cast<const double2*>(Fas)[e];
+      }
+      for (int e = lane; e < NN / 2; e += 64) {
+        reinterpret_cast<double2*>(in.E1x)[e] = reinterpret_cast<const double2*>(E1)[e];
+        reinterpret_cast<double2*>(in.B1x)[e] = reinterpret_cast<const double2*>(B1)[e];
+      }
+    } else {
+      for (int e = lane; e < W * NX; e += 64) { in.Exu[e] = Es[e]; in.Axu[e] = Fas[e]; }
+      for (int e = lane; e < NN; e += 64) { in.E1x[e] = E1[e]; in.B1x[e] = B1[e]; }
     }
     const double* zs = z + ((size_t)b * N + s) * ROWS;
     if (lane < W) in.zxu[lane] = zs[NX + lane];
@@ -333,8 +338,12 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
   __shared__ __attribute__((aligned(16))) double recl[BOUNDARY ? WAVES : 1][BOUNDARY ? REC : 2];
   if constexpr (BOUNDARY) {
     double* dst = recl[wave];
-    for (int e = lane; e < REC / 2; e += 64)
-      reinterpret_cast<double2*>(dst)[e] = reinterpret_cast<const double2*>(rcd)[e];
+    if constexpr (REC % 2 == 0) {
+      for (int e = lane; e < REC / 2; e += 64)
+        reinterpret_cast<double2*>(dst)[e] = reinterpret_cast<const double2*>(rcd)[e];
+    } else {
+      for (int e = lane; e < REC; e += 64) dst[e] = rcd[e];
+    }
     wave_lds_sync();
     rcd = dst;
     if (idle_lane) return;
@@ -526,6 +535,7 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
 
   // ---- stage [A | B] of my two knots (contiguous in memory)
   {
+    // two knots = 2 * NX * W doubles; the pair starts at an even multiple of NX * W: 16-byte aligned
     const double2* src = reinterpret_cast<const double2*>(AB + ((size_t)b * N + wgbase + 2 * wave) * NX * W);
     double2* dst = reinterpret_cast<double2*>(&me.ab[0][0]);
     for (int e = lane; e < NX * W; e += 64) dst[e] = src[e];

@@ -359,8 +359,11 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
     else        *err = keep ? launch_small<NX_, NU_, false, true>(c, J) : launch_small<NX_, NU_, false, false>(c, J); \
     return true;                                                                                    \
   }
-  NDLQR_SMALL_CASE(12, 4)
-  NDLQR_SMALL_CASE(6, 3)
+  NDLQR_SMALL_CASE(12, 4)  // quadrotor-sized headline shape
+  NDLQR_SMALL_CASE(6, 3)   // the reference's fixtures
+  NDLQR_SMALL_CASE(13, 4)  // quaternion quadrotor
+  NDLQR_SMALL_CASE(8, 4)
+  NDLQR_SMALL_CASE(4, 2)
 #undef NDLQR_SMALL_CASE
   return false;
 }

@@ -29,6 +29,7 @@ def stack(probs):
 
 
 SHAPES = [(6, 3, 8), (6, 3, 16), (6, 3, 64), (12, 4, 8), (12, 4, 16), (12, 4, 64), (5, 2, 32), (16, 8, 8),
+          (13, 4, 32), (8, 4, 64), (4, 2, 128),
           (3, 1, 2), (1, 1, 4), (7, 9, 16)]
 
 
