@@ -127,7 +127,7 @@ def cpu_baseline(n, m, N, probs, gpu_solutions):
         ref.L.ref_bench_throughput.restype = C.c_double
         ref.L.ref_bench_throughput.argtypes = [C.c_int] * 5 + [support.dp] * 8 + [C.c_int]
         ref.L.ref_bench_throughput(n, m, N, min(count, cores), 1, *args, cores)
-        reps = 2
+        reps = 3
         ms_ii = ref.L.ref_bench_throughput(n, m, N, count, reps, *args, cores)
         rate_ii = count * reps / (ms_ii * 1e-3)
         out.update(kind="reference", value=max(rate_i, rate_ii), unit="solves/s",
@@ -302,7 +302,7 @@ def main():
         if world == 1 and not args.no_cpu:
             cores = host_cores()
             log("cpu_baseline leg on %d cores" % cores)
-            count = args.cpu_sample or max(8, min(batch, 2 * cores))
+            count = args.cpu_sample or max(8, min(batch, 8 * cores))  # ~10 s of CPU work
             probs = [rslqr_amd.generate_synthetic(n, m, N, seed0 + p) for p in range(count)]
             gpu_sol = [bs.solution(p) for p in range(count)]
             base, worst = cpu_baseline(n, m, N, probs, gpu_sol)
