@@ -11,7 +11,7 @@
 //                    knot of every subtree only
 //   apply_small      every knot through all upper levels in registers, one pass
 //
-// Variants that were measured and dropped (numbers in DESIGN.md section 4): two separators per
+// Variants that were measured and dropped (numbers in DESIGN.md, "Tried and dropped"): two separators per
 // wavefront with L broadcast from LDS, an LDS-resident Cholesky/substitution with rolled pivot
 // loops, and an apply kernel with two rows per lane -- each lost to latency at low occupancy.
 #pragma once
@@ -296,7 +296,6 @@ struct SchurShape {
   static_assert(2 * ROWS <= 64, "two knots (2 * (2 NX + NU) rows) must fit a wavefront");
   static constexpr int WAVES = 4;
   static constexpr int KPB = KPW * WAVES;    // knots per workgroup
-  static constexpr int NREC = KPB / 2;       // subtrees a workgroup can span (level 0)
   static constexpr int REC = 2 * NX * NX + NX;  // doubles per record: f_a | f_bb | z_sep
 };
 
