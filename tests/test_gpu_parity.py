@@ -232,3 +232,75 @@ def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
     if (n, m) in ((12, 4), (6, 3)):
         assert bs.solve_rhs_only() == -1
     bs.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: the oracle is too slow to check every member, so parity rests on
+# size-independent properties -- the KKT residual of the raw problem (SURVEY.md 8c secondary
+# witness), linearity of the solution in the right-hand side, determinism -- plus a full oracle
+# comparison of a few sampled members.
+def _kkt_ok(oracle, prob, x):
+    res, bnorm = oracle.kkt_residual(prob, x)
+    return res <= 1e-9 * max(1.0, bnorm), (res, bnorm)
+
+
+@pytest.mark.parametrize("n,m,N,batch,sample", [(12, 4, 256, 1024, 12), (12, 4, 1024, 96, 4), (6, 3, 256, 1, 1),
+                                                (64, 16, 512, 4, 1)])
+def test_full_size_properties(ndlqr, oracle, n, m, N, batch, sample):
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_synthetic(1)
+    assert bs.solve() == 0 and bs.cholesky_failures() == 0
+    sol = bs.solutions()
+    assert np.isfinite(sol).all()
+    rng = np.random.default_rng(n * 1000 + N)
+    picks = sorted(set([0, batch - 1] + list(rng.integers(0, batch, size=sample))))
+    for p in picks:
+        prob = synth(ndlqr, n, m, N, 1 + p)  # problem p of ndlqr_InitializeBatchSynthetic(seed0 = 1)
+        ok, info = _kkt_ok(oracle, prob, sol[p])
+        assert ok, (p, info)
+    # full oracle comparison on two members (threads only speed the oracle up)
+    for p in picks[:2]:
+        prob = synth(ndlqr, n, m, N, 1 + p)
+        z, _, _, _ = oracle.solve(prob, 8)
+        ref = z[: prob.nvars]
+        assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+    # determinism: the same launch sequence gives the same bits
+    assert bs.solve() == 0
+    assert np.array_equal(bs.solutions(), sol)
+    bs.close()
+
+
+def test_linearity_in_the_right_hand_side(ndlqr):
+    """x(rhs1) + x(rhs2) == x(rhs1 + rhs2) for fixed A, B, Q, R (the KKT system is linear), checked
+    at the headline size on every member."""
+    n, m, N, batch = 12, 4, 256, 256
+    base = [ndlqr.generate_synthetic(n, m, N, 10 + p) for p in range(batch)]
+    alt = [ndlqr.generate_synthetic(n, m, N, 5000 + p) for p in range(batch)]
+    st = lambda lst, k: np.stack([g[k] for g in lst])
+    mats = [st(base, k) for k in ("A", "B", "Q", "R")]
+    r1 = [st(base, k) for k in ("q", "r", "d", "x0")]
+    r2 = [st(alt, k) for k in ("q", "r", "d", "x0")]
+    rsum = [a + b for a, b in zip(r1, r2)]
+    out = []
+    for rhs in (r1, r2, rsum):
+        bs = ndlqr.BatchSolver(n, m, N, batch)
+        bs.initialize_flat(*mats, *rhs)
+        assert bs.solve() == 0
+        out.append(bs.solutions())
+        bs.close()
+    err = np.linalg.norm(out[0] + out[1] - out[2], axis=1) / np.linalg.norm(out[2], axis=1)
+    assert err.max() <= 1e-10, err.max()
+
+
+@pytest.mark.parametrize("n,m,N", [(12, 4, 2), (12, 4, 4), (6, 3, 2), (6, 3, 4), (13, 4, 8), (4, 2, 8)])
+def test_short_horizons_specialised_shapes(ndlqr, oracle, n, m, N):
+    """Horizons too short for the fused kernels fall back to shorter fusion / the generic path."""
+    probs = [synth(ndlqr, n, m, N, 40 + p) for p in range(4)]
+    bs = ndlqr.BatchSolver(n, m, N, 4, flags=ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT)
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0
+    for p, prob in enumerate(probs):
+        z, fact, _, _ = oracle.solve(prob, 1, want_fact=True)
+        assert np.array_equal(bs.solution(p), z[: prob.nvars])
+        assert np.array_equal(bs.factors(p), fact)
+    bs.close()
