@@ -313,6 +313,11 @@ int ndlqr_InitializeBatch(NdLqrBatchSolver* bs, const LQRProblem* const* probs, 
 int ndlqr_InitializeBatchFlat(NdLqrBatchSolver* bs, const double* A, const double* B,
                               const double* Q, const double* R, const double* q,
                               const double* r, const double* d, const double* x0);
+/* Same flat layout, but DEVICE pointers (the problem is produced on the GPU): packed by a kernel
+ * on the solver's stream, no host round trip. */
+int ndlqr_InitializeBatchFlatDevice(NdLqrBatchSolver* bs, const double* dA, const double* dB,
+                                    const double* dQ, const double* dR, const double* dq,
+                                    const double* dr, const double* dd, const double* dx0);
 /* Seeded synthetic problems, problem p seeded with seed0 + p; generated on the
  * host, packed and uploaded. */
 int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0);

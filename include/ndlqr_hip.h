@@ -47,6 +47,12 @@ void* ndlqr_hip_get_stream(NdlqrHipCtx* ctx);
  * zero-padded KKT `data` array is never materialised (kernels read A,B,Q,R and the rhs directly). */
 int ndlqr_hip_upload_inputs(NdlqrHipCtx* ctx, int p0, int count, const double* AB,
                             const double* QR, const double* rhs);
+/* The same packing done ON the device from flat arrays that already live in HBM (reference
+ * layout: A [batch][N][n*n] and B [batch][N][n*m] column-major, Q,q,d [batch][N][n], R,r [batch][N][m],
+ * x0 [batch][n]); asynchronous on the context's stream. */
+int ndlqr_hip_pack_flat_device(NdlqrHipCtx* ctx, const double* A, const double* B, const double* Q,
+                               const double* R, const double* q, const double* r, const double* d,
+                               const double* x0);
 /* Device pointers for zero-copy producers (order: AB, QR, rhs, F, z). */
 int ndlqr_hip_device_pointers(NdlqrHipCtx* ctx, void** out5);
 

@@ -212,6 +212,7 @@ def lib():
     proto("ndlqr_InitializeBatch", ci, vp, C.POINTER(pp), ci)
     proto("ndlqr_InitializeBatchFlat", ci, vp, dp, dp, dp, dp, dp, dp, dp, dp)
     proto("ndlqr_InitializeBatchSynthetic", ci, vp, cu64)
+    proto("ndlqr_InitializeBatchFlatDevice", ci, vp, vp, vp, vp, vp, vp, vp, vp, vp)
     proto("ndlqr_SolveBatch", ci, vp)
     proto("ndlqr_BatchSetRhsFlat", ci, vp, dp, dp, dp, dp)
     proto("ndlqr_SolveBatchRhsOnly", ci, vp)
@@ -310,6 +311,12 @@ class BatchSolver:
         err = self.L.ndlqr_InitializeBatchFlat(self.h, *[_ptr(a) for a in arrs])
         if err:
             raise RuntimeError("ndlqr_InitializeBatchFlat failed: %d" % err)
+
+    def initialize_flat_device(self, *device_ptrs):
+        """Eight device pointers (ints), flat reference layout: A, B, Q, R, q, r, d, x0."""
+        err = self.L.ndlqr_InitializeBatchFlatDevice(self.h, *[C.c_void_p(int(p)) for p in device_ptrs])
+        if err:
+            raise RuntimeError("ndlqr_InitializeBatchFlatDevice failed: %d" % err)
 
     def initialize_synthetic(self, seed0):
         err = self.L.ndlqr_InitializeBatchSynthetic(self.h, seed0)

@@ -155,6 +155,13 @@ int ndlqr_InitializeBatchFlat(NdLqrBatchSolver* bs, const double* A, const doubl
   return NDLQR_OK;
 }
 
+int ndlqr_InitializeBatchFlatDevice(NdLqrBatchSolver* bs, const double* dA, const double* dB,
+                                    const double* dQ, const double* dR, const double* dq,
+                                    const double* dr, const double* dd, const double* dx0) {
+  if (!bs) return NDLQR_ERR_INVALID;
+  return ndlqr_hip_pack_flat_device(bs->ctx, dA, dB, dQ, dR, dq, dr, dd, dx0);
+}
+
 int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0) {
   if (!bs) return NDLQR_ERR_INVALID;
   const size_t n = (size_t)bs->n, m = (size_t)bs->m, N = (size_t)bs->N;

@@ -304,6 +304,39 @@ __global__ void schur_generic(Dims d, int l, double* F, double* z) {
   }
 }
 
+// ------------------------------------------------------------------------------------- device-side packing
+// The data movement of ndlqr_InitializeWithLQRProblem (src/solver.c:122-194) on the device, for
+// producers that already hold the problem in HBM in the flat reference layout (A [N][n*n] and
+// B [N][n*m] column-major, Q,q,d [N][n], R,r [N][m], x0 [n] per problem): transposes A, B into the
+// row-major [A | B] input, copies the diagonals and builds the negated right-hand side.
+// grid (N, batch), any block size.
+__global__ void pack_flat_generic(Dims d, const double* __restrict__ A, const double* __restrict__ B,
+                                  const double* __restrict__ Q, const double* __restrict__ R,
+                                  const double* __restrict__ q, const double* __restrict__ r,
+                                  const double* __restrict__ dd, const double* __restrict__ x0,
+                                  double* __restrict__ AB, double* __restrict__ QR, double* __restrict__ rhs) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int n = d.n, m = d.m, w = d.w, rows = d.rows, N = d.N;
+  const size_t pk = (size_t)b * N + k;
+  const double* Ak = A + pk * n * n;
+  const double* Bk = B + pk * n * m;
+  double* ab = AB + pk * n * w;
+  for (int e = threadIdx.x; e < n * w; e += blockDim.x) {
+    const int i = e / w, j = e - i * w;
+    ab[e] = j < n ? Ak[i + n * j] : Bk[i + n * (j - n)];
+  }
+  double* qr = QR + pk * w;
+  for (int e = threadIdx.x; e < w; e += blockDim.x) qr[e] = e < n ? Q[pk * n + e] : R[pk * m + (e - n)];
+  double* z = rhs + pk * rows;
+  for (int e = threadIdx.x; e < rows; e += blockDim.x) {
+    double v;
+    if (e < n) v = k == 0 ? -x0[(size_t)b * n + e] : -dd[(pk - 1) * n + e];
+    else if (e < 2 * n) v = -q[pk * n + (e - n)];
+    else v = k < N - 1 ? -r[pk * m + (e - 2 * n)] : 0.0;
+    z[e] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------- rhs-only sweep
 // Factor / solve split (the reference cannot separate them, docs/rslqr_usage.dox):
 // with the complete factor array kept on the device (NDLQR_FLAG_KEEP_FACT) a new right-hand side

@@ -201,6 +201,18 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   return NDLQR_OK;
 }
 
+int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B, const double* Q,
+                               const double* R, const double* q, const double* r, const double* d,
+                               const double* x0) {
+  if (!c || !A || !B || !Q || !R || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->d, A, B, Q, R,
+                     q, r, d, x0, c->AB, c->QR, c->rhs);
+  HIP_TRY(hipGetLastError());
+  c->fact_valid = false;
+  return NDLQR_OK;
+}
+
 int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
   if (!c || !out5) return NDLQR_ERR_INVALID;
   out5[0] = c->AB; out5[1] = c->QR; out5[2] = c->rhs; out5[3] = c->F; out5[4] = c->z;

@@ -304,3 +304,22 @@ def test_short_horizons_specialised_shapes(ndlqr, oracle, n, m, N):
         assert np.array_equal(bs.solution(p), z[: prob.nvars])
         assert np.array_equal(bs.factors(p), fact)
     bs.close()
+
+
+def test_device_side_packing_matches_host_packing(ndlqr):
+    """ndlqr_InitializeBatchFlatDevice (pack kernel, inputs already in HBM -- device memory comes
+    from torch here) gives the same bits as the host-packed upload."""
+    import torch
+    n, m, N, batch = 12, 4, 64, 6
+    probs = [synth(ndlqr, n, m, N, 60 + p) for p in range(batch)]
+    flat = stack(probs)
+    host = ndlqr.BatchSolver(n, m, N, batch, device=0)
+    host.initialize_flat(*flat)
+    assert host.solve() == 0
+    dev = ndlqr.BatchSolver(n, m, N, batch, device=0)
+    tens = [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in flat]
+    torch.cuda.synchronize()
+    dev.initialize_flat_device(*[t.data_ptr() for t in tens])
+    assert dev.solve() == 0
+    assert np.array_equal(dev.solutions(), host.solutions())
+    host.close(); dev.close()
