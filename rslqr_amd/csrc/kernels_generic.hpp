@@ -216,14 +216,49 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
     __syncthreads();
   }
 
-  // ---- P3: L Y = X (forward), then L' X = Y (transposed), all 2n+1 columns at once
+  // ---- P3: L Y = X (forward), then L' X = Y (transposed), all 2n+1 columns at once.
+  // Per pivot j the scaled row j is kept in registers (one value per lane and 64-column chunk),
+  // and each wavefront updates its rows two at a time so that the LDS round trips overlap.
+  constexpr int CH = 5;  // column chunks of 64 a lane may own: up to 2n+1 = 320 columns
+  auto sweep_rows = [&](int j, int i_begin, int i_end, bool transposed) {
+    double xj[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) { const int c = lane + 64 * q; xj[q] = c < ncols ? X[j * xs + c] : 0.0; }
+    int i = i_begin + wave;
+    for (; i + nwave < i_end; i += 2 * nwave) {
+      const int i2 = i + nwave;
+      const double l1 = transposed ? S[j * ns + i] : S[i * ns + j];
+      const double l2 = transposed ? S[j * ns + i2] : S[i2 * ns + j];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int c = lane + 64 * q;
+        if (c < ncols) {
+          const double a1 = X[i * xs + c], a2 = X[i2 * xs + c];
+          X[i * xs + c] = mad<STRICT>(-l1, xj[q], a1);
+          X[i2 * xs + c] = mad<STRICT>(-l2, xj[q], a2);
+        }
+      }
+    }
+    for (; i < i_end; i += nwave) {
+      const double l1 = transposed ? S[j * ns + i] : S[i * ns + j];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int c = lane + 64 * q;
+        if (c < ncols) X[i * xs + c] = mad<STRICT>(-l1, xj[q], X[i * xs + c]);
+      }
+    }
+  };
   for (int j = 0; j < n; ++j) {
     const double piv = S[j * ns + j];
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
     __syncthreads();
-    for (int i = j + 1 + wave; i < n; i += nwave) {
-      const double lij = S[i * ns + j];
-      for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lij, X[j * xs + c], X[i * xs + c]);
+    if (ncols <= 64 * CH) {
+      sweep_rows(j, j + 1, n, false);
+    } else {
+      for (int i = j + 1 + wave; i < n; i += nwave) {
+        const double lij = S[i * ns + j];
+        for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lij, X[j * xs + c], X[i * xs + c]);
+      }
     }
     __syncthreads();
   }
@@ -231,9 +266,13 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
     const double piv = S[j * ns + j];
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
     __syncthreads();
-    for (int i = wave; i < j; i += nwave) {
-      const double lji = S[j * ns + i];
-      for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lji, X[j * xs + c], X[i * xs + c]);
+    if (ncols <= 64 * CH) {
+      sweep_rows(j, 0, j, true);
+    } else {
+      for (int i = wave; i < j; i += nwave) {
+        const double lji = S[j * ns + i];
+        for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lji, X[j * xs + c], X[i * xs + c]);
+      }
     }
     __syncthreads();
   }
