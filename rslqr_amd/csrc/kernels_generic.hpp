@@ -132,7 +132,9 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
   int a, bb;
   outer_columns(base, l, N, a, bb);
-  const int ns = n + 1, xs = 2 * n + 1, ncols = 2 * n + 1;
+  const int ns = n + 1, ncols = 2 * n + 1;
+  // MFMA path: the panel is padded to whole 16-column tiles (zeroed), +1 keeps the pitch odd
+  const int xs = P1MFMA ? ((ncols + 15) / 16) * 16 + 1 : ncols;
   double* S = sm;
   double* X = S + n * ns;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -147,9 +149,9 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
 
   // ---- P1: inner products. Row i of A_s, B_s against the state / input rows of knot s,
   //      minus the state rows of knot s+1 (its coupling block is [-I; 0]).
+  typedef double acc4 __attribute__((ext_vector_type(4)));
+  const int li = lane & 15, lk = lane >> 4;
   if constexpr (P1MFMA) {
-    typedef double acc4 __attribute__((ext_vector_type(4)));
-    const int li = lane & 15, lk = lane >> 4;
     const int tiles = n / 16, ksteps = w / 4;
     for (int item = wave; item < 2 * tiles * tiles; item += nwave) {
       const int mat = item / (tiles * tiles), rt = (item / tiles) % tiles, ct = item % tiles;
@@ -170,8 +172,10 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
         for (int g = 0; g < 4; ++g) dst[4 * g * xs] = acc[g];
       }
     }
-    for (int i = wave; i < n; i += nwave)
+    for (int i = wave; i < n; i += nwave) {
       for (int c = lane; c < n; c += 64) X[i * xs + n + c] = -Fbs1[(size_t)(n + i) * n + c];
+      for (int c = ncols + lane; c < xs; c += 64) X[i * xs + c] = 0.0;  // tile padding
+    }
   } else {
     for (int i = wave; i < n; i += nwave) {
       const double* arow = ab + i * w;
@@ -199,6 +203,9 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
 
   // ---- P2: lower Cholesky in LDS, right-looking: finish column j, then subtract its outer
   //      product from the remaining lower triangle (wavefront per column c, lane per row i >= c).
+  //      MFMA path: blocked by 16 columns -- the rank-1 updates of a pivot only reach the end of
+  //      its 16-column panel, the rest of the lower triangle gets one rank-16 update per panel on
+  //      the matrix cores (different summation grouping than the reference: fast mode only).
   for (int j = 0; j < n; ++j) {
     const double pivot = S[j * ns + j];
     if (!(pivot > 0.0)) {  // uniform: every thread reads the same LDS word
@@ -209,11 +216,28 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
     __syncthreads();
     for (int i = j + threadIdx.x; i < n; i += blockDim.x) S[i * ns + j] /= root;
     __syncthreads();
-    for (int c = j + 1 + wave; c < n; c += nwave) {
+    const int cend = P1MFMA ? ((j >> 4) + 1) << 4 : n;  // columns this pivot updates directly
+    for (int c = j + 1 + wave; c < cend; c += nwave) {
       const double lcj = S[c * ns + j];
       for (int i = c + lane; i < n; i += 64) S[i * ns + c] = mad<STRICT>(-S[i * ns + j], lcj, S[i * ns + c]);
     }
     __syncthreads();
+    if (P1MFMA && (j & 15) == 15 && j + 1 < n) {
+      // rank-16 update of the trailing lower triangle with the finished panel [j0, j0+16)
+      const int j0 = j - 15, jb = j >> 4, nb = n >> 4, rem = nb - 1 - jb;
+      for (int item = wave; item < rem * rem; item += nwave) {
+        const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
+        if (ct > it) continue;  // lower triangle of tiles only
+        double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
+        acc4 acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                     S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+      }
+      __syncthreads();
+    }
   }
 
   // ---- P3: L Y = X (forward), then L' X = Y (transposed), all 2n+1 columns at once.
@@ -248,33 +272,66 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       }
     }
   };
+  const int ctiles = (ncols + 15) / 16;
   for (int j = 0; j < n; ++j) {
     const double piv = S[j * ns + j];
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
     __syncthreads();
+    const int iend = P1MFMA ? ((j >> 4) + 1) << 4 : n;  // MFMA path: rank-1 updates stay in the block
     if (ncols <= 64 * CH) {
-      sweep_rows(j, j + 1, n, false);
+      sweep_rows(j, j + 1, iend, false);
     } else {
-      for (int i = j + 1 + wave; i < n; i += nwave) {
+      for (int i = j + 1 + wave; i < iend; i += nwave) {
         const double lij = S[i * ns + j];
         for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lij, X[j * xs + c], X[i * xs + c]);
       }
     }
     __syncthreads();
+    if (P1MFMA && (j & 15) == 15 && j + 1 < n) {
+      // rows below the block: X[it] -= L[it, block] * X[block]   (rank-16 update, matrix cores)
+      const int j0 = j - 15, jb = j >> 4, nb = n >> 4, rem = nb - 1 - jb;
+      for (int item = wave; item < rem * ctiles; item += nwave) {
+        const int it = jb + 1 + item / ctiles, ct = item % ctiles;
+        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      __syncthreads();
+    }
   }
   for (int j = n - 1; j >= 0; --j) {
     const double piv = S[j * ns + j];
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
     __syncthreads();
+    const int ibeg = P1MFMA ? (j >> 4) << 4 : 0;
     if (ncols <= 64 * CH) {
-      sweep_rows(j, 0, j, true);
+      sweep_rows(j, ibeg, j, true);
     } else {
-      for (int i = wave; i < j; i += nwave) {
+      for (int i = ibeg + wave; i < j; i += nwave) {
         const double lji = S[j * ns + i];
         for (int c = lane; c < ncols; c += 64) X[i * xs + c] = mad<STRICT>(-lji, X[j * xs + c], X[i * xs + c]);
       }
     }
     __syncthreads();
+    if (P1MFMA && (j & 15) == 0 && j > 0) {
+      // rows above the block: X[it] -= L[block, it]' * X[block]
+      const int j0 = j, jb = j >> 4;
+      for (int item = wave; item < jb * ctiles; item += nwave) {
+        const int it = item / ctiles, ct = item % ctiles;
+        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(j0 + 4 * q + lk) * ns + 16 * it + li],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      __syncthreads();
+    }
   }
 
   // ---- store into the lambda rows of knot s+1 (columns l, a, bb) and of the rhs

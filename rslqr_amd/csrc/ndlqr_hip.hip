@@ -256,7 +256,8 @@ static int launch_generic(NdlqrHipCtx* c) {
     hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
                        c->AB, c->QR, c->rhs, c->F, c->z, c->info);
   }
-  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (2 * d.n + 1));
+  // S (n x (n+1)) + right-hand-side panel (n x pitch; pitch = 2n+1 padded to whole 16-column tiles + 1)
+  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (((2 * d.n + 1 + 15) / 16) * 16 + 1));
   if (lds > 160 * 1024) {
     g_last_error = "nstates too large for the generic separator kernel's LDS staging";
     return NDLQR_ERR_INVALID;
