@@ -24,6 +24,13 @@ __device__ __forceinline__ double mad(double a, double b, double acc) {
   }
 }
 
+// A Cholesky pivot was not positive: count it for problem b and in the batch total (slot
+// info[batch], the only word the host reads back after every solve).
+__device__ __forceinline__ void flag_failure(int* info, const Dims& d, int b) {
+  atomicAdd(info + b, 1);
+  atomicAdd(info + d.batch, 1);
+}
+
 // number of trailing one bits = tree level of separator k (src/binary_tree.c:9-37)
 __device__ __forceinline__ int trailing_ones(int k) { return __builtin_ctz(~k); }
 

@@ -39,7 +39,7 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
 
   // pivot check (clap_CholeskyFactorize fails on a pivot <= 0, linalg_custom.c:99-102)
   for (int i = threadIdx.x; i < n + (last ? 0 : m); i += blockDim.x)
-    if (!(qr[i] > 0.0)) atomicAdd(info + b, 1);
+    if (!(qr[i] > 0.0)) flag_failure(info, d, b);
 
   if (k == 0) {
     double* F0 = Fblk(F, d, b, 0, 0);
@@ -209,7 +209,7 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   for (int j = 0; j < n; ++j) {
     const double pivot = S[j * ns + j];
     if (!(pivot > 0.0)) {  // uniform: every thread reads the same LDS word
-      if (threadIdx.x == 0) atomicAdd(info + b, 1);
+      if (threadIdx.x == 0) flag_failure(info, d, b);
       break;
     }
     const double root = sqrt(pivot);

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double*
   const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
   const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, abrow, in, out, Lrow);
   __syncthreads();
-  if (bad && lane == 0) atomicAdd(info + b, 1);
+  if (bad && lane == 0) flag_failure(info, d, b);
 
   // stores: rows of the solved panel
   double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     if (!lam) {
       const double qv = qr[r - NX];
       if constexpr (STRICT) sc = qv / sqrt(qv); else rq = 1.0 / qv;
-      if (has_knot && !(qv > 0.0) && !(last && r >= 2 * NX)) atomicAdd(info + b, 1);
+      if (has_knot && !(qv > 0.0) && !(last && r >= 2 * NX)) flag_failure(info, d, b);
     }
     auto scale = [&](double v) -> double {
       if constexpr (STRICT) return (v / sc) / sc; else return v * rq;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       const int gi = lane % NX;
       const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
       const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, abrow, xc, sout, Lrow);
-      if (bad && lane == 0) atomicAdd(info + b, 1);
+      if (bad && lane == 0) flag_failure(info, d, b);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
     }
     __syncthreads();

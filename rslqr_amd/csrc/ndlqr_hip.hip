@@ -133,13 +133,13 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
             hipMalloc(&c->AB, bytes_AB(d)) == hipSuccess && hipMalloc(&c->QR, bytes_QR(d)) == hipSuccess &&
             hipMalloc(&c->rhs, bytes_z(d)) == hipSuccess && hipMalloc(&c->z, bytes_z(d)) == hipSuccess &&
             hipMalloc(&c->F, bytes_F(d)) == hipSuccess && hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
-            hipMalloc(&c->info, sizeof(int) * (size_t)batch) == hipSuccess;
+            hipMalloc(&c->info, sizeof(int) * ((size_t)batch + 1)) == hipSuccess;
   if (ok) {
     // Structural zeros of F are never written by the kernels; zero once so that the factor
     // download matches the reference's calloc'ed array (src/nddata.c:34).
     ok = hipMemsetAsync(c->F, 0, bytes_F(d), c->stream) == hipSuccess &&
          hipMemsetAsync(c->z, 0, bytes_z(d), c->stream) == hipSuccess &&
-         hipMemsetAsync(c->info, 0, sizeof(int) * (size_t)batch, c->stream) == hipSuccess &&
+         hipMemsetAsync(c->info, 0, sizeof(int) * ((size_t)batch + 1), c->stream) == hipSuccess &&
          hipStreamSynchronize(c->stream) == hipSuccess;
   }
   if (!ok) {
@@ -384,7 +384,7 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
 // Enqueue leaf/bottom + per-level + apply launches on the context's stream.
 static int enqueue_solve(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
-  HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int) * (size_t)d.batch, c->stream));
+  HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int) * ((size_t)d.batch + 1), c->stream));
   const bool strict = (c->flags & NDLQR_FLAG_STRICT_FP) != 0;
   int err = NDLQR_OK;
   bool done = false;
@@ -487,10 +487,8 @@ int ndlqr_hip_synchronize(NdlqrHipCtx* c) {
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     c->last_ms = ms;
     c->timing_pending = false;
-    std::vector<int> h(c->d.batch);
-    HIP_TRY(hipMemcpy(h.data(), c->info, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
-    int total = 0;
-    for (int v : h) total += v;
+    int total = 0;  // info[batch] = batch-wide count of non-positive pivots
+    HIP_TRY(hipMemcpy(&total, c->info + c->d.batch, sizeof(int), hipMemcpyDeviceToHost));
     c->last_failures = total;
   }
   for (auto& p : c->pending) {
