@@ -198,6 +198,7 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   HIP_TRY(hipMemcpyAsync(c->QR + p0 * sQR, QR, sizeof(double) * sQR * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host staging buffers are reused by the caller
+  c->fact_valid = false;  // new A, B, Q, R: a cached factorisation no longer matches the inputs
   return NDLQR_OK;
 }
 

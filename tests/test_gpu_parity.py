@@ -225,6 +225,13 @@ def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
         else:
             assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
     bs.close()
+    # new matrices invalidate the cached factorisation
+    bs2 = ndlqr.BatchSolver(n, m, N, batch, flags=fl)
+    bs2.initialize_flat(*stack(first))
+    assert bs2.solve() == 0
+    bs2.initialize_flat(*stack(other))
+    assert bs2.solve_rhs_only() == -1
+    bs2.close()
     # without a cached factorisation the call is refused
     bs = ndlqr.BatchSolver(n, m, N, batch)
     bs.initialize_flat(*stack(first))
