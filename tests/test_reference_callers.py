@@ -1,0 +1,71 @@
+"""The reference's own test programs, compiled unchanged against the drop-in.
+
+`oracle/Makefile` target `reftests` compiles test/{matrix,utils,binarytree,lqrdata,nddata,solver,
+linalg,nested_dissection}_test.c of the reference from where they lie (never copied) against
+`include/` and links them with `rslqr_amd/librslqr_amd.so`; the binaries land in
+`oracle/_ref/tests/` (git-ignored, they travel to the GPU box like `oracle/_ref/libref.so`).
+Their fixture macros (test/CMakeLists.txt:42-46 of the reference) point at the data copies in
+`tests/golden/`, so they run from the repo root.
+
+* host-only programs (containers, tree, JSON readers) run on the CPU here;
+* `solver_test`, `linalg_test`, `nested_dissection_test` run on the GPU: they call the stage
+  functions, the dense helpers and `ndlqr_Solve`, and assert the reference's literal golden
+  values (nested_dissection_test.c:44-105,133,166-229,277,299,307; linalg_test.c:19,55).
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "tests")
+HOST_ONLY = ["matrix", "utils", "binarytree", "lqrdata", "nddata"]
+DEVICE = ["solver", "linalg", "nested_dissection"]
+
+
+def _build_if_possible():
+    if os.path.isdir("/root/reference/test"):
+        import rslqr_amd.build as build
+
+        build.build()
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "reftests"], check=True,
+                       capture_output=True)
+
+
+def _run(name):
+    exe = os.path.join(BIN, name + "_test")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tests not built (needs /root/reference at build time)")
+    out = subprocess.run([exe], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    text = out.stdout + out.stderr
+    assert "TEST FAILED" not in text, text[-3000:]
+    assert "ALL TESTS PASSED!" in text, text[-3000:]
+    assert out.returncode == 0, text[-3000:]
+    return text
+
+
+@pytest.fixture(scope="module")
+def built():
+    _build_if_possible()
+
+
+@pytest.mark.parametrize("name", HOST_ONLY)
+def test_reference_host_program(built, name):
+    _run(name)
+
+
+def test_reference_device_programs_link(built):
+    """On the CPU box the device programs must at least have linked against the drop-in."""
+    if not os.path.isdir("/root/reference/test"):
+        pytest.skip("reference absent")
+    for name in DEVICE:
+        assert os.access(os.path.join(BIN, name + "_test"), os.X_OK), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", HOST_ONLY + DEVICE)
+def test_reference_program_on_gpu(name):
+    text = _run(name)
+    if name == "nested_dissection":
+        # the program prints its own final-solution error against lqr_prob.json's soln
+        assert "Accuracy of final solution" in text
