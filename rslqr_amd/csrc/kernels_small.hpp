@@ -495,6 +495,132 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
   *zp = zz;
 }
 
+// ------------------------------------------------------------------------------------- finish
+// Fast-mode replacement for apply_small when neither the finished factor columns (KEEP) nor the
+// reference's operation order (STRICT) is asked for. Above level J a knot row only contributes
+// to its own solution entry, and the map (E, C) -> (E', C') of one level (row_update followed by
+// rotate_roles) is linear and the same for every knot of a half-subtree:
+//     left half,  left child :  E' = -E f_bb      C' = C - E f_a
+//     left half,  right child:  E' = C - E f_a    C' = -E f_bb
+//     right half, left child :  E' = C - E f_bb   C' = -E f_a
+//     right half, right child:  E' = -E f_a       C' = C - E f_bb
+// so z_final = z - sum_l E_l z_sep(l) = z - [E_J C_J] w_J with the 2 NX-vector w_l of the knot's
+// half-subtree from the top-down recurrence (w_K = 0)
+//     w_l.E = z_sep(l) - P w_{l+1}.E - Q w_{l+1}.C,   (P, Q) = left child ? (f_bb, f_a) : (f_a, f_bb)
+//     w_l.C = (left half == left child) ? w_{l+1}.C : w_{l+1}.E
+// Two NX-term dot products per knot row instead of 2 NX^2 + NX multiply-adds per level; same
+// result up to rounding (tests: fast-mode tolerance against the oracle and the KKT residual).
+// Boundary knots join at the level where the boundary pass left them (lstart, see apply_small);
+// the lambda rows of knot s+1 start from the separator's own results one level higher.
+//   grid (N / KPB, batch), block 256, dynamic LDS = (K - J) * (REC + 2 * 2 NX) doubles; J >= 2.
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void finish_small(Dims d, int J, const double* __restrict__ F, double* z,
+                                                    const double* __restrict__ recs) {
+  using Sh = SchurShape<NX, NU>;
+  constexpr int ROWS = Sh::ROWS, KPW = Sh::KPW, KPB = Sh::KPB, REC = Sh::REC, NN = NX * NX;
+  constexpr int HB = 2, WV = 2 * NX;  // half-subtrees of a level that one workgroup can touch (l >= 2)
+  static_assert(KPB == 8, "half-subtree bookkeeping assumes eight knots per workgroup");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int N = d.N, K = d.K, b = blockIdx.y;
+  const int first = blockIdx.x * KPB;
+  double* wv = lds + (K - J) * REC;  // w of (level l, half-subtree hb) at wv[((l - J) * HB + hb) * WV]
+  for (int l = J; l < K; ++l) {
+    const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
+    const double* src = recs + ((size_t)b * N + qs) * REC;
+    double* dst = lds + (l - J) * REC;
+    for (int e = threadIdx.x; e < REC; e += 256) dst[e] = src[e];
+  }
+  __syncthreads();
+
+  for (int l = K - 1; l >= J; --l) {
+    const int nh = (KPB >> l) > 1 ? (KPB >> l) : 1;
+    if ((int)threadIdx.x < nh * WV) {
+      const int hb = threadIdx.x / WV, e = threadIdx.x - hb * WV;
+      const int h = (first >> l) + hb, sub = h >> 1;
+      const bool left = (h & 1) == 0, leftchild = (sub & 1) == 0;
+      int a, bb;
+      outer_columns(sub << (l + 1), l, N, a, bb);
+      const double* rc = lds + (l - J) * REC;
+      const bool top = (l == K - 1);
+      const double* wn = wv + ((top ? 0 : l + 1 - J) * HB) * WV;  // one half-subtree at l + 1 >= 3
+      double out = 0.0;
+      if (e < NX) {
+        out = rc[2 * NN + e];
+        if (!top) {
+          const double* P = leftchild ? rc + NN : rc;
+          const double* Q = leftchild ? rc : rc + NN;
+          const bool hasP = leftchild ? bb >= 0 : a >= 0, hasQ = leftchild ? a >= 0 : bb >= 0;
+          if (hasP) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) out = fma(-P[e * NX + c], wn[c], out);
+          }
+          if (hasQ) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) out = fma(-Q[e * NX + c], wn[NX + c], out);
+          }
+        }
+      } else if (!top) {
+        out = (left == leftchild) ? wn[e] : wn[e - NX];
+      }
+      wv[((l - J) * HB + hb) * WV + e] = out;
+    }
+    __syncthreads();
+  }
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kn = lane / ROWS, r = lane - kn * ROWS;
+  if (kn >= KPW) return;
+  const int i = first + wave * KPW + kn;
+  const bool lam = r < NX;
+  int l = J;
+  {
+    const int mask = (1 << J) - 1;
+    if ((i & mask) == 0) l = (i == 0) ? K : __builtin_ctz(i);
+    else if ((i & mask) == mask) l = trailing_ones(i);
+    if (l > K - 1) l = K - 1;
+  }
+  const int half = 1 << l, T = 2 << l;
+  const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+  int a, bb;
+  outer_columns(base, l, N, a, bb);
+  const bool left = i <= s;
+  const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+  double* zp = z + ((size_t)b * N + i) * ROWS + r;
+  if (!lam || calc_lambda) {
+    const double* w = wv + ((l - J) * HB + ((i >> l) - (first >> l))) * WV;
+    double E[NX];
+    load_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
+    double acc = *zp;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) acc = fma(-E[c], w[c], acc);
+    const int cc = left ? a : bb;
+    if (cc >= 0) {
+      load_row<NX>(Fblk(F, d, b, cc, i) + r * NX, E);
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc = fma(-E[c], w[NX + c], acc);
+    }
+    *zp = acc;
+  } else if (i == s + 1 && l + 1 < K) {
+    // lambda rows of knot s+1: z holds z_sep(l), the row's columns are f_a / f_bb of this level
+    const bool leftchild = (base & T) == 0;
+    const double* rc = lds + (l - J) * REC;
+    const double* w = wv + ((l + 1 - J) * HB) * WV;
+    const double* Ep = leftchild ? rc + NN + r * NX : rc + r * NX;
+    const double* Cp = leftchild ? rc + r * NX : rc + NN + r * NX;
+    const bool hasE = leftchild ? bb >= 0 : a >= 0, hasC = leftchild ? a >= 0 : bb >= 0;
+    double acc = *zp;
+    if (hasE) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc = fma(-Ep[c], w[c], acc);
+    }
+    if (hasC) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc = fma(-Cp[c], w[NX + c], acc);
+    }
+    *zp = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------- bottom
 // Leaf phase + tree levels 0..JB-1 in ONE launch, everything on chip: a workgroup owns 2^JB
 // consecutive knots, each wavefront two of them (lane = (knot, row)) with its rows of E, of the

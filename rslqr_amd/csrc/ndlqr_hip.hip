@@ -69,6 +69,7 @@ struct NdlqrHipCtx {
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
+  bool no_finish;     // NDLQR_NO_FINISH=1: fast mode keeps apply_small instead of finish_small (A/B timing)
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;
@@ -123,6 +124,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
   c->fuse_level = -1;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
+  c->no_finish = getenv("NDLQR_NO_FINISH") != nullptr;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_J = c->graph_JB = -2; c->graph_stream = nullptr;
@@ -350,6 +352,15 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   }
   if (J < d.K) {
     ScopedSlot t(c, SLOT_APPLY);
+    if constexpr (!STRICT && !KEEP) {
+      // only the solution is wanted: two dot products per knot row against the top-down vectors w
+      if (J >= 2 && !c->no_finish) {
+        const size_t lds = sizeof(double) * (size_t)(d.K - J) * (Sh::REC + 2 * 2 * NX);
+        hipLaunchKernelGGL((ndlqr::finish_small<NX, NU>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds, c->stream,
+                           d, J, c->F, c->z, c->rec);
+        return NDLQR_OK;
+      }
+    }
     const size_t lds = sizeof(double) * (size_t)(d.K - J) * Sh::REC;
     hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
                        c->stream, d, J, c->F, c->z, c->rec);
