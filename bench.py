@@ -251,6 +251,11 @@ def main():
         elif dom == "apply":
             covered = sum(level_b[JB:])
             dom_ms, dom_launches = used["apply"]
+        elif dom == "upper":
+            # separators + boundary Schur of levels JB..K-1 in one launch; model (B) charges those
+            # levels' P1-P3 bytes to it and the Schur/solution sweep to apply -- reported together
+            covered = sum(level_b[JB:])
+            dom_ms, dom_launches = used["upper"]
         else:
             dom_ms = sum(used[k][0] for k in ("separator", "schur") if k in used)
             dom_launches = used.get("schur", used.get("separator"))[1]

@@ -130,7 +130,8 @@ def lib():
         return _LIB
     if not os.path.exists(_build.LIB):
         _build.build()
-    L = C.CDLL(_build.LIB)
+    # NDLQR_LIBRARY: developer hook for instrumented builds of the same library (tools/segtime.py)
+    L = C.CDLL(os.environ.get("NDLQR_LIBRARY", _build.LIB))
     vp, ci, cd, cu64 = C.c_void_p, C.c_int, C.c_double, C.c_uint64
     sp = C.POINTER(NdLqrSolver)
     pp = C.POINTER(LQRProblem)

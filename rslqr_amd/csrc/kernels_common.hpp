@@ -50,4 +50,26 @@ __device__ __forceinline__ void outer_columns(int base, int l, int N, int& a, in
   bb = (base + span < N) ? __builtin_ctz(base + span) : -1;
 }
 
+// Developer instrumentation (tools/segtime.py; never defined in the shipped build): cycles spent
+// between consecutive marks, summed over lane 0 of every wavefront, per segment id.
+#ifdef NDLQR_SEGTIME
+__device__ unsigned long long ndlqr_seg[128];  // [k] cycle sums, [64 + k] sample counts
+// one problem in 32 is sampled so that the atomics do not perturb what they measure
+#define SEG_INIT() unsigned long long seg_last = __builtin_amdgcn_s_memtime()
+#define SEG(k)                                                                         \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long seg_now = __builtin_amdgcn_s_memtime();                   \
+    if (lane == 0 && (blockIdx.y & 31) == 0) {                                                  \
+      atomicAdd(&ndlqr_seg[k], seg_now - seg_last);                                    \
+      atomicAdd(&ndlqr_seg[64 + (k)], 1ull);                                           \
+    }                                                                                  \
+    seg_last = seg_now;                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define SEG_INIT() do {} while (0)
+#define SEG(k) do {} while (0)
+#endif
+
 }  // namespace ndlqr

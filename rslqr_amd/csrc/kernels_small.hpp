@@ -83,19 +83,19 @@ struct alignas(16) SepOut {
 
 // The core is run by ONE whole wavefront; its LDS traffic is only ordered within that wavefront
 // (wave_lds_sync), the caller provides the workgroup barriers around it.
-// abrow: row gi = lane % NX of [A_s | B_s] (global). Lrow: on return, row gi of the factor for
+// ab: row gi = lane % NX of [A_s | B_s], loaded by the caller (early, so that the latency of that
+// load is not on the separator's critical path). Lrow: on return, row gi of the factor for
 // lanes < NX (KEEPL: entries above the diagonal keep their S-bar values, like the reference's
 // in-place factorisation). Returns true when a pivot was not positive. The caller issues the
 // workgroup barrier that makes the solved panel visible to other wavefronts.
-template <int NX, int NU, bool STRICT, bool KEEPL>
-__device__ __forceinline__ bool separator_core(const int lane, const double* __restrict__ abrow,
+template <int NX, int NU, bool STRICT, bool KEEPL, int SEGB = 0>
+__device__ __forceinline__ bool separator_core(const int lane, const double (&ab)[NX + NU],
                                                const SepIn<NX, NU>& in, SepOut<NX>& out,
                                                double (&Lrow)[NX]) {
   constexpr int W = NX + NU, LD = SepOut<NX>::LD;
   static_assert(2 * NX + 1 <= LD && 2 * NX <= 64, "panel too narrow");
   const int grp = lane / NX, gi = lane - grp * NX;
-  double ab[W];  // every lane loads a (valid) row: no exec-masked branches around the loads
-  load_row<W>(abrow, ab);
+  SEG_INIT();
 
   // P1: row gi of S-bar (group 0) / of f_a (group 1)
   double acc[NX];
@@ -122,6 +122,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
     }
   }
 
+  SEG(SEGB + 1);
   // P2: left-looking Cholesky on the registers of group 0 (every lane runs it; rows of other
   // groups are don't-cares), row j broadcast with v_readlane; finished columns go to LDS.
   bool bad = false;
@@ -146,6 +147,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
 #pragma unroll
   for (int j = 0; j < NX; ++j) Lrow[j] = acc[j];
   wave_lds_sync();
+  SEG(SEGB + 2);
 
   // P3: one right-hand-side column per lane (lanes >= LD repeat a column: same values)
   const int col = lane & (LD - 1);
@@ -172,23 +174,30 @@ __device__ __forceinline__ bool separator_core(const int lane, const double* __r
     for (int k = 0; k < NX; ++k) out.X[k * LD + col] = x[k];
   }
   wave_lds_sync();
+  SEG(SEGB + 3);
   return bad;
 }
 
 // One wavefront per separator: stage the operands (whole rows, 16-byte loads), run the core,
-// store the record f_a | f_bb | z_sep and the lambda rows of knot s+1.
-//   grid (N >> (l+1), batch), block 64.
-template <int NX, int NU, bool STRICT, bool KEEP>
-__global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double* __restrict__ AB,
-                                                    double* F, double* z, double* __restrict__ rec,
-                                                    int* __restrict__ info) {
+// store the record f_a | f_bb | z_sep and the lambda rows of knot s+1. `in` / `out` belong to the
+// calling wavefront alone (all ordering is wave-local); on return the solved panel is in out.X.
+// LAMBDA_OUT: also write the lambda rows of knot s+1 (its f_a / f_bb rows and the Cholesky
+// factor) into F. A later full-level Schur pass or a factor download reads them; the
+// boundary-first schedule takes them from the record instead.
+template <int NX, int NU, bool STRICT, bool KEEP, bool LAMBDA_OUT>
+__device__ __forceinline__ void separator_wave(const Dims& d, const int l, const int sub, const int b,
+                                               const int lane, const double* __restrict__ AB, double* F,
+                                               double* z, double* __restrict__ rec, int* __restrict__ info,
+                                               SepIn<NX, NU>& in, SepOut<NX>& out) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, LD = SepOut<NX>::LD;
-  __shared__ SepIn<NX, NU> in;
-  __shared__ SepOut<NX> out;
-  const int N = d.N, b = blockIdx.y, lane = threadIdx.x;
-  const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
+  const int N = d.N;
+  const int half = 1 << l, base = sub * (2 << l), s = base + half - 1;
   int a, bb;
   outer_columns(base, l, N, a, bb);
+  SEG_INIT();
+  const int gi = lane % NX;
+  double ab[W];  // every lane loads a (valid) row: no exec-masked branches around the loads
+  load_row<W>(AB + (((size_t)b * N + s) * NX + gi) * W, ab);
   {
     const double* Es = Fblk(F, d, b, l, s) + NN;
     const double* Fas = Fblk(F, d, b, a >= 0 ? a : l, s) + NN;
@@ -211,13 +220,12 @@ __global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double*
     if (lane < W) in.zxu[lane] = zs[NX + lane];
     if (lane < 2 * NX) in.z1[lane] = zs[ROWS + lane];
   }
-  __syncthreads();
+  wave_lds_sync();
+  SEG(0);
   double Lrow[NX];
-  const int gi = lane % NX;
-  const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
-  const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, abrow, in, out, Lrow);
-  __syncthreads();
+  const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, ab, in, out, Lrow);
   if (bad && lane == 0) flag_failure(info, d, b);
+  SEG(6);  // re-arms the clock after the core's own marks
 
   // stores: rows of the solved panel
   double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
@@ -229,14 +237,25 @@ __global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double*
 #pragma unroll
       for (int c = 0; c < NX; ++c) row[c] = out.X[gi * LD + grp * NX + c];
       store_row<NX>(myrec + grp * NN + gi * NX, row);
-      store_row<NX>(Fblk(F, d, b, colidx, s + 1) + gi * NX, row);
+      if constexpr (LAMBDA_OUT) store_row<NX>(Fblk(F, d, b, colidx, s + 1) + gi * NX, row);
     }
   } else if (grp == 2) {
     const double v = out.X[gi * LD + 2 * NX];
     myrec[2 * NN + gi] = v;
     z[((size_t)b * N + s + 1) * ROWS + gi] = v;
   }
-  if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
+  if constexpr (LAMBDA_OUT) { if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow); }
+  SEG(4);
+}
+
+//   grid (N >> (l+1), batch), block 64.
+template <int NX, int NU, bool STRICT, bool KEEP>
+__global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double* __restrict__ AB,
+                                                    double* F, double* z, double* __restrict__ rec,
+                                                    int* __restrict__ info) {
+  __shared__ SepIn<NX, NU> in;
+  __shared__ SepOut<NX> out;
+  separator_wave<NX, NU, STRICT, KEEP, true>(d, l, blockIdx.x, blockIdx.y, threadIdx.x, AB, F, z, rec, info, in, out);
 }
 
 // ------------------------------------------------------------------------------------- row update helpers
@@ -299,6 +318,102 @@ struct SchurShape {
   static constexpr int REC = 2 * NX * NX + NX;  // doubles per record: f_a | f_bb | z_sep
 };
 
+// Rows of knot i (row r = this lane) through level l: the Schur update of ndlqr_UpdateShurFactor
+// restricted to the live columns, in two steps so that the loads can be issued long before the
+// separator's results exist: schur_rows_load (operands into registers) and schur_rows_apply
+// (arithmetic + stores). f(k, c) = fa[k * LDF + c], z_sep(k) = zsep[k * ZS].
+template <int NX>
+struct SchurRow {
+  double E[NX];  // this row of column l
+  double C[NX];  // this row of the knot's existing outer column (left half: a, right half: bb)
+  double zz;     // its rhs entry
+};
+
+template <int NX, int NU>
+__device__ __forceinline__ void schur_rows_load(const Dims& d, const int l, const int i, const int r, const int b,
+                                                const double* F, const double* z, SchurRow<NX>& row) {
+  constexpr int ROWS = 2 * NX + NU;
+  const int N = d.N, half = 1 << l;
+  const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+  int a, bb;
+  outer_columns(base, l, N, a, bb);
+  const bool left = i <= s;
+  const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+#pragma unroll
+  for (int c = 0; c < NX; ++c) { row.E[c] = 0.0; row.C[c] = 0.0; }
+  row.zz = 0.0;
+  if (r < NX && !calc_lambda) return;
+  load_row<NX>(Fblk(F, d, b, l, i) + r * NX, row.E);
+  const int cc = left ? a : bb;
+  if (cc >= 0) load_row<NX>(Fblk(F, d, b, cc, i) + r * NX, row.C);
+  row.zz = z[((size_t)b * N + i) * ROWS + r];
+}
+
+template <int NX, int NU, bool STRICT, int LDF, int ZS>
+__device__ __forceinline__ void schur_rows_apply(const Dims& d, const int l, const int i, const int r, const int b,
+                                                 double* F, double* z, const double* fa, const double* fb,
+                                                 const double* zsep, const SchurRow<NX>& row) {
+  constexpr int ROWS = 2 * NX + NU;
+  const int N = d.N, half = 1 << l;
+  const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+  int a, bb;
+  outer_columns(base, l, N, a, bb);
+  const bool left = i <= s;
+  const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+
+  if (r < NX && !calc_lambda) {
+    if (i != s + 1) {  // created blocks get explicit zero lambda rows (see schur_generic)
+      if (a >= 0 && !left) {
+        double* g = Fblk(F, d, b, a, i) + r * NX;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) g[c] = 0.0;
+      }
+      if (bb >= 0 && left) {
+        double* g = Fblk(F, d, b, bb, i) + r * NX;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) g[c] = 0.0;
+      }
+    }
+    return;
+  }
+
+  if (a >= 0) {
+    double acc[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) acc[c] = left ? row.C[c] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-row.E[k], fa[k * LDF + c], acc[c]);
+    store_row<NX>(Fblk(F, d, b, a, i) + r * NX, acc);
+  }
+  if (bb >= 0) {
+    double acc[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) acc[c] = left ? 0.0 : row.C[c];
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-row.E[k], fb[k * LDF + c], acc[c]);
+    store_row<NX>(Fblk(F, d, b, bb, i) + r * NX, acc);
+  }
+  {
+    double accz = row.zz;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) accz = mad<STRICT>(-row.E[k], zsep[k * ZS], accz);
+    z[((size_t)b * N + i) * ROWS + r] = accz;
+  }
+}
+
+template <int NX, int NU, bool STRICT, int LDF, int ZS>
+__device__ __forceinline__ void schur_rows(const Dims& d, const int l, const int i, const int r, const int b,
+                                           double* F, double* z, const double* fa, const double* fb,
+                                           const double* zsep) {
+  SchurRow<NX> row;
+  schur_rows_load<NX, NU>(d, l, i, r, b, F, z, row);
+  schur_rows_apply<NX, NU, STRICT, LDF, ZS>(d, l, i, r, b, F, z, fa, fb, zsep, row);
+}
+
 // BOUNDARY = false: every knot (grid.x = N / KPB workgroups of KPB consecutive knots).
 // BOUNDARY = true : only the first and the last knot of every level-l subtree, the two that
 //                   later separators read (one wavefront per subtree, KPW must be 2..; grid.x =
@@ -325,8 +440,6 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
     i = blockIdx.x * KPB + wave * KPW + kn;
   }
   const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
-  int a, bb;
-  outer_columns(base, l, N, a, bb);
   // All knots of a wavefront sit in the same level-l subtree (KPW consecutive, aligned knots),
   // so the separator record address is wave-uniform.
   //   full-level mode: scalar loads, SGPR operands in the FMAs (many wavefronts hide the latency);
@@ -350,64 +463,64 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
   const double* fa = rcd;
   const double* fb = rcd + NX * NX;
   const double* zsep = rcd + 2 * NX * NX;
-  const bool left = i <= s;
-  const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+  schur_rows<NX, NU, STRICT, NX, 1>(d, l, i, r, b, F, z, fa, fb, zsep);
+}
 
-  if (r < NX && !calc_lambda) {
-    if (i != s + 1) {  // created blocks get explicit zero lambda rows (see schur_generic)
-      if (a >= 0 && !left) {
-        double* g = Fblk(F, d, b, a, i) + r * NX;
-#pragma unroll
-        for (int c = 0; c < NX; ++c) g[c] = 0.0;
+// ------------------------------------------------------------------------------------- upper levels
+// Levels l0..K-1 of ONE problem in one launch: per level every wavefront takes subtrees in turn --
+// separator (separator_wave) and, below the top level, the Schur update of the subtree's first
+// and last knot straight from the solved panel in LDS -- and the workgroup barrier between levels
+// replaces the launch boundary (all hand-overs between levels go through global memory, which a
+// workgroup sees coherently across its barrier). Same arithmetic per element as separator_one +
+// schur_small<BOUNDARY> level by level; what it removes is 2 (K - l0) - 1 short, latency-bound
+// launches whose tails each drain the whole chip.
+//   grid (batch), block 64 * nw, dynamic LDS = nw * (sizeof(SepIn) + sizeof(SepOut)).
+template <int NX, int NU, bool STRICT, bool KEEP>
+__global__ __launch_bounds__(512) void upper_small(Dims d, int l0, const double* __restrict__ AB, double* F,
+                                                   double* z, double* __restrict__ rec,
+                                                   int* __restrict__ info) {
+  constexpr int ROWS = 2 * NX + NU, LD = SepOut<NX>::LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char upper_lds[];
+  const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  SepIn<NX, NU>& in = reinterpret_cast<SepIn<NX, NU>*>(upper_lds)[wave];
+  SepOut<NX>& out = reinterpret_cast<SepOut<NX>*>(upper_lds + (size_t)nw * sizeof(SepIn<NX, NU>))[wave];
+  const int b = blockIdx.x, K = d.K;
+  const int kn = lane / ROWS, r = lane - kn * ROWS;
+  for (int l = l0; l < K; ++l) {
+    const int nsub = d.N >> (l + 1), T = 2 << l;
+    for (int sub = wave; sub < nsub; sub += nw) {
+      separator_wave<NX, NU, STRICT, KEEP, KEEP>(d, l, sub, b, lane, AB, F, z, rec, info, in, out);
+      if (l < K - 1 && kn < 2) {
+        const int i = sub * T + (kn == 0 ? 0 : T - 1);
+        schur_rows<NX, NU, STRICT, LD, LD>(d, l, i, r, b, F, z, out.X, out.X + NX, out.X + 2 * NX);
       }
-      if (bb >= 0 && left) {
-        double* g = Fblk(F, d, b, bb, i) + r * NX;
-#pragma unroll
-        for (int c = 0; c < NX; ++c) g[c] = 0.0;
-      }
+      wave_lds_sync();  // the panel is rewritten by this wavefront's next subtree
     }
-    return;
+    __syncthreads();
   }
+}
 
-  double E[NX];
-  load_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
-  if (a >= 0) {
-    double* g = Fblk(F, d, b, a, i) + r * NX;
-    double acc[NX];
-    if (left) {
-      load_row<NX>(g, acc);
-    } else {
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc[c] = 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < NX; ++k)
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fa[k * NX + c], acc[c]);
-    store_row<NX>(g, acc);
+// One level, one wavefront per subtree: separator + boundary Schur update in the same launch
+// (the loop body of upper_small with chip-wide parallelism).  grid (N >> (l+1), batch), block 64.
+template <int NX, int NU, bool STRICT, bool KEEP>
+__global__ __launch_bounds__(64) void level_small(Dims d, int l, const double* __restrict__ AB, double* F,
+                                                  double* z, double* __restrict__ rec, int* __restrict__ info) {
+  constexpr int ROWS = 2 * NX + NU, LD = SepOut<NX>::LD;
+  __shared__ SepIn<NX, NU> in;
+  __shared__ SepOut<NX> out;
+  const int lane = threadIdx.x, sub = blockIdx.x, b = blockIdx.y;
+  separator_wave<NX, NU, STRICT, KEEP, KEEP>(d, l, sub, b, lane, AB, F, z, rec, info, in, out);
+  SEG_INIT();
+  const int kn = lane / ROWS, r = lane - kn * ROWS;
+  if (l < d.K - 1 && kn < 2) {
+    const int T = 2 << l;
+    const int i = sub * T + (kn == 0 ? 0 : T - 1);
+    schur_rows<NX, NU, STRICT, LD, LD>(d, l, i, r, b, F, z, out.X, out.X + NX, out.X + 2 * NX);
   }
-  if (bb >= 0) {
-    double* g = Fblk(F, d, b, bb, i) + r * NX;
-    double acc[NX];
-    if (!left) {
-      load_row<NX>(g, acc);
-    } else {
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc[c] = 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < NX; ++k)
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc[c] = mad<STRICT>(-E[k], fb[k * NX + c], acc[c]);
-    store_row<NX>(g, acc);
-  }
-  {
-    double* g = z + ((size_t)b * N + i) * ROWS + r;
-    double accz = *g;
-#pragma unroll
-    for (int k = 0; k < NX; ++k) accz = mad<STRICT>(-E[k], zsep[k], accz);
-    *g = accz;
-  }
+#ifdef NDLQR_SEGTIME
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SEG(5);
 }
 
 // ------------------------------------------------------------------------------------- apply
@@ -641,8 +754,11 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
   constexpr int W = NX + NU, ROWS = 2 * NX + NU;
   constexpr int NK = 1 << JB, NWAVE = NK / 2;
   static_assert(2 * ROWS <= 64 && 3 * NX <= 64, "two knots per wavefront, three lane groups of NX");
+  // row pitch of the staged [A | B]: even W padded by two doubles so that the 12-16 row reads of
+  // the separator (one row per lane, 16-byte LDS reads) fall into distinct banks
+  constexpr int WP = (W % 2 == 0) ? W + 2 : W;
   struct alignas(16) Priv {   // per wavefront
-    double ab[2][NX * W];     // [A | B] of the wavefront's two knots (leaf phase)
+    double ab[2][NX * WP];    // [A | B] of the wavefront's two knots (leaf phase, separators)
   };
   __shared__ SepIn<NX, NU> xs[NK / 2];   // per subtree of the current level: separator operands
   __shared__ SepOut<NX> so[NK / 2];      // per subtree: solved right-hand sides
@@ -658,28 +774,43 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
   const bool lam = r < NX;
   Priv& me = pv[wave];
 
-  // ---- stage [A | B] of my two knots (contiguous in memory)
+  SEG_INIT();
+  // ---- stage [A | B] of my two knots (contiguous in memory); the leaf's own operands are
+  //      requested in the same round trip
+  const double* qr = QR + ((size_t)b * N + i) * W;
+  const double* r0 = rhs + ((size_t)b * N + i) * ROWS;
+  const double qv_in = qr[lam ? r : r - NX];
+  const double rv = r0[r];
   {
-    // two knots = 2 * NX * W doubles; the pair starts at an even multiple of NX * W: 16-byte aligned
-    const double2* src = reinterpret_cast<const double2*>(AB + ((size_t)b * N + wgbase + 2 * wave) * NX * W);
-    double2* dst = reinterpret_cast<double2*>(&me.ab[0][0]);
-    for (int e = lane; e < NX * W; e += 64) dst[e] = src[e];
+    const double* src = AB + ((size_t)b * N + wgbase + 2 * wave) * NX * W;
+    if constexpr (W % 2 == 0) {
+      // two knots = 2 NX rows of W doubles; the pair starts 16-byte aligned
+      for (int e = lane; e < NX * W; e += 64) {
+        const int row = e / (W / 2), c2 = e - row * (W / 2);
+        const int knot = row / NX, rr = row - knot * NX;
+        reinterpret_cast<double2*>(&me.ab[knot][rr * WP])[c2] = reinterpret_cast<const double2*>(src)[e];
+      }
+    } else {
+      for (int e = lane; e < 2 * NX * W; e += 64) {
+        const int knot = e / (NX * W);
+        me.ab[knot][e - knot * NX * W] = src[e];
+      }
+    }
   }
   __syncthreads();
+  SEG(20);
 
   // ---- leaf phase in registers (ndlqr_SolveLeaf): own block O, block P towards the previous knot
   double E[NX], Ca[NX], Cb[NX], zz;
   {
     const double* abk = me.ab[has_knot ? kn : 1];
-    const double* qr = QR + ((size_t)b * N + i) * W;
-    const double* r0 = rhs + ((size_t)b * N + i) * ROWS;
     const bool last = (i == N - 1);
     // Row scaling by the diagonal Q (state rows) / R (input rows). STRICT reproduces the
     // reference's two divisions by L = q / sqrt(q) of its dense Cholesky solve; the fast mode
     // multiplies by one reciprocal (L * L == q up to rounding).
     double sc = 1.0, rq = 1.0;
     if (!lam) {
-      const double qv = qr[r - NX];
+      const double qv = qv_in;
       if constexpr (STRICT) sc = qv / sqrt(qv); else rq = 1.0 / qv;
       if (has_knot && !(qv > 0.0) && !(last && r >= 2 * NX)) flag_failure(info, d, b);
     }
@@ -690,9 +821,9 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
       double o;
-      if (lam) o = (i == 0) ? -abk[c * W + r] : 0.0;
+      if (lam) o = (i == 0) ? -abk[c * WP + r] : 0.0;
       else if (i == 0 && r < 2 * NX) o = 0.0;
-      else o = scale(abk[c * W + (r - NX)]);
+      else o = scale(abk[c * WP + (r - NX)]);
       O[c] = last ? 0.0 : o;
       P[c] = (!lam && r < 2 * NX && c == r - NX) ? scale(-1.0) : 0.0;
     }
@@ -703,9 +834,8 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       Ca[c] = (even && i > 0) ? P[c] : 0.0;
       Cb[c] = even ? 0.0 : O[c];
     }
-    const double rv = r0[r];
     if (i == 0) {
-      if (lam) zz = mad<STRICT>(-qr[r], rv, -r0[NX + r]);
+      if (lam) zz = mad<STRICT>(-qv_in, rv, -r0[NX + r]);
       else if (r < 2 * NX) zz = -r0[r - NX];
       else zz = scale(rv);
     } else {
@@ -715,6 +845,7 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     }
   }
 
+  SEG(21);
   // ---- levels 0 .. JB-1
 #pragma unroll
   for (int l = 0; l < JB; ++l) {
@@ -748,18 +879,33 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       }
     }
     __syncthreads();
+    SEG(22);
 
     // separator of the subtree: computed once, by the wavefront that holds knot s+1; the other
     // wavefronts of the subtree wait at the barrier (their issue slots go to other workgroups)
     if (owner) {
-      double Lrow[NX];
+      double Lrow[NX], ab[W];
       const int gi = lane % NX;
-      const double* abrow = AB + (((size_t)b * N + s) * NX + gi) * W;
-      const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, abrow, xc, sout, Lrow);
+      {  // row gi of [A_s | B_s] from the staged copy of the wavefront that holds knot s
+        const double* abs_ = pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1] + gi * WP;
+        if constexpr (WP % 2 == 0) {
+#pragma unroll
+          for (int k = 0; k < W / 2; ++k) {
+            const double2 t = reinterpret_cast<const double2*>(abs_)[k];
+            ab[2 * k] = t.x; ab[2 * k + 1] = t.y;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < W; ++k) ab[k] = abs_[k];
+        }
+      }
+      const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow);
       if (bad && lane == 0) flag_failure(info, d, b);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
     }
+    SEG(23);
     __syncthreads();
+    SEG(24);
 
     // Schur update of my two knots, then rotate the column roles
     const double* fa = sout.X;           // f_a(k, c)  = X[k * LD + c]
@@ -776,7 +922,9 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       zz = zsp[r * LD];
     }
     rotate_roles<NX>(E, Ca, Cb, (base & T) == 0);
+    SEG(25);
     __syncthreads();  // xs / pv are reused by the next level
+    SEG(26);
   }
 
   // ---- hand-off: column JB, the live outer column at level JB, the rhs block
@@ -798,6 +946,10 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     else        { if (bb >= 0) store_row<NX>(Fblk(F, d, b, bb, i) + r * NX, Cb); }
     z[((size_t)b * N + i) * ROWS + r] = zz;
   }
+#ifdef NDLQR_SEGTIME
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SEG(27);
 }
 
 }  // namespace ndlqr

@@ -47,8 +47,8 @@ int ndlqr_hip_device_count(void) {
 
 // ------------------------------------------------------------------------------ context
 
-enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_BOUNDARY, SLOT_APPLY, SLOT_BOTTOM, SLOT_COUNT };
-static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom"};
+enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_BOUNDARY, SLOT_APPLY, SLOT_BOTTOM, SLOT_UPPER, SLOT_COUNT };
+static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom", "upper"};
 
 struct PendingEvent {
   int slot;
@@ -69,6 +69,9 @@ struct NdlqrHipCtx {
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
+  const void* big_lds_kernel;  // last kernel whose dynamic-LDS limit was raised on this device
+  int upper_mode;     // NDLQR_UPPER=0: separator_one + schur_small<BOUNDARY> per level; 1 (default): one
+                      // launch per level (level_small); 2: all upper levels in one launch (upper_small)
   bool no_finish;     // NDLQR_NO_FINISH=1: fast mode keeps apply_small instead of finish_small (A/B timing)
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
@@ -125,6 +128,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->fuse_level = -1;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->no_finish = getenv("NDLQR_NO_FINISH") != nullptr;
+  c->upper_mode = getenv("NDLQR_UPPER") ? atoi(getenv("NDLQR_UPPER")) : 1;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_J = c->graph_JB = -2; c->graph_stream = nullptr;
@@ -331,6 +335,28 @@ static int launch_small(NdlqrHipCtx* c, int J) {
                          c->AB, c->QR, c->rhs, c->F, c->z, c->info);
     }
   }
+  if (JB >= J && JB >= 1 && JB < d.K && c->upper_mode == 1) {
+    // no full-level Schur pass left: separator + boundary update of a level in one launch
+    for (int l = JB; l < d.K; ++l) {
+      ScopedSlot t(c, SLOT_UPPER);
+      hipLaunchKernelGGL((ndlqr::level_small<NX, NU, STRICT, KEEP>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0,
+                         c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
+    }
+  } else if (JB >= J && JB >= 1 && JB < d.K && c->upper_mode == 2) {
+    // no full-level Schur pass left: all remaining levels of a problem in one launch
+    ScopedSlot t(c, SLOT_UPPER);
+    auto kern = ndlqr::upper_small<NX, NU, STRICT, KEEP>;
+    int nw = 8;
+    while (nw > 1 && nw / 2 >= (d.N >> (JB + 1))) nw /= 2;  // not more wavefronts than subtrees
+    const size_t lds = (size_t)nw * (sizeof(ndlqr::SepIn<NX, NU>) + sizeof(ndlqr::SepOut<NX>));
+    if (lds > 64 * 1024 && c->big_lds_kernel != reinterpret_cast<const void*>(kern)) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      c->big_lds_kernel = reinterpret_cast<const void*>(kern);
+    }
+    hipLaunchKernelGGL(kern, dim3(d.batch), dim3(64 * nw), lds, c->stream, d, JB, c->AB, c->F, c->z, c->rec,
+                       c->info);
+  } else
   for (int l = JB; l < d.K; ++l) {
     {
       ScopedSlot t(c, SLOT_SEP);
@@ -666,3 +692,17 @@ int ndlqr_hip_potrs_lower(int n, int nrhs, const double* L, int ldl, double* B, 
   HIP_TRY(hipMemcpy(B, dB.p, bB, hipMemcpyDeviceToHost));
   return NDLQR_OK;
 }
+
+#ifdef NDLQR_SEGTIME
+// developer instrumentation only (tools/segtime.py): read / clear the per-segment cycle sums
+extern "C" int ndlqr_hip_debug_segments(unsigned long long* out, int n, int reset) {
+  unsigned long long host[128];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ndlqr::ndlqr_seg), sizeof(host)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 128; ++i) out[i] = host[i];
+  if (reset) {
+    for (int i = 0; i < 128; ++i) host[i] = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ndlqr::ndlqr_seg), host, sizeof(host)) != hipSuccess) return -1;
+  }
+  return 128;
+}
+#endif
