@@ -76,7 +76,10 @@ struct alignas(16) SepIn {      // what a separator reads from its two neighbour
 };
 template <int NX>
 struct alignas(16) SepOut {
-  static constexpr int LD = 32;  // panel row length: [f_a (NX) | f_bb (NX) | z_sep | pad]
+  static constexpr int NC = 32;  // panel columns: [f_a (NX) | f_bb (NX) | z_sep | unused]
+  // row pitch: two doubles of padding put the rows that the NX lanes of a group write (P1) and
+  // read (record stores) side by side into distinct LDS banks (32 doubles = all in one bank)
+  static constexpr int LD = NC + 2;
   double X[NX * LD];             // right-hand sides in, solutions out; row k, column c
   double rdiag[NX];              // fast mode: 1 / L(j,j)
 };
@@ -93,7 +96,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
                                                const SepIn<NX, NU>& in, SepOut<NX>& out,
                                                double (&Lrow)[NX]) {
   constexpr int W = NX + NU, LD = SepOut<NX>::LD;
-  static_assert(2 * NX + 1 <= LD && 2 * NX <= 64, "panel too narrow");
+  static_assert(2 * NX + 1 <= SepOut<NX>::NC && 2 * NX <= 64, "panel too narrow");
   const int grp = lane / NX, gi = lane - grp * NX;
   SEG_INIT();
 
@@ -150,7 +153,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
   SEG(SEGB + 2);
 
   // P3: one right-hand-side column per lane (lanes >= LD repeat a column: same values)
-  const int col = lane & (LD - 1);
+  const int col = lane & (SepOut<NX>::NC - 1);
   double x[NX];
 #pragma unroll
   for (int k = 0; k < NX; ++k) x[k] = out.X[k * LD + col];
@@ -169,7 +172,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
     __builtin_amdgcn_sched_barrier(0);
   }
   wave_lds_sync();
-  if (lane < LD) {
+  if (lane < SepOut<NX>::NC) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) out.X[k * LD + col] = x[k];
   }

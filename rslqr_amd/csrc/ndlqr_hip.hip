@@ -125,7 +125,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
-  c->fuse_level = -1;
+  c->fuse_level = getenv("NDLQR_FUSE_LEVEL") ? atoi(getenv("NDLQR_FUSE_LEVEL")) : -1;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->no_finish = getenv("NDLQR_NO_FINISH") != nullptr;
   c->upper_mode = getenv("NDLQR_UPPER") ? atoi(getenv("NDLQR_UPPER")) : 1;
