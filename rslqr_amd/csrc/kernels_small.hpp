@@ -737,6 +737,107 @@ __global__ __launch_bounds__(256) void finish_small(Dims d, int J, const double*
   }
 }
 
+// ------------------------------------------------------------------------------------- back-substitution
+// Fast mode without KEEP: the solution straight from the separator records and the problem data
+// (the classic nested-dissection back-substitution; replaces hand-off + finish_small).
+//   multipliers, top-down over the tree:  y_s = z_sep(s) - f_a(s) y_A - f_bb(s) y_B,
+//       A / B = the separators left / right of s's subtree (columns a / bb), absent at the ends;
+//   lambda_k = y_{k-1}; knot 0: lambda = Q x0 + q + A_0' y_0;
+//   x_k = Q^-1 (-q_k - A_k' y_k + y_{k-1}),  u_k = R^-1 (-r_k - B_k' y_k)     (stationarity rows)
+// -- the same quantities the level-by-level sweep produces, up to rounding. A workgroup owns 8
+// consecutive knots: the 7 separators inside them and the K - 3 on their path to the root; every
+// (separator, row) pair is fetched by one thread up front, then the levels resolve through LDS.
+//   grid (N / 8, batch), block 256; requires N >= 8 and (K + 4) * NX <= 256.
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void backsub_small(Dims d, const double* __restrict__ AB,
+                                                     const double* __restrict__ QR,
+                                                     const double* __restrict__ rhs,
+                                                     const double* __restrict__ recs, double* __restrict__ z) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, MAXSLOT = 256 / NX;
+  __shared__ double ys[MAXSLOT][NX];
+  const int N = d.N, K = d.K, b = blockIdx.y, first = blockIdx.x * KPB;
+  const int npath = K - 3, nslot = npath + 7;
+  // slot -> separator: slots 0..npath-1 the path (level K-1 first), then the 7 local ones
+  auto slot_sep = [&](int q, int& s, int& l) {
+    if (q < npath) { l = K - 1 - q; s = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1; }
+    else { s = first + (q - npath); l = trailing_ones(s); }
+  };
+  auto sep_slot = [&](int s) -> int {  // only called for separators of this workgroup's scope
+    return (s >= first && s < first + 7) ? npath + (s - first) : K - 1 - trailing_ones(s);
+  };
+
+  // ---- every thread's operands, requested before anything waits
+  const int t = threadIdx.x;
+  const int q = t / NX, r = t - q * NX;
+  int s = 0, l = 0, slotA = -1, slotB = -1;
+  double fa[NX], fb[NX], zs = 0.0;
+  const bool sep_thread = q < nslot;
+  if (sep_thread) {
+    slot_sep(q, s, l);
+    const int base = s - ((1 << l) - 1);
+    const bool hasA = base > 0, hasB = base + (2 << l) < N;
+    const double* rc = recs + ((size_t)b * N + s) * REC;
+    zs = rc[2 * NN + r];
+    if (hasA) { load_row<NX>(rc + r * NX, fa); slotA = sep_slot(base - 1); }
+    if (hasB) { load_row<NX>(rc + NN + r * NX, fb); slotB = sep_slot(base + (2 << l) - 1); }
+  }
+  const int kn = t / ROWS, rr = t - kn * ROWS;  // output role: knot kn of the workgroup, row rr
+  const bool out_thread = kn < KPB;
+  const int i = first + (out_thread ? kn : 0);
+  const bool lam = rr < NX;
+  const int col = lam ? rr : rr - NX;  // column of [A_i | B_i] this row dots with y_i
+  const bool needs_ab = out_thread && i < N - 1 && (lam ? i == 0 : !(i == 0 && rr < 2 * NX));
+  double abcol[NX], rv = 0.0, rv2 = 0.0, qv = 1.0;
+  if (out_thread) {
+    const double* r0 = rhs + ((size_t)b * N + i) * ROWS;
+    const double* qr = QR + ((size_t)b * N + i) * W;
+    rv = r0[rr];
+    if (i == 0 && lam) { rv2 = r0[NX + rr]; qv = qr[rr]; }
+    else if (!lam) qv = qr[rr - NX];
+    if (needs_ab) {
+      const double* abk = AB + ((size_t)b * N + i) * NX * W + col;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) abcol[c] = abk[c * W];
+    }
+  }
+
+  // ---- multipliers, one tree level per step
+  for (int L = K - 1; L >= 0; --L) {
+    if (sep_thread && l == L) {
+      double acc = zs;
+      if (slotA >= 0) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc = fma(-fa[c], ys[slotA][c], acc);
+      }
+      if (slotB >= 0) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc = fma(-fb[c], ys[slotB][c], acc);
+      }
+      ys[q][r] = acc;
+    }
+    __syncthreads();
+  }
+
+  // ---- solution rows
+  if (!out_thread) return;
+  double out;
+  const double* yi = ys[sep_slot(i < N - 1 ? i : i - 1)];        // y_i   (unused for the last knot)
+  const double* yp = ys[sep_slot(i > 0 ? i - 1 : 0)];            // y_{i-1} (unused for knot 0)
+  double dot = 0.0;
+  if (needs_ab) {
+#pragma unroll
+    for (int c = 0; c < NX; ++c) dot = fma(abcol[c], yi[c], dot);
+  }
+  if (lam) {
+    out = (i == 0) ? fma(-qv, rv, -rv2) + dot : yp[rr];
+  } else if (rr < 2 * NX) {
+    out = (i == 0) ? -rhs[((size_t)b * N) * ROWS + (rr - NX)] : (rv - dot + yp[rr - NX]) / qv;
+  } else {
+    out = (i == N - 1) ? rv : (rv - dot) / qv;
+  }
+  z[((size_t)b * N + i) * ROWS + rr] = out;
+}
+
 // ------------------------------------------------------------------------------------- bottom
 // Leaf phase + tree levels 0..JB-1 in ONE launch, everything on chip: a workgroup owns 2^JB
 // consecutive knots, each wavefront two of them (lane = (knot, row)) with its rows of E, of the
@@ -753,7 +854,11 @@ template <int NX, int NU, bool STRICT, bool KEEP, int JB>
 __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double* __restrict__ AB,
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
-                                                         double* z, int* __restrict__ info) {
+                                                         double* z, int* __restrict__ info,
+                                                         double* __restrict__ rec, const int lean) {
+  // lean (fast mode without KEEP only): the solution comes from backsub_small, which needs the
+  // records of the on-chip separators but nothing of the interior knots -- write those records
+  // and hand off only the first and the last knot of the workgroup (what the upper levels read)
   constexpr int W = NX + NU, ROWS = 2 * NX + NU;
   constexpr int NK = 1 << JB, NWAVE = NK / 2;
   static_assert(2 * ROWS <= 64 && 3 * NX <= 64, "two knots per wavefront, three lane groups of NX");
@@ -905,6 +1010,22 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow);
       if (bad && lane == 0) flag_failure(info, d, b);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
+      if constexpr (!STRICT && !KEEP) {
+        if (lean) {  // record f_a | f_bb | z_sep of this separator (layout of separator_wave)
+          double* myrec = rec + ((size_t)b * N + s) * (2 * NX * NX + NX);
+          const int grp = lane / NX;
+          if (grp < 2) {
+            if ((grp == 0 ? a : bb) >= 0) {
+              double row[NX];
+#pragma unroll
+              for (int c = 0; c < NX; ++c) row[c] = sout.X[gi * LD + grp * NX + c];
+              store_row<NX>(myrec + grp * NX * NX + gi * NX, row);
+            }
+          } else if (grp == 2) {
+            myrec[2 * NX * NX + gi] = sout.X[gi * LD + 2 * NX];
+          }
+        }
+      }
     }
     SEG(23);
     __syncthreads();
@@ -931,7 +1052,9 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
   }
 
   // ---- hand-off: column JB, the live outer column at level JB, the rhs block
-  if (has_knot) {
+  bool handoff = has_knot;
+  if constexpr (!STRICT && !KEEP) { if (lean) handoff = has_knot && (i == wgbase || i == wgbase + NK - 1); }
+  if (handoff) {
     const int l = JB;
     const int base = (i >> (l + 1)) << (l + 1), s = base + (1 << l) - 1;
     int a, bb;

@@ -72,6 +72,7 @@ struct NdlqrHipCtx {
   const void* big_lds_kernel;  // last kernel whose dynamic-LDS limit was raised on this device
   int upper_mode;     // NDLQR_UPPER=0: separator_one + schur_small<BOUNDARY> per level; 1 (default): one
                       // launch per level (level_small); 2: all upper levels in one launch (upper_small)
+  bool no_backsub;    // NDLQR_NO_BACKSUB=1: fast mode keeps hand-off + finish_small (A/B timing)
   bool no_finish;     // NDLQR_NO_FINISH=1: fast mode keeps apply_small instead of finish_small (A/B timing)
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
@@ -128,6 +129,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->fuse_level = getenv("NDLQR_FUSE_LEVEL") ? atoi(getenv("NDLQR_FUSE_LEVEL")) : -1;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->no_finish = getenv("NDLQR_NO_FINISH") != nullptr;
+  c->no_backsub = getenv("NDLQR_NO_BACKSUB") != nullptr;
   c->upper_mode = getenv("NDLQR_UPPER") ? atoi(getenv("NDLQR_UPPER")) : 1;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
@@ -309,11 +311,11 @@ static int launch_generic(NdlqrHipCtx* c) {
 // (tiny grids), then ONE apply_small pass that takes every knot through all those levels in
 // registers. J = K disables the second form (pure level-by-level streaming).
 template <int NX, int NU, bool STRICT, bool KEEP, int JB>
-static void launch_bottom(NdlqrHipCtx* c) {
+static void launch_bottom(NdlqrHipCtx* c, bool lean) {
   const ndlqr::Dims& d = c->d;
   ScopedSlot t(c, SLOT_BOTTOM);
   hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), 0,
-                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0);
 }
 
 template <int NX, int NU, bool STRICT, bool KEEP>
@@ -325,10 +327,14 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   if (JB > 3) JB = 3;
   while (JB > 0 && d.K <= JB) --JB;
   if (JB > J) JB = J;
+  // fast mode without KEEP: solution by back-substitution from the separator records (needs the
+  // boundary-first schedule right after the bottom kernel, so that no level reads interior knots)
+  const bool lean = !STRICT && !KEEP && JB >= J && JB >= 1 && JB < d.K && c->upper_mode != 0 &&
+                    (d.K + 4) * NX <= 256 && !c->no_backsub;
   switch (JB) {
-    case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c); break;
-    case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c); break;
-    case 1: launch_bottom<NX, NU, STRICT, KEEP, 1>(c); break;
+    case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c, lean); break;
+    case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c, lean); break;
+    case 1: launch_bottom<NX, NU, STRICT, KEEP, 1>(c, lean); break;
     default: {
       ScopedSlot t(c, SLOT_LEAF);
       hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
@@ -375,6 +381,13 @@ static int launch_small(NdlqrHipCtx* c, int J) {
                          dim3((nsub + Sh::WAVES - 1) / Sh::WAVES, d.batch), dim3(256), 0, c->stream, d, l,
                          c->F, c->z, c->rec);
     }
+  }
+  if (lean) {
+    ScopedSlot t(c, SLOT_APPLY);
+    if constexpr (!STRICT && !KEEP)
+      hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+                         c->QR, c->rhs, c->rec, c->z);
+    return NDLQR_OK;
   }
   if (J < d.K) {
     ScopedSlot t(c, SLOT_APPLY);
