@@ -192,13 +192,40 @@ def test_env_variants_agree(ndlqr, oracle):
         "assert bs.solve() == 0; print(json.dumps(bs.solutions().tolist()))\n"
         % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     outs = []
-    for env in ({}, {"NDLQR_BOTTOM_LEVELS": "0"}, {"NDLQR_BOTTOM_LEVELS": "1"}, {"NDLQR_BOTTOM_LEVELS": "3"}):
+    for env in ({}, {"NDLQR_BOTTOM_LEVELS": "0"}, {"NDLQR_BOTTOM_LEVELS": "1"}, {"NDLQR_BOTTOM_LEVELS": "3"},
+                {"NDLQR_UPPER": "0"}, {"NDLQR_UPPER": "2"}, {"NDLQR_UPPER": "2", "NDLQR_BOTTOM_LEVELS": "1"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+def test_env_variants_fast_mode(ndlqr, oracle):
+    """Fast mode has three solution sweeps (back-substitution from the records, finish kernel on the
+    hand-off columns, apply pass) and three schedules of the upper levels: each stays within the
+    fast-mode tolerance of the oracle (relative l2 <= 1e-9, here ~1e-15)."""
+    import subprocess, sys, json
+    n, m, N, batch, seed = 12, 4, 128, 3, 91
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import rslqr_amd as R\n"
+        "bs = R.BatchSolver(%d, %d, %d, %d); bs.initialize_synthetic(%d)\n"
+        "assert bs.solve() == 0; print(json.dumps(bs.solutions().tolist()))\n"
+        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+           n, m, N, batch, seed))
+    probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
+    ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
+    for env in ({}, {"NDLQR_NO_BACKSUB": "1"}, {"NDLQR_NO_BACKSUB": "1", "NDLQR_NO_FINISH": "1"},
+                {"NDLQR_UPPER": "0"}, {"NDLQR_UPPER": "2"}, {"NDLQR_BOTTOM_LEVELS": "1"},
+                {"NDLQR_BOTTOM_LEVELS": "3", "NDLQR_FUSE_LEVEL": "3"}, {"NDLQR_BOTTOM_LEVELS": "0"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        got = np.array(json.loads(r.stdout.strip().splitlines()[-1]))
+        err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert err <= REL_TOL, (env, err)
 
 
 @pytest.mark.parametrize("n,m,N", [(12, 4, 64), (6, 3, 32), (5, 2, 16), (32, 16, 16)])
