@@ -838,6 +838,256 @@ __global__ __launch_bounds__(256) void backsub_small(Dims d, const double* __res
   z[((size_t)b * N + i) * ROWS + rr] = out;
 }
 
+// ------------------------------------------------------------------------------------- rhs-only re-solve
+// New right-hand side against a cached factorisation (fast mode, NDLQR_FLAG_KEEP_FACT): the
+// forward half of the nested-dissection solve on the separators alone, then backsub_small.
+//   b~_s   = leaf_s - sum_{l' < l} [ f_bb(s - 2^l')' b~_{s - 2^l'} + f_a(s + 2^l')' b~_{s + 2^l'} ]
+//   z_sep(s) = (L_s L_s')^-1 b~_s
+// leaf_s = A_s z.x + B_s z.u - z(s+1).x - z(s+1).lambda on the leaf-phase rhs (what the inner
+// product of level 0 forms); s -/+ 2^l' are the separators of the two child chains whose subtrees
+// end / start at s -- by symmetry of the reduced system their coupling to s is the transpose
+// of their own f_bb / f_a. Reads per separator: its record and factor, nothing of the knots'
+// factor columns (the level-by-level sweep streams all N K of them).
+template <int NX, int NU>
+__device__ __forceinline__ double leaf_rhs_entry(const Dims& d, const int b, const int i, const int rr,
+                                                 const double* __restrict__ QR, const double* __restrict__ rhs) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU;
+  const double* r0 = rhs + ((size_t)b * d.N + i) * ROWS;
+  const double* qr = QR + ((size_t)b * d.N + i) * W;
+  const bool lam = rr < NX, last = (i == d.N - 1);
+  if (i == 0) {
+    if (lam) return fma(-qr[rr], r0[rr], -r0[NX + rr]);
+    if (rr < 2 * NX) return -r0[rr - NX];
+    return r0[rr] / qr[rr - NX];
+  }
+  if (lam) return r0[rr];
+  if (rr < 2 * NX || !last) return r0[rr] / qr[rr - NX];
+  return r0[rr];
+}
+
+// (L L')^-1 applied to one vector by one wavefront: lane r < NX holds entry r of the vector, row
+// r of L (Lrow[j] = L(r, j), j <= r) and column r of L (Lcol[j] = L(j, r), j >= r).
+template <int NX>
+__device__ __forceinline__ double chol_solve_wave(double v, const double (&Lrow)[NX], const double (&Lcol)[NX],
+                                                  const int lane) {
+  double dinv = 1.0;  // lane j: 1 / L(j, j)
+#pragma unroll
+  for (int j = 0; j < NX; ++j) dinv = (lane == j) ? 1.0 / Lrow[j] : dinv;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
+    v = (lane == j) ? xj : ((lane > j) ? fma(-Lrow[j], xj, v) : v);
+  }
+#pragma unroll
+  for (int j = NX - 1; j >= 0; --j) {
+    const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
+    v = (lane == j) ? xj : ((lane < j) ? fma(-Lcol[j], xj, v) : v);
+  }
+  return v;
+}
+
+// Operands of one separator's forward step, fetched by its wavefront in one round trip:
+// row / column rc of the factor and, per child-chain level, column rc of f_bb(s - 2^lp) and of
+// f_a(s + 2^lp) (the transposed products read columns).
+template <int NX, int NLP>
+struct ForwardOps {
+  double Lrow[NX], Lcol[NX];
+  double fl[NLP > 0 ? NLP : 1][NX], fr[NLP > 0 ? NLP : 1][NX];
+};
+
+template <int NX, int NU, int NLP>
+__device__ __forceinline__ void forward_fetch(const Dims& d, const int b, const int s, const int l, const int lp0,
+                                              const int rc, const double* F, const double* recs,
+                                              ForwardOps<NX, NLP>& op) {
+  constexpr int NN = NX * NX, REC = 2 * NN + NX;
+  const double* Lb = Fblk(F, d, b, l, s + 1);  // lambda rows of knot s+1, column l: the factor
+  load_row<NX>(Lb + rc * NX, op.Lrow);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) op.Lcol[j] = Lb[j * NX + rc];
+#pragma unroll
+  for (int q = 0; q < NLP; ++q) {
+    const int lp = lp0 + q;
+    if (lp < l) {
+      const double* fbb = recs + ((size_t)b * d.N + (s - (1 << lp))) * REC + NN;
+      const double* fa = recs + ((size_t)b * d.N + (s + (1 << lp))) * REC;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) { op.fl[q][c] = fbb[c * NX + rc]; op.fr[q][c] = fa[c * NX + rc]; }
+    }
+  }
+}
+
+// b~ = acc - child-chain terms (bt_of(s') = b~ of separator s'), z_sep = (L L')^-1 b~ -> record
+template <int NX, int NU, int NLP, class BtOf>
+__device__ __forceinline__ double forward_finish(const Dims& d, const int b, const int s, const int l,
+                                                 const int lp0, double acc, const int lane, double* recs,
+                                                 const ForwardOps<NX, NLP>& op, BtOf bt_of) {
+  constexpr int NN = NX * NX, REC = 2 * NN + NX;
+#pragma unroll
+  for (int q = 0; q < NLP; ++q) {
+    const int lp = lp0 + q;
+    if (lp < l) {
+      const double* bl = bt_of(s - (1 << lp));
+      const double* br = bt_of(s + (1 << lp));
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc = fma(-op.fl[q][c], bl[c], acc);
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc = fma(-op.fr[q][c], br[c], acc);
+    }
+  }
+  const double zs = chol_solve_wave<NX>(acc, op.Lrow, op.Lcol, lane);
+  if (lane < NX) recs[((size_t)b * d.N + s) * REC + 2 * NN + lane] = zs;
+  return acc;
+}
+
+// (L L')^-1 applied to four vectors at once, one per 16-lane group of a wavefront (lane r of a
+// group: entry r, row r and column r of that group's factor); broadcasts are width-16 shuffles.
+template <int NX>
+__device__ __forceinline__ double chol_solve_group16(double v, const double (&Lrow)[NX], const double (&Lcol)[NX],
+                                                     const int r) {
+  double diag = 1.0;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) diag = (r == j) ? Lrow[j] : diag;
+  const double dinv = 1.0 / diag;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const double xj = __shfl(v * dinv, j, 16);
+    v = (r == j) ? xj : ((r > j) ? fma(-Lrow[j], xj, v) : v);
+  }
+#pragma unroll
+  for (int j = NX - 1; j >= 0; --j) {
+    const double xj = __shfl(v * dinv, j, 16);
+    v = (r == j) ? xj : ((r < j) ? fma(-Lcol[j], xj, v) : v);
+  }
+  return v;
+}
+
+// Levels 0..2 inside every block of 8 knots by ONE wavefront: 16-lane group g takes separator
+// 2g (level 0), 4g+1 (level 1, g < 2), 3 (level 2, g = 0); idle groups shadow a live one and
+// store nothing. Small workgroups keep thousands of them in flight, which is what hides the
+// three dependent memory round trips. Also writes the block's share of the sums of the upper
+// separators (left at z(first).x, right at z(first+1).x -- z is rewritten by backsub_small).
+//   grid (N / 8, batch), block 64; NX <= 16.
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void rhs_forward_small(Dims d, const double* __restrict__ AB,
+                                                        const double* __restrict__ QR,
+                                                        const double* __restrict__ rhs, const double* F,
+                                                        double* recs, double* z) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX;
+  static_assert(NX <= 16, "one separator row per lane of a 16-lane group");
+  __shared__ double zl[8][ROWS];
+  __shared__ double bt[7][NX];
+  const int N = d.N, b = blockIdx.y, first = blockIdx.x * 8;
+  const int lane = threadIdx.x, g = lane >> 4, r = lane & 15;
+  const int rc = r < NX ? r : NX - 1;
+  for (int e = lane; e < 8 * ROWS; e += 64) {
+    const int kn = e / ROWS, rr = e - kn * ROWS;
+    zl[kn][rr] = leaf_rhs_entry<NX, NU>(d, b, first + kn, rr, QR, rhs);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    const bool act = g < (4 >> lvl) && r < NX;
+    const int gg = g & ((4 >> lvl) - 1);
+    const int j = (gg << (lvl + 1)) + (1 << lvl) - 1, s = first + j;
+    const double* Lb = Fblk(F, d, b, lvl, s + 1);  // lambda rows of knot s+1, column lvl: the factor
+    double Lrow[NX], Lcol[NX], abrow[W];
+    load_row<NX>(Lb + rc * NX, Lrow);
+#pragma unroll
+    for (int q = 0; q < NX; ++q) Lcol[q] = Lb[q * NX + rc];
+    load_row<W>(AB + (((size_t)b * N + s) * NX + rc) * W, abrow);
+    double acc = -zl[j + 1][rc];
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc = fma(abrow[k], zl[j][NX + k], acc);
+    acc -= zl[j + 1][NX + rc];
+#pragma unroll
+    for (int lp = 0; lp < lvl; ++lp) {
+      const int jl = j - (1 << lp), jr = j + (1 << lp);
+      const double* fbb = recs + ((size_t)b * N + first + jl) * REC + NN;
+      const double* fa = recs + ((size_t)b * N + first + jr) * REC;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc = fma(-fbb[c * NX + rc], bt[jl][c], acc);
+#pragma unroll
+      for (int c = 0; c < NX; ++c) acc = fma(-fa[c * NX + rc], bt[jr][c], acc);
+    }
+    const double zs = chol_solve_group16<NX>(acc, Lrow, Lcol, r);
+    if (act) {
+      bt[j][r] = acc;
+      recs[((size_t)b * N + s) * REC + 2 * NN + r] = zs;
+    }
+    wave_lds_sync();
+  }
+  if (g < 2 && r < NX) {
+    // group 0: separators whose subtree starts at `first` -> terms of separator first-1;
+    // group 1: subtrees ending at first+7 -> terms of separator first+7
+    const bool left = g == 0;
+    if (left ? first > 0 : first + 8 < N) {
+      double a2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int jq = left ? (q == 0 ? 0 : (q == 1 ? 1 : 3)) : (q == 0 ? 6 : (q == 1 ? 5 : 3));
+        const double* f = recs + ((size_t)b * N + first + jq) * REC + (left ? 0 : NN);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) a2 = fma(f[c * NX + r], bt[jq][c], a2);
+      }
+      z[((size_t)b * N + first + (left ? 0 : 1)) * ROWS + NX + r] = a2;
+    }
+  }
+}
+
+// Levels 3..K-1 of one problem: one wavefront per separator, level by level.
+//   grid (batch), block 512, dynamic LDS = (N / 8) * NX doubles.
+template <int NX, int NU>
+__global__ __launch_bounds__(512) void rhs_forward_upper(Dims d, const double* __restrict__ AB,
+                                                         const double* __restrict__ QR,
+                                                         const double* __restrict__ rhs, const double* F,
+                                                         double* recs, const double* z) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU;
+  extern __shared__ double btu[];  // b~ of separator 8 m + 7 at btu[m * NX]
+  const int N = d.N, K = d.K, b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int rc = lane < NX ? lane : NX - 1;
+  for (int lvl = 3; lvl < K; ++lvl) {
+    const int nsep = N >> (lvl + 1);
+    for (int q = wave; q < nsep; q += nw) {
+      const int s = q * (2 << lvl) + (1 << lvl) - 1;
+      const double zxu = lane < W ? leaf_rhs_entry<NX, NU>(d, b, s, NX + lane, QR, rhs) : 0.0;
+      const double* abrow = AB + (((size_t)b * N + s) * NX + rc) * W;
+      double acc = -leaf_rhs_entry<NX, NU>(d, b, s + 1, rc, QR, rhs);
+#pragma unroll
+      for (int k = 0; k < W; ++k) acc = fma(abrow[k], readlane_f64(zxu, k), acc);
+      acc -= leaf_rhs_entry<NX, NU>(d, b, s + 1, NX + rc, QR, rhs);
+      // levels 0..2 of the two neighbouring blocks
+      acc -= z[((size_t)b * N + (s - 7) + 1) * ROWS + NX + rc];
+      acc -= z[((size_t)b * N + (s + 1)) * ROWS + NX + rc];
+      // child chains of levels 3..lvl-1, two levels per fetch; the last fetch carries the factor
+      auto bt_of = [&](int sp) -> const double* { return btu + ((sp - 7) >> 3) * NX; };
+      int lp0 = 3;
+      for (; lp0 + 2 < lvl; lp0 += 2) {
+        ForwardOps<NX, 2> op;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int lp = lp0 + q;
+          const double* fbb = recs + ((size_t)b * N + (s - (1 << lp))) * (2 * NX * NX + NX) + NX * NX;
+          const double* fa = recs + ((size_t)b * N + (s + (1 << lp))) * (2 * NX * NX + NX);
+          const double* bl = bt_of(s - (1 << lp));
+          const double* br = bt_of(s + (1 << lp));
+#pragma unroll
+          for (int c = 0; c < NX; ++c) { op.fl[q][c] = fbb[c * NX + rc]; op.fr[q][c] = fa[c * NX + rc]; }
+#pragma unroll
+          for (int c = 0; c < NX; ++c) acc = fma(-op.fl[q][c], bl[c], acc);
+#pragma unroll
+          for (int c = 0; c < NX; ++c) acc = fma(-op.fr[q][c], br[c], acc);
+        }
+      }
+      ForwardOps<NX, 2> op;
+      forward_fetch<NX, NU, 2>(d, b, s, lvl, lp0, rc, F, recs, op);
+      const double btl = forward_finish<NX, NU, 2>(d, b, s, lvl, lp0, acc, lane, recs, op, bt_of);
+      if (lane < NX) btu[((s - 7) >> 3) * NX + lane] = btl;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------- bottom
 // Leaf phase + tree levels 0..JB-1 in ONE launch, everything on chip: a workgroup owns 2^JB
 // consecutive knots, each wavefront two of them (lane = (knot, row)) with its rows of E, of the
@@ -855,10 +1105,13 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
                                                          double* z, int* __restrict__ info,
-                                                         double* __restrict__ rec, const int lean) {
+                                                         double* __restrict__ rec, const int lean,
+                                                         const int recout) {
   // lean (fast mode without KEEP only): the solution comes from backsub_small, which needs the
-  // records of the on-chip separators but nothing of the interior knots -- write those records
-  // and hand off only the first and the last knot of the workgroup (what the upper levels read)
+  // records of the on-chip separators but nothing of the interior knots -- hand off only the
+  // first and the last knot of the workgroup (what the upper levels read).
+  // recout (fast mode): write the records of the on-chip separators (lean, or KEEP for the
+  // record-based right-hand-side re-solve).
   constexpr int W = NX + NU, ROWS = 2 * NX + NU;
   constexpr int NK = 1 << JB, NWAVE = NK / 2;
   static_assert(2 * ROWS <= 64 && 3 * NX <= 64, "two knots per wavefront, three lane groups of NX");
@@ -1010,8 +1263,8 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow);
       if (bad && lane == 0) flag_failure(info, d, b);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
-      if constexpr (!STRICT && !KEEP) {
-        if (lean) {  // record f_a | f_bb | z_sep of this separator (layout of separator_wave)
+      if constexpr (!STRICT) {
+        if (recout) {  // record f_a | f_bb | z_sep of this separator (layout of separator_wave)
           double* myrec = rec + ((size_t)b * N + s) * (2 * NX * NX + NX);
           const int grp = lane / NX;
           if (grp < 2) {

@@ -69,6 +69,7 @@ struct NdlqrHipCtx {
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
+  bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP)
   const void* big_lds_kernel;  // last kernel whose dynamic-LDS limit was raised on this device
   int upper_mode;     // NDLQR_UPPER=0: separator_one + schur_small<BOUNDARY> per level; 1 (default): one
                       // launch per level (level_small); 2: all upper levels in one launch (upper_small)
@@ -207,6 +208,7 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host staging buffers are reused by the caller
   c->fact_valid = false;  // new A, B, Q, R: a cached factorisation no longer matches the inputs
+  c->rec_complete = false;
   return NDLQR_OK;
 }
 
@@ -316,7 +318,8 @@ static void launch_bottom(NdlqrHipCtx* c, bool lean) {
   ScopedSlot t(c, SLOT_BOTTOM);
   const size_t pad = getenv("NDLQR_BOTTOM_LDS_PAD") ? (size_t)atoi(getenv("NDLQR_BOTTOM_LDS_PAD")) : 0;  // occupancy experiments
   hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), pad,
-                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0);
+                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0,
+                     (lean || (KEEP && !STRICT)) ? 1 : 0);
 }
 
 template <int NX, int NU, bool STRICT, bool KEEP>
@@ -422,6 +425,7 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
     if (J > d.K) J = d.K;                                                                           \
     if (strict) *err = keep ? launch_small<NX_, NU_, true, true>(c, J) : launch_small<NX_, NU_, true, false>(c, J);   \
     else        *err = keep ? launch_small<NX_, NU_, false, true>(c, J) : launch_small<NX_, NU_, false, false>(c, J); \
+    c->rec_complete = !strict && keep; /* every separator's record f_a | f_bb | z_sep is in rec */ \
     return true;                                                                                    \
   }
   NDLQR_SMALL_CASE(12, 4)  // quadrotor-sized headline shape
@@ -440,6 +444,7 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   const bool strict = (c->flags & NDLQR_FLAG_STRICT_FP) != 0;
   int err = NDLQR_OK;
   bool done = false;
+  c->rec_complete = false;
   if (!(c->flags & NDLQR_FLAG_GENERIC)) done = try_launch_small(c, strict, &err);
   if (!done) err = strict ? launch_generic<true>(c) : launch_generic<false>(c);
   return err;
@@ -514,6 +519,44 @@ static void launch_rhs_sweep(NdlqrHipCtx* c) {
   }
 }
 
+// Record-based re-solve (fast mode, specialised sizes): forward pass over the separators, then
+// the same back-substitution as the full solve. Returns false when the shape has no instance.
+template <int NX, int NU>
+static void launch_rhs_records(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  {
+    ScopedSlot t(c, SLOT_SEP);
+    hipLaunchKernelGGL((ndlqr::rhs_forward_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(64), 0, c->stream, d, c->AB,
+                       c->QR, c->rhs, c->F, c->rec, c->z);
+  }
+  if (d.K > 3) {
+    ScopedSlot t(c, SLOT_UPPER);
+    const size_t lds = sizeof(double) * (size_t)(d.N / 8) * NX;
+    hipLaunchKernelGGL((ndlqr::rhs_forward_upper<NX, NU>), dim3(d.batch), dim3(512), lds, c->stream, d, c->AB, c->QR,
+                       c->rhs, c->F, c->rec, c->z);
+  }
+  {
+    ScopedSlot t(c, SLOT_APPLY);
+    hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+                       c->QR, c->rhs, c->rec, c->z);
+  }
+}
+
+static bool try_launch_rhs_records(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  if (!c->rec_complete || (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_GENERIC)) || c->no_backsub) return false;
+  if (d.N < 8 || (size_t)(d.N / 8) * d.n * sizeof(double) > 60 * 1024) return false;
+#define NDLQR_RHS_CASE(NX_, NU_)                                                  \
+  if (d.n == NX_ && d.m == NU_ && (d.K + 4) * NX_ <= 256) { launch_rhs_records<NX_, NU_>(c); return true; }
+  NDLQR_RHS_CASE(12, 4)
+  NDLQR_RHS_CASE(6, 3)
+  NDLQR_RHS_CASE(13, 4)
+  NDLQR_RHS_CASE(8, 4)
+  NDLQR_RHS_CASE(4, 2)
+#undef NDLQR_RHS_CASE
+  return false;
+}
+
 int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   if (!c->fact_valid) {
@@ -523,7 +566,9 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
   }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
-  if (c->flags & NDLQR_FLAG_STRICT_FP) launch_rhs_sweep<true>(c); else launch_rhs_sweep<false>(c);
+  if (!try_launch_rhs_records(c)) {
+    if (c->flags & NDLQR_FLAG_STRICT_FP) launch_rhs_sweep<true>(c); else launch_rhs_sweep<false>(c);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->timing_pending = true;

@@ -24,6 +24,11 @@ def synth(ndlqr, n, m, N, seed):
     return Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
 
 
+def _kkt_ok(oracle, prob, x):
+    res, bnorm = oracle.kkt_residual(prob, x)
+    return res <= 1e-9 * max(1.0, bnorm), (res, bnorm)
+
+
 def stack(probs):
     return [np.stack([getattr(p, k) for p in probs]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
 
@@ -228,7 +233,8 @@ def test_env_variants_fast_mode(ndlqr, oracle):
         assert err <= REL_TOL, (env, err)
 
 
-@pytest.mark.parametrize("n,m,N", [(12, 4, 64), (6, 3, 32), (5, 2, 16), (32, 16, 16)])
+@pytest.mark.parametrize("n,m,N", [(12, 4, 64), (6, 3, 32), (5, 2, 16), (32, 16, 16), (12, 4, 8), (12, 4, 16),
+                                   (12, 4, 256), (12, 4, 1024), (13, 4, 64), (4, 2, 128), (8, 4, 32), (6, 3, 4)])
 @pytest.mark.parametrize("strict", [True, False])
 def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
     """Factor once (KEEP_FACT), then new q, r, d, x0 through the rhs-only sweep: must equal a full
@@ -247,6 +253,18 @@ def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
     for p, prob in enumerate(mixed):
         z, _, _, _ = oracle.solve(prob, 1)
         ref = z[: prob.nvars]
+        if strict:
+            assert np.array_equal(sol[p], ref)
+        else:
+            assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+            ok, detail = _kkt_ok(oracle, prob, sol[p])
+            assert ok, detail
+    # a second new right-hand side against the same cached factorisation (back to the first one)
+    bs.set_rhs_flat(*[np.stack([getattr(p, k) for p in first]) for k in ("q", "r", "d", "x0")])
+    assert bs.solve_rhs_only() == 0
+    sol = bs.solutions()
+    for p, prob in enumerate(first):
+        ref = oracle.solve(prob, 1)[0][: prob.nvars]
         if strict:
             assert np.array_equal(sol[p], ref)
         else:
@@ -273,11 +291,6 @@ def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
 # size-independent properties -- the KKT residual of the raw problem (SURVEY.md 8c secondary
 # witness), linearity of the solution in the right-hand side, determinism -- plus a full oracle
 # comparison of a few sampled members.
-def _kkt_ok(oracle, prob, x):
-    res, bnorm = oracle.kkt_residual(prob, x)
-    return res <= 1e-9 * max(1.0, bnorm), (res, bnorm)
-
-
 @pytest.mark.parametrize("n,m,N,batch,sample", [(12, 4, 256, 1024, 12), (12, 4, 1024, 96, 4), (6, 3, 256, 1, 1),
                                                 (64, 16, 512, 4, 1)])
 def test_full_size_properties(ndlqr, oracle, n, m, N, batch, sample):
