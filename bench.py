@@ -228,8 +228,13 @@ def main():
     prof = bs.profile()
     bs.set_flags(args.flags)
 
-    elapsed_max, fails_max = sharding.max_over_ranks([elapsed, float(fails)],
-                                                     device="cuda" if backend == "nccl" else "cpu")
+    # every problem of the shard, checked on the device against its raw data (outside the timed
+    # region): worst ||K z - b|| / max(1, ||b||) -- SURVEY.md 8(d) "KKT residual of every problem"
+    kres, kbn = bs.kkt_residuals()
+    kkt_worst = float((kres / [max(1.0, v) for v in kbn]).max())
+
+    elapsed_max, fails_max, kkt_max = sharding.max_over_ranks(
+        [elapsed, float(fails), kkt_worst], device="cuda" if backend == "nccl" else "cpu")
     fails_max = int(fails_max)
 
     if rank == 0:
@@ -284,7 +289,8 @@ def main():
             "config": {"workload": "nx=%d nu=%d N=%d batch=%d per GPU, fp64, factor+solve per step"
                                    % (n, m, N, batch),
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "flags": args.flags, "cholesky_failures": fails_max},
+                       "flags": args.flags, "cholesky_failures": fails_max,
+                       "kkt_residual_rel_max": kkt_max},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": dom_launches,

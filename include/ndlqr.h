@@ -336,6 +336,9 @@ int ndlqr_CopyBatchSolution(NdLqrBatchSolver* bs, int p, double* soln);    /* nv
 int ndlqr_CopyBatchSolutions(NdLqrBatchSolver* bs, double* soln);          /* batch*nvars */
 int ndlqr_CopyBatchFactors(NdLqrBatchSolver* bs, int p, double* fact);     /* reference layout */
 int ndlqr_BatchCholeskyFailures(NdLqrBatchSolver* bs);
+/* KKT residual ||K z - b||_2 and ||b||_2 of every problem's resident solution against its raw
+ * data, evaluated on the device (batch doubles each; bnorm may be NULL). */
+int ndlqr_BatchKktResiduals(NdLqrBatchSolver* bs, double* res, double* bnorm);
 double ndlqr_BatchSolveTimeMs(const NdLqrBatchSolver* bs); /* HIP-event time of last solve */
 void* ndlqr_BatchDeviceContext(NdLqrBatchSolver* bs);      /* NdlqrHipCtx* (ndlqr_hip.h) */
 

@@ -73,6 +73,10 @@ double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
 int ndlqr_hip_download_solutions(NdlqrHipCtx* ctx, int p0, int count, double* soln);
 int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* ctx, int p, double* z_full); /* N*(2n+m) */
 int ndlqr_hip_download_factors(NdlqrHipCtx* ctx, int p, double* fact); /* needs NDLQR_FLAG_KEEP_FACT */
+/* Residual of the resident solution against the raw problem, per problem, computed on the device:
+ * res[b] = ||K z - b||_2, bnorm[b] = ||b||_2 (bnorm may be NULL); the rows are those of the
+ * reference's KKT system (src/solver.c:122-194). batch doubles each. */
+int ndlqr_hip_kkt_residual(NdlqrHipCtx* ctx, double* res, double* bnorm);
 /* Tuning knob: tree level J from which the upper levels run boundary-first + one apply pass
  * (-1 = default, K = pure level-by-level streaming). Results do not depend on it. */
 int ndlqr_hip_set_fuse_level(NdlqrHipCtx* ctx, int J);

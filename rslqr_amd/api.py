@@ -225,6 +225,7 @@ def lib():
     proto("ndlqr_CopyBatchSolutions", ci, vp, dp)
     proto("ndlqr_CopyBatchFactors", ci, vp, ci, dp)
     proto("ndlqr_BatchCholeskyFailures", ci, vp)
+    proto("ndlqr_BatchKktResiduals", ci, vp, dp, dp)
     proto("ndlqr_BatchSolveTimeMs", cd, vp)
     proto("ndlqr_BatchDeviceContext", vp, vp)
     # shim bits used by the benchmark
@@ -352,6 +353,15 @@ class BatchSolver:
         if got != self.nvars:
             raise RuntimeError("ndlqr_CopyBatchSolution failed: %d" % got)
         return out
+
+    def kkt_residuals(self):
+        """(res, bnorm): ||K z - b||_2 and ||b||_2 of every problem, evaluated on the device."""
+        res = np.zeros(self.batch)
+        bn = np.zeros(self.batch)
+        err = self.L.ndlqr_BatchKktResiduals(self.h, _ptr(res), _ptr(bn))
+        if err:
+            raise RuntimeError("ndlqr_BatchKktResiduals failed: %d" % err)
+        return res, bn
 
     def solutions(self):
         out = np.zeros((self.batch, self.nvars))

@@ -260,6 +260,10 @@ double ndlqr_BatchSolveTimeMs(const NdLqrBatchSolver* bs) {
 int ndlqr_BatchCholeskyFailures(NdLqrBatchSolver* bs) {
   return bs ? ndlqr_hip_cholesky_failures(bs->ctx) : NDLQR_ERR_INVALID;
 }
+int ndlqr_BatchKktResiduals(NdLqrBatchSolver* bs, double* res, double* bnorm) {
+  if (!bs || !res) return NDLQR_ERR_INVALID;
+  return ndlqr_hip_kkt_residual(bs->ctx, res, bnorm);
+}
 int ndlqr_CopyBatchSolution(NdLqrBatchSolver* bs, int p, double* soln) {
   if (!bs || !soln || p < 0 || p >= bs->batch) return NDLQR_ERR_INVALID;
   int err = ndlqr_hip_download_solutions(bs->ctx, p, 1, soln);

@@ -537,6 +537,62 @@ __global__ void rhs_update_generic(Dims d, int l, const double* __restrict__ F, 
   *g = acc;
 }
 
+// ------------------------------------------------------------------------------------- KKT residual
+// Secondary witness: the residual of the solution in z against the RAW problem
+// (the packed inputs, not the factorisation), per problem:
+//   x_0 - x_init;  Q x_k + q_k - lambda_k + A_k' lambda_{k+1};  R u_k + r_k + B_k' lambda_{k+1};
+//   A_k x_k + B_k u_k + d_k - x_{k+1}                        (oracle_kkt_residual, oracle/ndlqr_oracle.c)
+// z(k) = [lambda_k | x_k | u_k] with lambda_k the multiplier of the dynamics INTO knot k; rhs holds
+// -(x_init or d_{k-1}) | -q_k | -r_k. out[b] = ||K z - b||_2, out[batch + b] = ||b||_2.
+//   grid (batch), block 256.
+__global__ void kkt_residual_generic(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+                                     const double* __restrict__ rhs, const double* __restrict__ z,
+                                     double* __restrict__ out) {
+  const int n = d.n, m = d.m, N = d.N, rows = d.rows, w = d.w, b = blockIdx.x;
+  const double* zb = z + (size_t)b * N * rows;
+  const double* rb = rhs + (size_t)b * N * rows;
+  double res = 0.0, bn = 0.0;
+  for (int e = threadIdx.x; e < N * rows; e += blockDim.x) {
+    const int k = e / rows, r = e - k * rows;
+    const double* zk = zb + (size_t)k * rows;
+    const double* ab = AB + ((size_t)b * N + k) * n * w;
+    const double* qr = QR + ((size_t)b * N + k) * w;
+    double v = 0.0, bv = -rb[(size_t)k * rows + r];
+    if (r < n) {
+      if (k == 0) {
+        v = zk[n + r] - bv;  // x_0 - x_init
+      } else {
+        const double* zp = zk - rows;                             // knot k-1
+        const double* abp = ab - (size_t)n * w + (size_t)r * w;   // row r of [A_{k-1} | B_{k-1}]
+        v = bv - zk[n + r];                                       // d_{k-1} - x_k
+        for (int j = 0; j < w; ++j) v = fma(abp[j], zp[n + j], v);
+      }
+    } else if (r < 2 * n) {
+      const int i = r - n;
+      v = fma(qr[i], zk[n + i], bv) - zk[i];
+      if (k < N - 1)
+        for (int j = 0; j < n; ++j) v = fma(ab[(size_t)j * w + i], zk[rows + j], v);
+    } else if (k < N - 1) {
+      const int i = r - 2 * n;
+      v = fma(qr[n + i], zk[2 * n + i], bv);
+      for (int j = 0; j < n; ++j) v = fma(ab[(size_t)j * w + n + i], zk[rows + j], v);
+    } else {
+      bv = 0.0;  // the u slot of the last knot is not part of the system
+    }
+    res = fma(v, v, res);
+    bn = fma(bv, bv, bn);
+  }
+  __shared__ double sres[256], sbn[256];
+  sres[threadIdx.x] = res; sbn[threadIdx.x] = bn;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { sres[threadIdx.x] += sres[threadIdx.x + off]; sbn[threadIdx.x] += sbn[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[b] = sqrt(sres[0]); out[d.batch + b] = sqrt(sbn[0]); }
+}
+
+
 // ------------------------------------------------------------------------------------- dense helpers
 // Device versions of the reference's internal routines, one element / column per thread.
 // C = alpha*op(A)*op(B) + beta*C  (linalg_custom.c:20-43): beta first, then k ascending.

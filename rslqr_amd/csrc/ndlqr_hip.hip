@@ -632,6 +632,24 @@ int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln
   return NDLQR_OK;
 }
 
+int ndlqr_hip_kkt_residual(NdlqrHipCtx* c, double* res, double* bnorm) {
+  if (!c || !res) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipSetDevice(c->device));
+  double* out = nullptr;
+  HIP_TRY(hipMalloc(&out, sizeof(double) * 2 * (size_t)d.batch));
+  hipLaunchKernelGGL(ndlqr::kkt_residual_generic, dim3(d.batch), dim3(256), 0, c->stream, d, c->AB, c->QR, c->rhs,
+                     c->z, out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(res, out, sizeof(double) * d.batch, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && bnorm)
+    e = hipMemcpyAsync(bnorm, out + d.batch, sizeof(double) * d.batch, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(out);
+  if (e != hipSuccess) return fail("ndlqr_hip_kkt_residual", e);
+  return NDLQR_OK;
+}
+
 int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
   if (!c || !z_full || p < 0 || p >= c->d.batch) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;

@@ -299,6 +299,8 @@ def test_full_size_properties(ndlqr, oracle, n, m, N, batch, sample):
     assert bs.solve() == 0 and bs.cholesky_failures() == 0
     sol = bs.solutions()
     assert np.isfinite(sol).all()
+    res, bn = bs.kkt_residuals()  # every member, on the device
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all(), float((res / np.maximum(1.0, bn)).max())
     rng = np.random.default_rng(n * 1000 + N)
     picks = sorted(set([0, batch - 1] + list(rng.integers(0, batch, size=sample))))
     for p in picks:
@@ -314,6 +316,34 @@ def test_full_size_properties(ndlqr, oracle, n, m, N, batch, sample):
     # determinism: the same launch sequence gives the same bits
     assert bs.solve() == 0
     assert np.array_equal(bs.solutions(), sol)
+    bs.close()
+
+
+@pytest.mark.parametrize("n,m,N", [(12, 4, 64), (6, 3, 16), (5, 2, 8), (16, 8, 4)])
+def test_device_kkt_residual_matches_oracle(ndlqr, oracle, n, m, N):
+    """ndlqr_BatchKktResiduals evaluates the same rows as the oracle's KKT residual: tiny for the
+    solution, and -- with the right-hand side swapped under a stale solution -- the same large
+    number the oracle computes for that (solution, problem) pair."""
+    batch = 3
+    first = [synth(ndlqr, n, m, N, 40 + p) for p in range(batch)]
+    other = [synth(ndlqr, n, m, N, 90 + p) for p in range(batch)]
+    mixed = [Problem(n, m, N, f.A, f.B, f.Q, f.R, o.q, o.r, o.d, o.x0) for f, o in zip(first, other)]
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*stack(first))
+    assert bs.solve() == 0
+    sol = bs.solutions()
+    res, bn = bs.kkt_residuals()
+    for p, prob in enumerate(first):
+        ores, obn = oracle.kkt_residual(prob, sol[p])
+        assert abs(bn[p] - obn) <= 1e-12 * obn
+        assert res[p] <= 1e-9 * max(1.0, bn[p]) and ores <= 1e-9 * max(1.0, obn)
+    bs.set_rhs_flat(*[np.stack([getattr(p, k) for p in mixed]) for k in ("q", "r", "d", "x0")])
+    res, bn = bs.kkt_residuals()  # stale solution against the new right-hand side
+    for p, prob in enumerate(mixed):
+        ores, obn = oracle.kkt_residual(prob, sol[p])
+        assert ores > 1e-3
+        assert abs(res[p] - ores) <= 1e-10 * ores, (res[p], ores)
+        assert abs(bn[p] - obn) <= 1e-12 * obn
     bs.close()
 
 
