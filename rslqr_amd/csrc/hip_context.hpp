@@ -1,0 +1,98 @@
+// hip_context.hpp -- internal: the device context behind NdlqrHipCtx* and the launch-profiling
+// helper, shared by ndlqr_hip.hip and the per-size translation units (small_instance.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ndlqr.h"
+#include "ndlqr_hip.h"
+
+#include "kernels_common.hpp"
+
+// records the message for ndlqr_hip_last_error(), prints it, returns NDLQR_ERR_NO_DEVICE
+int ndlqr_hip_fail(const char* what, hipError_t e);
+#define HIP_TRY(expr)                                                  \
+  do {                                                                 \
+    hipError_t e_ = (expr);                                            \
+    if (e_ != hipSuccess) return ndlqr_hip_fail(#expr, e_);            \
+  } while (0)
+
+// ------------------------------------------------------------------------------ context
+
+enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_BOUNDARY, SLOT_APPLY, SLOT_BOTTOM, SLOT_UPPER, SLOT_COUNT };
+
+struct PendingEvent {
+  int slot;
+  hipEvent_t start, stop;
+};
+
+struct NdlqrHipCtx {
+  ndlqr::Dims d;
+  int device;
+  unsigned flags;
+  hipStream_t stream;
+  bool own_stream;
+  double* AB;
+  double* QR;
+  double* rhs;
+  double* F;
+  double* z;
+  double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
+  int* info;
+  bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
+  bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP)
+  const void* big_lds_kernel;  // last kernel whose dynamic-LDS limit was raised on this device
+  int upper_mode;     // NDLQR_UPPER=0: separator_one + schur_small<BOUNDARY> per level; 1 (default): one
+                      // launch per level (level_small); 2: all upper levels in one launch (upper_small)
+  bool no_backsub;    // NDLQR_NO_BACKSUB=1: fast mode keeps hand-off + finish_small (A/B timing)
+  bool no_finish;     // NDLQR_NO_FINISH=1: fast mode keeps apply_small instead of finish_small (A/B timing)
+  int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
+  int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
+  hipEvent_t ev_start, ev_stop;
+  bool timing_pending;
+  double last_ms;
+  int last_failures;
+  // the launch sequence captured as a hipGraph (replayed when nothing that shapes it changed)
+  hipGraphExec_t graph_exec;
+  unsigned graph_flags;
+  int graph_J, graph_JB;
+  hipStream_t graph_stream;
+  bool fact_valid;   // the device holds a complete factorisation (last solve ran with KEEP_FACT)
+  // profile
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  double slot_ms[SLOT_COUNT];
+  int slot_launches[SLOT_COUNT];
+};
+
+static inline hipEvent_t take_event(NdlqrHipCtx* c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t ev = c->event_pool.back();
+    c->event_pool.pop_back();
+    return ev;
+  }
+  hipEvent_t ev = nullptr;
+  (void)hipEventCreate(&ev);
+  return ev;
+}
+
+struct ScopedSlot {  // brackets one kernel launch with events when profiling is on
+  NdlqrHipCtx* c;
+  PendingEvent pe;
+  bool on;
+  ScopedSlot(NdlqrHipCtx* ctx, int slot) : c(ctx), on((ctx->flags & NDLQR_FLAG_PROFILE) != 0) {
+    if (!on) return;
+    pe.slot = slot; pe.start = take_event(c); pe.stop = take_event(c);
+    (void)hipEventRecord(pe.start, c->stream);
+  }
+  ~ScopedSlot() {
+    if (!on) return;
+    (void)hipEventRecord(pe.stop, c->stream);
+    c->pending.push_back(pe);
+  }
+};

@@ -19,97 +19,9 @@
 //     divisions -- the very operations the reference executes on the non-zero entries.
 #pragma once
 #include "kernels_common.hpp"
+#include "kernels_leaf.hpp"
 
 namespace ndlqr {
-
-// ------------------------------------------------------------------------------------- leaves
-// grid (N, batch), any block size. Writes both factor blocks of knot k completely (zero rows
-// included) and the leaf-processed rhs block, so no memset is needed between solves.
-template <bool STRICT>
-__global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
-                             const double* __restrict__ rhs, double* __restrict__ F,
-                             double* __restrict__ z, int* __restrict__ info) {
-  const int k = blockIdx.x, b = blockIdx.y;
-  const int n = d.n, m = d.m, w = d.w, rows = d.rows, N = d.N;
-  const double* ab = AB + ((size_t)b * N + k) * n * w;
-  const double* qr = QR + ((size_t)b * N + k) * w;
-  const double* r0 = rhs + ((size_t)b * N + k) * rows;
-  double* zk = z + ((size_t)b * N + k) * rows;
-  const bool last = (k == N - 1);
-
-  // pivot check (clap_CholeskyFactorize fails on a pivot <= 0, linalg_custom.c:99-102)
-  for (int i = threadIdx.x; i < n + (last ? 0 : m); i += blockDim.x)
-    if (!(qr[i] > 0.0)) flag_failure(info, d, b);
-
-  if (k == 0) {
-    double* F0 = Fblk(F, d, b, 0, 0);
-    for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
-      const int r = e / n, c = e - r * n;
-      double v = 0.0;
-      if (r < n) {
-        v = -ab[c * w + r];  // Fy = -A'
-      } else if (r >= 2 * n) {
-        const int i = r - 2 * n;
-        const double s = qr[n + i] / sqrt(qr[n + i]);
-        v = (ab[c * w + n + i] / s) / s;  // Fu = R \ B'
-      }
-      F0[e] = v;
-    }
-    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
-      double v;
-      if (i < n) {
-        v = mad<STRICT>(-qr[i], r0[i], -r0[n + i]);  // zy = -Q*zy_old - zx_old
-      } else if (i < 2 * n) {
-        v = -r0[i - n];  // zx = -zy_old
-      } else {
-        const double s = qr[i - n] / sqrt(qr[i - n]);
-        v = (r0[i] / s) / s;  // zu = R \ zu
-      }
-      zk[i] = v;
-    }
-    return;
-  }
-
-  const int lvl = trailing_ones(k), plvl = trailing_ones(k - 1);
-  if (!last) {
-    double* Fk = Fblk(F, d, b, lvl, k);
-    for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
-      const int r = e / n, c = e - r * n;
-      double v = 0.0;
-      if (r >= 2 * n) {
-        const int i = r - 2 * n;
-        const double s = qr[n + i] / sqrt(qr[n + i]);
-        v = (ab[c * w + n + i] / s) / s;  // Fu = R \ B'
-      } else if (r >= n) {
-        const int i = r - n;
-        const double s = qr[i] / sqrt(qr[i]);
-        v = (ab[c * w + i] / s) / s;  // Fx = Q \ A'
-      }
-      Fk[e] = v;
-    }
-  }
-  double* Fp = Fblk(F, d, b, plvl, k);
-  for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
-    const int r = e / n, c = e - r * n;
-    double v = 0.0;
-    if (r >= n && r < 2 * n && r - n == c) {
-      const double s = qr[c] / sqrt(qr[c]);
-      v = (-1.0 / s) / s;  // Q \ (-I)
-    }
-    Fp[e] = v;
-  }
-  for (int i = threadIdx.x; i < rows; i += blockDim.x) {
-    double v = r0[i];
-    if (i >= n && i < 2 * n) {
-      const double s = qr[i - n] / sqrt(qr[i - n]);
-      v = (v / s) / s;
-    } else if (i >= 2 * n && !last) {
-      const double s = qr[i - n] / sqrt(qr[i - n]);
-      v = (v / s) / s;
-    }
-    zk[i] = v;
-  }
-}
 
 // ------------------------------------------------------------------------------------- separators
 // grid (N / 2^(l+1), batch), block 256, dynamic LDS = (n (n+1) + n (2n+1)) doubles.
@@ -406,7 +318,7 @@ __global__ void schur_generic(Dims d, int l, double* F, double* z) {
 // B [N][n*m] column-major, Q,q,d [N][n], R,r [N][m], x0 [n] per problem): transposes A, B into the
 // row-major [A | B] input, copies the diagonals and builds the negated right-hand side.
 // grid (N, batch), any block size.
-__global__ void pack_flat_generic(Dims d, const double* __restrict__ A, const double* __restrict__ B,
+static __global__ void pack_flat_generic(Dims d, const double* __restrict__ A, const double* __restrict__ B,
                                   const double* __restrict__ Q, const double* __restrict__ R,
                                   const double* __restrict__ q, const double* __restrict__ r,
                                   const double* __restrict__ dd, const double* __restrict__ x0,
@@ -545,10 +457,10 @@ __global__ void rhs_update_generic(Dims d, int l, const double* __restrict__ F, 
 // z(k) = [lambda_k | x_k | u_k] with lambda_k the multiplier of the dynamics INTO knot k; rhs holds
 // -(x_init or d_{k-1}) | -q_k | -r_k. out[b] = ||K z - b||_2, out[batch + b] = ||b||_2.
 //   grid (batch), block 256.
-__global__ void kkt_residual_generic(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+static __global__ void kkt_residual_generic(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                                      const double* __restrict__ rhs, const double* __restrict__ z,
                                      double* __restrict__ out) {
-  const int n = d.n, m = d.m, N = d.N, rows = d.rows, w = d.w, b = blockIdx.x;
+  const int n = d.n, N = d.N, rows = d.rows, w = d.w, b = blockIdx.x;
   const double* zb = z + (size_t)b * N * rows;
   const double* rb = rhs + (size_t)b * N * rows;
   double res = 0.0, bn = 0.0;
@@ -596,7 +508,7 @@ __global__ void kkt_residual_generic(Dims d, const double* __restrict__ AB, cons
 // ------------------------------------------------------------------------------------- dense helpers
 // Device versions of the reference's internal routines, one element / column per thread.
 // C = alpha*op(A)*op(B) + beta*C  (linalg_custom.c:20-43): beta first, then k ascending.
-__global__ void dense_gemm(int tA, int tB, int m, int n, int k, double alpha, const double* A, int lda,
+static __global__ void dense_gemm(int tA, int tB, int m, int n, int k, double alpha, const double* A, int lda,
                            const double* B, int ldb, double beta, double* C, int ldc) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= m * n) return;
@@ -611,7 +523,7 @@ __global__ void dense_gemm(int tA, int tB, int m, int n, int k, double alpha, co
 }
 
 // in-place lower Cholesky (linalg_custom.c:88-111); single block.
-__global__ void dense_potrf(int n, double* A, int lda, int* info) {
+static __global__ void dense_potrf(int n, double* A, int lda, int* info) {
   for (int j = 0; j < n; ++j) {
     for (int i = j + threadIdx.x; i < n; i += blockDim.x) {
       double acc = A[i + (size_t)lda * j];
@@ -632,7 +544,7 @@ __global__ void dense_potrf(int n, double* A, int lda, int* info) {
 }
 
 // L L' x = b (linalg_custom.c:113-138); one thread per right-hand side.
-__global__ void dense_potrs(int n, int nrhs, const double* L, int ldl, double* B, int ldb) {
+static __global__ void dense_potrs(int n, int nrhs, const double* L, int ldl, double* B, int ldb) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nrhs) return;
   double* x = B + (size_t)ldb * c;

@@ -1,0 +1,133 @@
+// launch_small.hpp -- internal: launch sequences of the size-specialised kernels, instantiated
+// once per (nstates, ninputs) in its own translation unit (small_instance.hip) so that the
+// instances compile in parallel.
+#pragma once
+#include "hip_context.hpp"
+#include "kernels_leaf.hpp"
+#include "kernels_small.hpp"
+
+// Size-specialised launch sequence. Levels below J: one separator + one Schur launch each.
+// Levels J..K-1 ("boundary-first"): separator + Schur on the two boundary knots of every subtree
+// (tiny grids), then ONE apply_small pass that takes every knot through all those levels in
+// registers. J = K disables the second form (pure level-by-level streaming).
+template <int NX, int NU, bool STRICT, bool KEEP, int JB>
+static void launch_bottom(NdlqrHipCtx* c, bool lean) {
+  const ndlqr::Dims& d = c->d;
+  ScopedSlot t(c, SLOT_BOTTOM);
+  const size_t pad = getenv("NDLQR_BOTTOM_LDS_PAD") ? (size_t)atoi(getenv("NDLQR_BOTTOM_LDS_PAD")) : 0;  // occupancy experiments
+  hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), pad,
+                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0,
+                     (lean || (KEEP && !STRICT)) ? 1 : 0);
+}
+
+template <int NX, int NU, bool STRICT, bool KEEP>
+static int launch_small(NdlqrHipCtx* c, int J) {
+  const ndlqr::Dims& d = c->d;
+  using Sh = ndlqr::SchurShape<NX, NU>;
+  // leaf + levels 0..JB-1 fused on chip when the horizon is long enough, else the leaf kernel
+  int JB = c->bottom_levels;
+  if (JB > 3) JB = 3;
+  while (JB > 0 && d.K <= JB) --JB;
+  if (JB > J) JB = J;
+  // fast mode without KEEP: solution by back-substitution from the separator records (needs the
+  // boundary-first schedule right after the bottom kernel, so that no level reads interior knots)
+  const bool lean = !STRICT && !KEEP && JB >= J && JB >= 1 && JB < d.K && c->upper_mode != 0 &&
+                    (d.K + 4) * NX <= 256 && !c->no_backsub;
+  switch (JB) {
+    case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c, lean); break;
+    case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c, lean); break;
+    case 1: launch_bottom<NX, NU, STRICT, KEEP, 1>(c, lean); break;
+    default: {
+      ScopedSlot t(c, SLOT_LEAF);
+      hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
+                         c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+    }
+  }
+  if (JB >= J && JB >= 1 && JB < d.K && c->upper_mode == 1) {
+    // no full-level Schur pass left: separator + boundary update of a level in one launch
+    for (int l = JB; l < d.K; ++l) {
+      ScopedSlot t(c, SLOT_UPPER);
+      hipLaunchKernelGGL((ndlqr::level_small<NX, NU, STRICT, KEEP>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0,
+                         c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
+    }
+  } else if (JB >= J && JB >= 1 && JB < d.K && c->upper_mode == 2) {
+    // no full-level Schur pass left: all remaining levels of a problem in one launch
+    ScopedSlot t(c, SLOT_UPPER);
+    auto kern = ndlqr::upper_small<NX, NU, STRICT, KEEP>;
+    int nw = 8;
+    while (nw > 1 && nw / 2 >= (d.N >> (JB + 1))) nw /= 2;  // not more wavefronts than subtrees
+    const size_t lds = (size_t)nw * (sizeof(ndlqr::SepIn<NX, NU>) + sizeof(ndlqr::SepOut<NX>));
+    if (lds > 64 * 1024 && c->big_lds_kernel != reinterpret_cast<const void*>(kern)) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      c->big_lds_kernel = reinterpret_cast<const void*>(kern);
+    }
+    hipLaunchKernelGGL(kern, dim3(d.batch), dim3(64 * nw), lds, c->stream, d, JB, c->AB, c->F, c->z, c->rec,
+                       c->info);
+  } else
+  for (int l = JB; l < d.K; ++l) {
+    {
+      ScopedSlot t(c, SLOT_SEP);
+      const int nsep = d.N >> (l + 1);
+      hipLaunchKernelGGL((ndlqr::separator_one<NX, NU, STRICT, KEEP>), dim3(nsep, d.batch), dim3(64), 0, c->stream,
+                         d, l, c->AB, c->F, c->z, c->rec, c->info);
+    }
+    if (l < J) {
+      ScopedSlot t(c, SLOT_SCHUR);
+      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT, false>), dim3(d.N / Sh::KPB, d.batch), dim3(256),
+                         0, c->stream, d, l, c->F, c->z, c->rec);
+    } else if (l < d.K - 1) {
+      ScopedSlot t(c, SLOT_BOUNDARY);
+      const int nsub = d.N >> (l + 1);
+      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT, true>),
+                         dim3((nsub + Sh::WAVES - 1) / Sh::WAVES, d.batch), dim3(256), 0, c->stream, d, l,
+                         c->F, c->z, c->rec);
+    }
+  }
+  if (lean) {
+    ScopedSlot t(c, SLOT_APPLY);
+    if constexpr (!STRICT && !KEEP)
+      hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+                         c->QR, c->rhs, c->rec, c->z);
+    return NDLQR_OK;
+  }
+  if (J < d.K) {
+    ScopedSlot t(c, SLOT_APPLY);
+    if constexpr (!STRICT && !KEEP) {
+      // only the solution is wanted: two dot products per knot row against the top-down vectors w
+      if (J >= 2 && !c->no_finish) {
+        const size_t lds = sizeof(double) * (size_t)(d.K - J) * (Sh::REC + 2 * 2 * NX);
+        hipLaunchKernelGGL((ndlqr::finish_small<NX, NU>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds, c->stream,
+                           d, J, c->F, c->z, c->rec);
+        return NDLQR_OK;
+      }
+    }
+    const size_t lds = sizeof(double) * (size_t)(d.K - J) * Sh::REC;
+    hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
+                       c->stream, d, J, c->F, c->z, c->rec);
+  }
+  return NDLQR_OK;
+}
+
+// Record-based re-solve (fast mode, specialised sizes): forward pass over the separators, then
+// the same back-substitution as the full solve. Returns false when the shape has no instance.
+template <int NX, int NU>
+static void launch_rhs_records(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  {
+    ScopedSlot t(c, SLOT_SEP);
+    hipLaunchKernelGGL((ndlqr::rhs_forward_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(64), 0, c->stream, d, c->AB,
+                       c->QR, c->rhs, c->F, c->rec, c->z);
+  }
+  if (d.K > 3) {
+    ScopedSlot t(c, SLOT_UPPER);
+    const size_t lds = sizeof(double) * (size_t)(d.N / 8) * NX;
+    hipLaunchKernelGGL((ndlqr::rhs_forward_upper<NX, NU>), dim3(d.batch), dim3(512), lds, c->stream, d, c->AB, c->QR,
+                       c->rhs, c->F, c->rec, c->z);
+  }
+  {
+    ScopedSlot t(c, SLOT_APPLY);
+    hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+                       c->QR, c->rhs, c->rec, c->z);
+  }
+}

@@ -6,21 +6,12 @@
 // Written for wave64 / gfx950 only; built with -ffp-contract=off so that every fused
 // multiply-add in the kernels is an explicit fma() (fast mode) or an explicit mul + add
 // (NDLQR_FLAG_STRICT_FP, which reproduces the reference's default CPU build bit for bit).
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "ndlqr.h"
-#include "ndlqr_hip.h"
-
-#include "kernels_common.hpp"
+#include "hip_context.hpp"
 #include "kernels_generic.hpp"
-#include "kernels_small.hpp"
 #include "kernels_mfma.hpp"
+#ifdef NDLQR_SINGLE_TU  // developer builds (tools/segtime.py): every instance in this translation unit
+#include "launch_small.hpp"
+#endif
 
 // ------------------------------------------------------------------------------ errors
 
@@ -28,16 +19,12 @@ static thread_local std::string g_last_error = "";
 
 const char* ndlqr_hip_last_error(void) { return g_last_error.c_str(); }
 
-static int fail(const char* what, hipError_t e) {
+int ndlqr_hip_fail(const char* what, hipError_t e) {
   g_last_error = std::string(what) + ": " + hipGetErrorString(e);
   fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
   return NDLQR_ERR_NO_DEVICE;
 }
-#define HIP_TRY(expr)                                        \
-  do {                                                       \
-    hipError_t e_ = (expr);                                  \
-    if (e_ != hipSuccess) return fail(#expr, e_);            \
-  } while (0)
+static int fail(const char* what, hipError_t e) { return ndlqr_hip_fail(what, e); }
 
 int ndlqr_hip_device_count(void) {
   int count = 0;
@@ -45,54 +32,7 @@ int ndlqr_hip_device_count(void) {
   return count;
 }
 
-// ------------------------------------------------------------------------------ context
-
-enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_BOUNDARY, SLOT_APPLY, SLOT_BOTTOM, SLOT_UPPER, SLOT_COUNT };
 static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom", "upper"};
-
-struct PendingEvent {
-  int slot;
-  hipEvent_t start, stop;
-};
-
-struct NdlqrHipCtx {
-  ndlqr::Dims d;
-  int device;
-  unsigned flags;
-  hipStream_t stream;
-  bool own_stream;
-  double* AB;
-  double* QR;
-  double* rhs;
-  double* F;
-  double* z;
-  double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
-  int* info;
-  bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
-  bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP)
-  const void* big_lds_kernel;  // last kernel whose dynamic-LDS limit was raised on this device
-  int upper_mode;     // NDLQR_UPPER=0: separator_one + schur_small<BOUNDARY> per level; 1 (default): one
-                      // launch per level (level_small); 2: all upper levels in one launch (upper_small)
-  bool no_backsub;    // NDLQR_NO_BACKSUB=1: fast mode keeps hand-off + finish_small (A/B timing)
-  bool no_finish;     // NDLQR_NO_FINISH=1: fast mode keeps apply_small instead of finish_small (A/B timing)
-  int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
-  int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
-  hipEvent_t ev_start, ev_stop;
-  bool timing_pending;
-  double last_ms;
-  int last_failures;
-  // the launch sequence captured as a hipGraph (replayed when nothing that shapes it changed)
-  hipGraphExec_t graph_exec;
-  unsigned graph_flags;
-  int graph_J, graph_JB;
-  hipStream_t graph_stream;
-  bool fact_valid;   // the device holds a complete factorisation (last solve ran with KEEP_FACT)
-  // profile
-  std::vector<PendingEvent> pending;
-  std::vector<hipEvent_t> event_pool;
-  double slot_ms[SLOT_COUNT];
-  int slot_launches[SLOT_COUNT];
-};
 
 static size_t bytes_AB(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.n * d.w; }
 static size_t bytes_QR(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.w; }
@@ -232,33 +172,6 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
 
 // ------------------------------------------------------------------------------ launches
 
-static hipEvent_t take_event(NdlqrHipCtx* c) {
-  if (!c->event_pool.empty()) {
-    hipEvent_t ev = c->event_pool.back();
-    c->event_pool.pop_back();
-    return ev;
-  }
-  hipEvent_t ev = nullptr;
-  (void)hipEventCreate(&ev);
-  return ev;
-}
-
-struct ScopedSlot {  // brackets one kernel launch with events when profiling is on
-  NdlqrHipCtx* c;
-  PendingEvent pe;
-  bool on;
-  ScopedSlot(NdlqrHipCtx* ctx, int slot) : c(ctx), on((ctx->flags & NDLQR_FLAG_PROFILE) != 0) {
-    if (!on) return;
-    pe.slot = slot; pe.start = take_event(c); pe.stop = take_event(c);
-    (void)hipEventRecord(pe.start, c->stream);
-  }
-  ~ScopedSlot() {
-    if (!on) return;
-    (void)hipEventRecord(pe.stop, c->stream);
-    c->pending.push_back(pe);
-  }
-};
-
 template <bool STRICT>
 static int launch_generic(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
@@ -308,133 +221,63 @@ static int launch_generic(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
-// Size-specialised launch sequence. Levels below J: one separator + one Schur launch each.
-// Levels J..K-1 ("boundary-first"): separator + Schur on the two boundary knots of every subtree
-// (tiny grids), then ONE apply_small pass that takes every knot through all those levels in
-// registers. J = K disables the second form (pure level-by-level streaming).
-template <int NX, int NU, bool STRICT, bool KEEP, int JB>
-static void launch_bottom(NdlqrHipCtx* c, bool lean) {
-  const ndlqr::Dims& d = c->d;
-  ScopedSlot t(c, SLOT_BOTTOM);
-  const size_t pad = getenv("NDLQR_BOTTOM_LDS_PAD") ? (size_t)atoi(getenv("NDLQR_BOTTOM_LDS_PAD")) : 0;  // occupancy experiments
-  hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), pad,
-                     c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0,
-                     (lean || (KEEP && !STRICT)) ? 1 : 0);
-}
+// ---- size-specialised instances: one translation unit each (small_instance.hip), listed in
+//      small_instances.def
+#define NDLQR_SMALL_INSTANCE(NX_, NU_)                                              \
+  int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep, int J); \
+  void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c);                               \
+  int ndlqr_small_kpb_##NX_##_##NU_(void);
+#include "small_instances.def"
+#undef NDLQR_SMALL_INSTANCE
 
-template <int NX, int NU, bool STRICT, bool KEEP>
-static int launch_small(NdlqrHipCtx* c, int J) {
-  const ndlqr::Dims& d = c->d;
-  using Sh = ndlqr::SchurShape<NX, NU>;
-  // leaf + levels 0..JB-1 fused on chip when the horizon is long enough, else the leaf kernel
-  int JB = c->bottom_levels;
-  if (JB > 3) JB = 3;
-  while (JB > 0 && d.K <= JB) --JB;
-  if (JB > J) JB = J;
-  // fast mode without KEEP: solution by back-substitution from the separator records (needs the
-  // boundary-first schedule right after the bottom kernel, so that no level reads interior knots)
-  const bool lean = !STRICT && !KEEP && JB >= J && JB >= 1 && JB < d.K && c->upper_mode != 0 &&
-                    (d.K + 4) * NX <= 256 && !c->no_backsub;
-  switch (JB) {
-    case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c, lean); break;
-    case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c, lean); break;
-    case 1: launch_bottom<NX, NU, STRICT, KEEP, 1>(c, lean); break;
-    default: {
-      ScopedSlot t(c, SLOT_LEAF);
-      hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
-                         c->AB, c->QR, c->rhs, c->F, c->z, c->info);
-    }
-  }
-  if (JB >= J && JB >= 1 && JB < d.K && c->upper_mode == 1) {
-    // no full-level Schur pass left: separator + boundary update of a level in one launch
-    for (int l = JB; l < d.K; ++l) {
-      ScopedSlot t(c, SLOT_UPPER);
-      hipLaunchKernelGGL((ndlqr::level_small<NX, NU, STRICT, KEEP>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0,
-                         c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
-    }
-  } else if (JB >= J && JB >= 1 && JB < d.K && c->upper_mode == 2) {
-    // no full-level Schur pass left: all remaining levels of a problem in one launch
-    ScopedSlot t(c, SLOT_UPPER);
-    auto kern = ndlqr::upper_small<NX, NU, STRICT, KEEP>;
-    int nw = 8;
-    while (nw > 1 && nw / 2 >= (d.N >> (JB + 1))) nw /= 2;  // not more wavefronts than subtrees
-    const size_t lds = (size_t)nw * (sizeof(ndlqr::SepIn<NX, NU>) + sizeof(ndlqr::SepOut<NX>));
-    if (lds > 64 * 1024 && c->big_lds_kernel != reinterpret_cast<const void*>(kern)) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-      c->big_lds_kernel = reinterpret_cast<const void*>(kern);
-    }
-    hipLaunchKernelGGL(kern, dim3(d.batch), dim3(64 * nw), lds, c->stream, d, JB, c->AB, c->F, c->z, c->rec,
-                       c->info);
-  } else
-  for (int l = JB; l < d.K; ++l) {
-    {
-      ScopedSlot t(c, SLOT_SEP);
-      const int nsep = d.N >> (l + 1);
-      hipLaunchKernelGGL((ndlqr::separator_one<NX, NU, STRICT, KEEP>), dim3(nsep, d.batch), dim3(64), 0, c->stream,
-                         d, l, c->AB, c->F, c->z, c->rec, c->info);
-    }
-    if (l < J) {
-      ScopedSlot t(c, SLOT_SCHUR);
-      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT, false>), dim3(d.N / Sh::KPB, d.batch), dim3(256),
-                         0, c->stream, d, l, c->F, c->z, c->rec);
-    } else if (l < d.K - 1) {
-      ScopedSlot t(c, SLOT_BOUNDARY);
-      const int nsub = d.N >> (l + 1);
-      hipLaunchKernelGGL((ndlqr::schur_small<NX, NU, STRICT, true>),
-                         dim3((nsub + Sh::WAVES - 1) / Sh::WAVES, d.batch), dim3(256), 0, c->stream, d, l,
-                         c->F, c->z, c->rec);
-    }
-  }
-  if (lean) {
-    ScopedSlot t(c, SLOT_APPLY);
-    if constexpr (!STRICT && !KEEP)
-      hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
-                         c->QR, c->rhs, c->rec, c->z);
-    return NDLQR_OK;
-  }
-  if (J < d.K) {
-    ScopedSlot t(c, SLOT_APPLY);
-    if constexpr (!STRICT && !KEEP) {
-      // only the solution is wanted: two dot products per knot row against the top-down vectors w
-      if (J >= 2 && !c->no_finish) {
-        const size_t lds = sizeof(double) * (size_t)(d.K - J) * (Sh::REC + 2 * 2 * NX);
-        hipLaunchKernelGGL((ndlqr::finish_small<NX, NU>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds, c->stream,
-                           d, J, c->F, c->z, c->rec);
-        return NDLQR_OK;
-      }
-    }
-    const size_t lds = sizeof(double) * (size_t)(d.K - J) * Sh::REC;
-    hipLaunchKernelGGL((ndlqr::apply_small<NX, NU, STRICT, KEEP>), dim3(d.N / Sh::KPB, d.batch), dim3(256), lds,
-                       c->stream, d, J, c->F, c->z, c->rec);
-  }
-  return NDLQR_OK;
+struct SmallInstance {
+  int nx, nu;
+  int (*solve)(NdlqrHipCtx*, bool, bool, int);
+  void (*rhs)(NdlqrHipCtx*);
+  int (*kpb)(void);
+};
+#ifdef NDLQR_SINGLE_TU
+#define NDLQR_SMALL_INSTANCE(NX_, NU_)                                                              \
+  int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep, int J) {              \
+    if (strict) return keep ? launch_small<NX_, NU_, true, true>(c, J) : launch_small<NX_, NU_, true, false>(c, J); \
+    return keep ? launch_small<NX_, NU_, false, true>(c, J) : launch_small<NX_, NU_, false, false>(c, J);           \
+  }                                                                                                 \
+  void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c) { launch_rhs_records<NX_, NU_>(c); }           \
+  int ndlqr_small_kpb_##NX_##_##NU_(void) { return ndlqr::SchurShape<NX_, NU_>::KPB; }
+#include "small_instances.def"
+#undef NDLQR_SMALL_INSTANCE
+#endif
+
+static const SmallInstance kSmallInstances[] = {
+#define NDLQR_SMALL_INSTANCE(NX_, NU_) \
+  {NX_, NU_, ndlqr_small_solve_##NX_##_##NU_, ndlqr_small_rhs_##NX_##_##NU_, ndlqr_small_kpb_##NX_##_##NU_},
+#include "small_instances.def"
+#undef NDLQR_SMALL_INSTANCE
+};
+
+static const SmallInstance* find_small(const ndlqr::Dims& d) {
+  for (const SmallInstance& s : kSmallInstances)
+    if (s.nx == d.n && s.nu == d.m) return &s;
+  return nullptr;
 }
 
 // returns true when (n, m, N) has a size-specialised instance and it was launched
 static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
   const ndlqr::Dims& d = c->d;
+  const SmallInstance* inst = find_small(d);
+  if (!inst) return false;
+  const int kpb = inst->kpb();
+  if (d.N < kpb) return false;
   const bool keep = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0;
-#define NDLQR_SMALL_CASE(NX_, NU_)                                                                  \
-  if (d.n == NX_ && d.m == NU_ && d.N >= ndlqr::SchurShape<NX_, NU_>::KPB) {                        \
-    /* apply_small needs all KPB knots of a workgroup inside one level-J subtree: 2^(J+1) >= KPB */ \
-    int Jmin = 0;                                                                                   \
-    while ((2 << Jmin) < ndlqr::SchurShape<NX_, NU_>::KPB) ++Jmin;                                  \
-    int J = c->fuse_level >= 0 ? c->fuse_level : 2;                                                 \
-    if (J < Jmin) J = Jmin;                                                                         \
-    if (J > d.K) J = d.K;                                                                           \
-    if (strict) *err = keep ? launch_small<NX_, NU_, true, true>(c, J) : launch_small<NX_, NU_, true, false>(c, J);   \
-    else        *err = keep ? launch_small<NX_, NU_, false, true>(c, J) : launch_small<NX_, NU_, false, false>(c, J); \
-    c->rec_complete = !strict && keep; /* every separator's record f_a | f_bb | z_sep is in rec */ \
-    return true;                                                                                    \
-  }
-  NDLQR_SMALL_CASE(12, 4)  // quadrotor-sized headline shape
-  NDLQR_SMALL_CASE(6, 3)   // the reference's fixtures
-  NDLQR_SMALL_CASE(13, 4)  // quaternion quadrotor
-  NDLQR_SMALL_CASE(8, 4)
-  NDLQR_SMALL_CASE(4, 2)
-#undef NDLQR_SMALL_CASE
-  return false;
+  // apply_small needs all KPB knots of a workgroup inside one level-J subtree: 2^(J+1) >= KPB
+  int Jmin = 0;
+  while ((2 << Jmin) < kpb) ++Jmin;
+  int J = c->fuse_level >= 0 ? c->fuse_level : 2;
+  if (J < Jmin) J = Jmin;
+  if (J > d.K) J = d.K;
+  *err = inst->solve(c, strict, keep, J);
+  c->rec_complete = !strict && keep;  // every separator's record f_a | f_bb | z_sep is in rec
+  return true;
 }
 
 // Enqueue leaf/bottom + per-level + apply launches on the context's stream.
@@ -519,42 +362,14 @@ static void launch_rhs_sweep(NdlqrHipCtx* c) {
   }
 }
 
-// Record-based re-solve (fast mode, specialised sizes): forward pass over the separators, then
-// the same back-substitution as the full solve. Returns false when the shape has no instance.
-template <int NX, int NU>
-static void launch_rhs_records(NdlqrHipCtx* c) {
-  const ndlqr::Dims& d = c->d;
-  {
-    ScopedSlot t(c, SLOT_SEP);
-    hipLaunchKernelGGL((ndlqr::rhs_forward_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(64), 0, c->stream, d, c->AB,
-                       c->QR, c->rhs, c->F, c->rec, c->z);
-  }
-  if (d.K > 3) {
-    ScopedSlot t(c, SLOT_UPPER);
-    const size_t lds = sizeof(double) * (size_t)(d.N / 8) * NX;
-    hipLaunchKernelGGL((ndlqr::rhs_forward_upper<NX, NU>), dim3(d.batch), dim3(512), lds, c->stream, d, c->AB, c->QR,
-                       c->rhs, c->F, c->rec, c->z);
-  }
-  {
-    ScopedSlot t(c, SLOT_APPLY);
-    hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
-                       c->QR, c->rhs, c->rec, c->z);
-  }
-}
-
 static bool try_launch_rhs_records(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   if (!c->rec_complete || (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_GENERIC)) || c->no_backsub) return false;
   if (d.N < 8 || (size_t)(d.N / 8) * d.n * sizeof(double) > 60 * 1024) return false;
-#define NDLQR_RHS_CASE(NX_, NU_)                                                  \
-  if (d.n == NX_ && d.m == NU_ && (d.K + 4) * NX_ <= 256) { launch_rhs_records<NX_, NU_>(c); return true; }
-  NDLQR_RHS_CASE(12, 4)
-  NDLQR_RHS_CASE(6, 3)
-  NDLQR_RHS_CASE(13, 4)
-  NDLQR_RHS_CASE(8, 4)
-  NDLQR_RHS_CASE(4, 2)
-#undef NDLQR_RHS_CASE
-  return false;
+  const SmallInstance* inst = find_small(d);
+  if (!inst || (d.K + 4) * inst->nx > 256) return false;
+  inst->rhs(c);
+  return true;
 }
 
 int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {

@@ -1,0 +1,28 @@
+// small_instance.hip -- one size-specialised instance of the kernels in kernels_small.hpp.
+// Compiled once per line of small_instances.def with -DNDLQR_INST_NX=<nstates>
+// -DNDLQR_INST_NU=<ninputs>; exports the two entry points ndlqr_hip.hip dispatches to:
+//   ndlqr_small_solve_<nx>_<nu>(ctx, strict, keep, J)   factor + solve launch sequence
+//   ndlqr_small_rhs_<nx>_<nu>(ctx)                      record-based right-hand-side re-solve
+//   ndlqr_small_kpb_<nx>_<nu>()                         knots per workgroup of its Schur kernels
+#include "launch_small.hpp"
+
+#if !defined(NDLQR_INST_NX) || !defined(NDLQR_INST_NU)
+#error "compile with -DNDLQR_INST_NX=... -DNDLQR_INST_NU=..."
+#endif
+
+#define NDLQR_PASTE_(prefix, a, b) prefix##a##_##b
+#define NDLQR_PASTE(prefix, a, b) NDLQR_PASTE_(prefix, a, b)
+#define NDLQR_INST_NAME(prefix) NDLQR_PASTE(prefix, NDLQR_INST_NX, NDLQR_INST_NU)
+
+namespace {
+constexpr int NX = NDLQR_INST_NX, NU = NDLQR_INST_NU;
+}
+
+int NDLQR_INST_NAME(ndlqr_small_solve_)(NdlqrHipCtx* c, bool strict, bool keep, int J) {
+  if (strict) return keep ? launch_small<NX, NU, true, true>(c, J) : launch_small<NX, NU, true, false>(c, J);
+  return keep ? launch_small<NX, NU, false, true>(c, J) : launch_small<NX, NU, false, false>(c, J);
+}
+
+void NDLQR_INST_NAME(ndlqr_small_rhs_)(NdlqrHipCtx* c) { launch_rhs_records<NX, NU>(c); }
+
+int NDLQR_INST_NAME(ndlqr_small_kpb_)(void) { return ndlqr::SchurShape<NX, NU>::KPB; }

@@ -34,7 +34,7 @@ def stack(probs):
 
 
 SHAPES = [(6, 3, 8), (6, 3, 16), (6, 3, 64), (12, 4, 8), (12, 4, 16), (12, 4, 64), (5, 2, 32), (16, 8, 8),
-          (13, 4, 32), (8, 4, 64), (4, 2, 128),
+          (13, 4, 32), (8, 4, 64), (4, 2, 128), (10, 4, 32), (9, 3, 16), (4, 1, 64), (2, 1, 16), (5, 2, 8),
           (3, 1, 2), (1, 1, 4), (7, 9, 16)]
 
 
@@ -234,7 +234,8 @@ def test_env_variants_fast_mode(ndlqr, oracle):
 
 
 @pytest.mark.parametrize("n,m,N", [(12, 4, 64), (6, 3, 32), (5, 2, 16), (32, 16, 16), (12, 4, 8), (12, 4, 16),
-                                   (12, 4, 256), (12, 4, 1024), (13, 4, 64), (4, 2, 128), (8, 4, 32), (6, 3, 4)])
+                                   (12, 4, 256), (12, 4, 1024), (13, 4, 64), (4, 2, 128), (8, 4, 32), (6, 3, 4),
+                                   (10, 4, 32), (9, 3, 64), (4, 1, 16), (2, 1, 128)])
 @pytest.mark.parametrize("strict", [True, False])
 def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
     """Factor once (KEEP_FACT), then new q, r, d, x0 through the rhs-only sweep: must equal a full

@@ -34,9 +34,10 @@ def build():
     objs = [os.path.join(b.OBJDIR, s + ".o") for s in b.C_SOURCES]
     o = os.path.join(b.OBJDIR, "ndlqr_hip_seg.o")
     hipcc = b._hipcc()
+    # one translation unit with every instance (the counters are one __device__ array per unit)
     subprocess.run([hipcc, "--offload-arch=" + b.ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC",
-                    "-DNDLQR_SEGTIME", "-I" + b.INCLUDE, "-I" + b.CSRC, "-c",
-                    os.path.join(b.CSRC, "ndlqr_hip.hip"), "-o", o], check=True)
+                    "-DNDLQR_SEGTIME", "-DNDLQR_SINGLE_TU", "-I" + b.INCLUDE, "-I" + b.CSRC, "-c",
+                    os.path.join(b.CSRC, b.HIP_MAIN), "-o", o], check=True)
     subprocess.run([hipcc, "--offload-arch=" + b.ARCH, "-shared", "-fPIC", "-o", SEGLIB] + objs + [o, "-lm"],
                    check=True)
     print("built", SEGLIB)
