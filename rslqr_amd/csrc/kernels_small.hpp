@@ -272,12 +272,12 @@ __device__ __forceinline__ void row_update(double (&E)[NX], double (&Ca)[NX], do
                                            const double* fa, const double* fb, const double* zsp,
                                            const int zstride, const bool has_a, const bool has_b,
                                            const bool left, const bool active) {
+  // The column that gets created this level (Ca of a right-half knot, Cb of a left-half knot)
+  // is zero on entry: the leaf phase, rotate_roles and the loads at lstart leave it so -- no
+  // select needed. `left` only documents which one that is.
+  (void)left;
 #pragma unroll
-  for (int c = 0; c < NX; ++c) {
-    E[c] = active ? E[c] : 0.0;
-    Ca[c] = left ? Ca[c] : 0.0;   // the column a right-half knot gets created this level
-    Cb[c] = left ? 0.0 : Cb[c];   // the column a left-half knot gets created this level
-  }
+  for (int c = 0; c < NX; ++c) E[c] = active ? E[c] : 0.0;
   if (has_a) {
 #pragma unroll
     for (int k = 0; k < NX; ++k)
