@@ -145,3 +145,21 @@ def test_c_example_compiles_and_runs(ndlqr, tmp_path):
         out = subprocess.run([exe, os.path.join(GOLDEN, fname)], check=True, capture_output=True, text=True).stdout
         line = [l for l in out.splitlines() if "||x - soln||_2" in l][0]
         assert float(line.split("=")[1].split()[0]) < tol, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [[], ["6", "3", "32", "5", "3"], ["7", "2", "16", "4", "2"]])
+def test_mpc_batch_example(ndlqr, tmp_path, args):
+    """examples/mpc_batch.c: factor once, re-solve for new right-hand sides, device-side KKT check
+    of every problem after every solve (specialised and generic shapes)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mpc_batch")
+    libdir = os.path.dirname(ndlqr.library_path())
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "mpc_batch.c"), "-L" + libdir, "-lrslqr_amd",
+                    "-Wl,-rpath," + libdir, "-lm", "-o", exe], check=True)
+    out = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("re-solve") >= 2
+
