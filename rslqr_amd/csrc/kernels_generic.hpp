@@ -37,7 +37,7 @@ namespace ndlqr {
 // v_mfma_f64_16x16x4_f64, one 16x16 tile of S-bar / f_a per wavefront.
 template <bool STRICT, bool P1MFMA>
 __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, double* F, double* z,
-                                  int* __restrict__ info) {
+                                  int* __restrict__ info, double* __restrict__ rec) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = d.n, m = d.m, w = d.w, N = d.N;
   const int b = blockIdx.y;
@@ -257,6 +257,17 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       if (outb) outb[i * n + c] = X[i * xs + n + c];
     }
   for (int i = threadIdx.x; i < n; i += blockDim.x) zs1[i] = X[i * xs + 2 * n];
+  if (rec) {
+    // record f_a | f_bb | z_sep for the back-substitution (backsub_*_generic): the lambda rows of
+    // knot s+1 written above are updated again by later levels when that knot is a boundary knot
+    double* myrec = rec + ((size_t)b * d.N + s) * (2 * n * n + n);
+    for (int i = wave; i < n; i += nwave)
+      for (int c = lane; c < n; c += 64) {
+        if (a >= 0) myrec[i * n + c] = X[i * xs + c];
+        if (bb >= 0) myrec[n * n + i * n + c] = X[i * xs + n + c];
+      }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) myrec[2 * n * n + i] = X[i * xs + 2 * n];
+  }
 }
 
 // ------------------------------------------------------------------------------------- Schur update
@@ -264,14 +275,19 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
 //   g(i, p) -= E(i) * f_p   for the live outer columns p in {a, bb}, and the rhs (c == 0).
 // Left-half knots own column a already (read-modify-write) and get column bb created
 // (written, not accumulated); right-half knots the other way round.
+// boundary != 0: only the first and the last knot of every level-l subtree (what the next
+// separators read; the other knots get their solution from the back-substitution): the grid
+// then covers 2 * (N >> (l+1)) knots.
 template <bool STRICT>
-__global__ void schur_generic(Dims d, int l, double* F, double* z) {
+__global__ void schur_generic(Dims d, int l, double* F, double* z, int boundary) {
   const int n = d.n, rows = d.rows, N = d.N;
   const int b = blockIdx.y;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long)N * rows * n) return;
-  const int i = (int)(e / (rows * n));
-  const int rem = (int)(e - (long)i * rows * n);
+  const int nknots = boundary ? 2 * (N >> (l + 1)) : N;
+  if (e >= (long)nknots * rows * n) return;
+  const int ik = (int)(e / (rows * n));
+  const int i = boundary ? (ik >> 1) * (2 << l) + ((ik & 1) ? (2 << l) - 1 : 0) : ik;
+  const int rem = (int)(e - (long)ik * rows * n);
   const int r = rem / n, c = rem - r * n;
   const int half = 1 << l;
   const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
@@ -447,6 +463,57 @@ __global__ void rhs_update_generic(Dims d, int l, const double* __restrict__ F, 
     for (int k = 0; k < n; ++k) acc = mad<STRICT>(-Erow[k], zsep[k], acc);
   }
   *g = acc;
+}
+
+// ------------------------------------------------------------------------------------- back-substitution
+// Runtime-sized form of backsub_small (kernels_small.hpp): multipliers level by level, top-down,
+//   y_s = z_sep(s) - f_a(s) y_A - f_bb(s) y_B     (record of s; y_A, y_B final in z(A+1), z(B+1))
+// written to the lambda rows of knot s+1, then states and inputs of every knot from the problem
+// data. Fast mode without KEEP: the Schur passes then only touch the boundary knots.
+//   multipliers: grid (ceil((N >> (l+1)) * n / 256), batch), block 256, once per level K-1 .. 0
+//   states:      grid (ceil(N * rows / 256), batch), block 256
+static __global__ void backsub_multipliers_generic(Dims d, int l, const double* __restrict__ recs, double* z) {
+  const int n = d.n, rows = d.rows, N = d.N, b = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (N >> (l + 1)) * n) return;
+  const int q = e / n, r = e - q * n;
+  const int T = 2 << l, base = q * T, s = base + (1 << l) - 1;
+  const double* rc = recs + ((size_t)b * N + s) * (2 * n * n + n);
+  double acc = rc[2 * n * n + r];
+  if (base > 0) {
+    const double* f = rc + (size_t)r * n;
+    const double* y = z + ((size_t)b * N + base) * rows;  // y_A lives in the lambda rows of knot A+1 = base
+    for (int c = 0; c < n; ++c) acc = fma(-f[c], y[c], acc);
+  }
+  if (base + T < N) {
+    const double* f = rc + (size_t)n * n + (size_t)r * n;
+    const double* y = z + ((size_t)b * N + base + T) * rows;
+    for (int c = 0; c < n; ++c) acc = fma(-f[c], y[c], acc);
+  }
+  z[((size_t)b * N + s + 1) * rows + r] = acc;
+}
+
+static __global__ void backsub_states_generic(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+                                              const double* __restrict__ rhs, double* z) {
+  const int n = d.n, rows = d.rows, w = d.w, N = d.N, b = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * rows) return;
+  const int k = e / rows, r = e - k * rows;
+  if (r < n && k > 0) return;  // lambda rows of knots >= 1 are the multipliers already
+  const double* r0 = rhs + ((size_t)b * N + k) * rows;
+  const double* qr = QR + ((size_t)b * N + k) * w;
+  const double* ab = AB + ((size_t)b * N + k) * n * w;
+  double* zk = z + ((size_t)b * N + k) * rows;
+  const double* yk = zk + rows;  // y_k: lambda rows of knot k+1
+  const int col = r < n ? r : r - n;  // column of [A_k | B_k] this row meets
+  double dot = 0.0;
+  if (k < N - 1 && !(k == 0 && r >= n && r < 2 * n))
+    for (int c = 0; c < n; ++c) dot = fma(ab[(size_t)c * w + col], yk[c], dot);
+  double out;
+  if (r < n) out = fma(-qr[r], r0[r], -r0[n + r]) + dot;                               // knot 0: Q x0 + q + A_0' y_0
+  else if (r < 2 * n) out = (k == 0) ? -r0[r - n] : (r0[r] - dot + zk[r - n]) / qr[r - n];  // x_k (zk[.] = y_{k-1})
+  else out = (k == N - 1) ? r0[r] : (r0[r] - dot) / qr[r - n];                          // u_k
+  zk[r] = out;
 }
 
 // ------------------------------------------------------------------------------------- KKT residual

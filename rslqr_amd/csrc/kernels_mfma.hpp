@@ -17,14 +17,17 @@ namespace ndlqr {
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 
 // One workgroup (4 wavefronts) per knot; row tiles of 16 rows are dealt to the wavefronts.
-//   NB = nstates / 16. grid (N, batch), block 256, dynamic LDS = n * (n + 16) doubles.
+//   NB = nstates / 16. grid (N, batch) -- or (2 * (N >> (l+1)), batch) in boundary mode --, block 256,
+//   dynamic LDS = n * (n + 16) doubles.
 template <int NB>
-__global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, double* z) {
+__global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, double* z, int boundary) {
   constexpr int NX = 16 * NB, KS = NX / 4;
   // LDS row length with 2 * LDSW = 32 (mod 64) dwords: the two k-rows a 32-lane group reads hit disjoint banks
   constexpr int LDSW = (NX % 32 == 16) ? NX : NX + 16;
   extern __shared__ __attribute__((aligned(16))) double fl[];
-  const int N = d.N, rows = d.rows, b = blockIdx.y, i = blockIdx.x;
+  // boundary != 0: grid.x = 2 * (N >> (l+1)), first and last knot of every level-l subtree only
+  const int N = d.N, rows = d.rows, b = blockIdx.y;
+  const int i = boundary ? (blockIdx.x >> 1) * (2 << l) + ((blockIdx.x & 1) ? (2 << l) - 1 : 0) : blockIdx.x;
   const int half = 1 << l;
   const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
   int a, bb;

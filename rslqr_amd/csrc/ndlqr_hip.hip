@@ -172,9 +172,12 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
 
 // ------------------------------------------------------------------------------ launches
 
+// lean (fast mode without KEEP): the Schur passes only keep the boundary knots of every subtree
+// up to date, the solution comes from the back-substitution over the separator records.
 template <bool STRICT>
-static int launch_generic(NdlqrHipCtx* c) {
+static int launch_generic(NdlqrHipCtx* c, bool lean) {
   const ndlqr::Dims& d = c->d;
+  double* rec = lean ? c->rec : nullptr;
   {
     ScopedSlot t(c, SLOT_LEAF);
     hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
@@ -193,30 +196,44 @@ static int launch_generic(NdlqrHipCtx* c) {
       const bool p1mfma = !STRICT && d.n % 16 == 0 && d.w % 4 == 0 && !c->no_mfma;
       if (p1mfma)
         hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, true>), dim3(nsub, d.batch), dim3(256), lds,
-                           c->stream, d, l, c->AB, c->F, c->z, c->info);
+                           c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
       else
         hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, false>), dim3(nsub, d.batch), dim3(256), lds,
-                           c->stream, d, l, c->AB, c->F, c->z, c->info);
+                           c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
     }
+    if (lean && l == d.K - 1) break;  // nothing above the root separator
     {
-      ScopedSlot t(c, SLOT_SCHUR);
+      ScopedSlot t(c, lean ? SLOT_BOUNDARY : SLOT_SCHUR);
+      const int bnd = lean ? 1 : 0;
+      const unsigned gx = lean ? 2u * (unsigned)nsub : (unsigned)d.N;  // knots this pass updates
       // block sizes that fill 16x16 MFMA tiles: Schur update on the fp64 matrix cores (fast mode)
       const bool mfma = !STRICT && d.n % 16 == 0 && d.rows % 16 == 0 && d.n <= 64 && !c->no_mfma;
       const size_t flds = sizeof(double) * (size_t)d.n * (d.n + 16);
       if (mfma && d.n == 64)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<4>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<4>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
       else if (mfma && d.n == 48)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<3>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<3>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
       else if (mfma && d.n == 32)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<2>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<2>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
       else if (mfma && d.n == 16)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<1>), dim3(d.N, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<1>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
       else {
-        const long work = (long)d.N * d.rows * d.n;
+        const long work = (long)gx * d.rows * d.n;
         hipLaunchKernelGGL((ndlqr::schur_generic<STRICT>), dim3((unsigned)((work + 255) / 256), d.batch),
-                           dim3(256), 0, c->stream, d, l, c->F, c->z);
+                           dim3(256), 0, c->stream, d, l, c->F, c->z, bnd);
       }
     }
+  }
+  if (lean) {
+    ScopedSlot t(c, SLOT_APPLY);
+    for (int l = d.K - 1; l >= 0; --l) {
+      const int work = (d.N >> (l + 1)) * d.n;
+      hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3((work + 255) / 256, d.batch), dim3(256), 0, c->stream,
+                         d, l, c->rec, c->z);
+    }
+    const int work = d.N * d.rows;
+    hipLaunchKernelGGL(ndlqr::backsub_states_generic, dim3((work + 255) / 256, d.batch), dim3(256), 0, c->stream, d,
+                       c->AB, c->QR, c->rhs, c->z);
   }
   return NDLQR_OK;
 }
@@ -289,7 +306,10 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   bool done = false;
   c->rec_complete = false;
   if (!(c->flags & NDLQR_FLAG_GENERIC)) done = try_launch_small(c, strict, &err);
-  if (!done) err = strict ? launch_generic<true>(c) : launch_generic<false>(c);
+  if (!done) {
+    const bool lean = !strict && !(c->flags & NDLQR_FLAG_KEEP_FACT) && !c->no_backsub;
+    err = strict ? launch_generic<true>(c, false) : launch_generic<false>(c, lean);
+  }
   return err;
 }
 
@@ -325,7 +345,9 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->timing_pending = true;
-  c->fact_valid = (c->flags & (NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_GENERIC)) != 0;
+  // a complete factor array is on the device with KEEP, and on the strict runtime-sized path
+  c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 ||
+                  ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
   return NDLQR_OK;
 }
 
@@ -489,7 +511,7 @@ int ndlqr_hip_set_bottom_levels(NdlqrHipCtx* c, int JB) {
 
 int ndlqr_hip_download_factors(NdlqrHipCtx* c, int p, double* fact) {
   if (!c || !fact || p < 0 || p >= c->d.batch) return NDLQR_ERR_INVALID;
-  if (!(c->flags & (NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_GENERIC))) {
+  if (!c->fact_valid) {
     g_last_error = "factor download needs NDLQR_FLAG_KEEP_FACT set before the solve";
     fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
     return NDLQR_ERR_INVALID;

@@ -87,10 +87,7 @@ def test_batch_fast_within_tolerance(ndlqr, oracle, n, m, N, flags):
     assert bs.solve() == 0
     assert np.array_equal(bs.solutions(), sol)
     with pytest.raises(RuntimeError):  # factors are only materialised with NDLQR_FLAG_KEEP_FACT
-        if flags != "generic":
-            bs.factors(0)
-        else:
-            raise RuntimeError("generic path always keeps the factors")
+        bs.factors(0)
     bs.close()
 
 
@@ -157,8 +154,11 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
     kernels; where the blocks fill 16x16 tiles the fast mode puts the Schur update on
     v_mfma_f64_16x16x4_f64 (kernels_mfma.hpp). Strict mode bit-exact, fast mode within tolerance."""
     probs = [synth(ndlqr, n, m, N, 900 + p) for p in range(batch)]
-    for strict in (True, False):
-        bs = ndlqr.BatchSolver(n, m, N, batch, flags=(ndlqr.FLAG_STRICT_FP if strict else 0) | ndlqr.FLAG_KEEP_FACT)
+    # strict + KEEP, fast + KEEP (full Schur passes), fast without KEEP (boundary knots only +
+    # back-substitution over the separator records)
+    for strict, keep in ((True, True), (False, True), (False, False)):
+        bs = ndlqr.BatchSolver(n, m, N, batch, flags=(ndlqr.FLAG_STRICT_FP if strict else 0) |
+                               (ndlqr.FLAG_KEEP_FACT if keep else 0))
         bs.initialize_flat(*stack(probs))
         assert bs.solve() == 0
         sol = bs.solutions()
@@ -170,6 +170,8 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
                 assert np.array_equal(bs.factors(p), fact)
             else:
                 assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+                ok, detail = _kkt_ok(oracle, prob, sol[p])
+                assert ok, detail
         bs.close()
 
 
@@ -381,6 +383,13 @@ def test_short_horizons_specialised_shapes(ndlqr, oracle, n, m, N):
         z, fact, _, _ = oracle.solve(prob, 1, want_fact=True)
         assert np.array_equal(bs.solution(p), z[: prob.nvars])
         assert np.array_equal(bs.factors(p), fact)
+    bs.close()
+    bs = ndlqr.BatchSolver(n, m, N, 4)  # fast mode, solution only
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0
+    for p, prob in enumerate(probs):
+        ref = oracle.solve(prob, 1)[0][: prob.nvars]
+        assert np.linalg.norm(bs.solution(p) - ref) / np.linalg.norm(ref) <= REL_TOL
     bs.close()
 
 
