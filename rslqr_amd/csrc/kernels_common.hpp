@@ -50,6 +50,13 @@ __device__ __forceinline__ void outer_columns(int base, int l, int N, int& a, in
   bb = (base + span < N) ? __builtin_ctz(base + span) : -1;
 }
 
+// value of `v` in lane `src` (src must be wave-uniform): two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // Developer instrumentation (tools/segtime.py; never defined in the shipped build): cycles spent
 // between consecutive marks, summed over lane 0 of every wavefront, per segment id.
 #ifdef NDLQR_SEGTIME

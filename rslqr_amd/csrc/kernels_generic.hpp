@@ -35,6 +35,52 @@ namespace ndlqr {
 // transposed sweep), so the results equal the left-looking / column-by-column reference loops.
 // P1MFMA (fast mode, n a multiple of 16, n+m of 4): the inner products run on
 // v_mfma_f64_16x16x4_f64, one 16x16 tile of S-bar / f_a per wavefront.
+// Fast path of the blocked separator: lower Cholesky of one 16x16 diagonal block AND the inverse
+// of that factor by ONE wavefront in registers (lanes 0..15 own a row, then a column; broadcasts
+// with v_readlane, no barrier). With W = L11^-1 the panel below the block, the block rows of the
+// right-hand sides and their transposed counterparts all become 16x16 matrix-core products, so a
+// 16-column block costs a handful of workgroup barriers instead of three per pivot.
+// Sblk = &S[j0 * ns + j0] (LDS, row pitch ns), Wblk: 16 x 16, row pitch 17 (LDS).
+__device__ __forceinline__ bool chol16_and_inverse(double* Sblk, const int ns, double* Wblk, const int lane) {
+  const int r = lane & 15;
+  double acc[16], rinvs[16], w[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = Sblk[r * ns + c];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v = fma(-acc[k], readlane_f64(acc[k], j), v);
+    acc[j] = v;
+    const double pivot = readlane_f64(acc[j], j);
+    bad = bad || !(pivot > 0.0);
+    const double rinv = rsqrt(pivot);
+    acc[j] = acc[j] * rinv;
+    rinvs[j] = rinv;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c <= r) Sblk[r * ns + c] = acc[c];
+  }
+  // column r of W = L11^-1 by forward substitution on the unit vector e_r
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    double sacc = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < rr; ++k) sacc = fma(-readlane_f64(acc[k], rr), w[k], sacc);
+    w[rr] = sacc * rinvs[rr];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) Wblk[rr * 17 + r] = w[rr];
+  }
+  return bad;
+}
+
 template <bool STRICT, bool P1MFMA>
 __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, double* F, double* z,
                                   int* __restrict__ info, double* __restrict__ rec) {
@@ -118,6 +164,98 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   //      MFMA path: blocked by 16 columns -- the rank-1 updates of a pivot only reach the end of
   //      its 16-column panel, the rest of the lower triangle gets one rank-16 update per panel on
   //      the matrix cores (different summation grouping than the reference: fast mode only).
+  if constexpr (P1MFMA) {
+    // blocked: diagonal block + its inverse in one wavefront, panel and trailing update on the
+    // matrix cores (see chol16_and_inverse)
+    double* Wd = X + (size_t)n * xs;  // n/16 blocks of 16 x 17
+    const int nb = n >> 4;
+    for (int jb = 0; jb < nb; ++jb) {
+      const int j0 = 16 * jb, rem = nb - 1 - jb;
+      if (wave == 0) {
+        const bool bad = chol16_and_inverse(S + j0 * ns + j0, ns, Wd + jb * 16 * 17, lane);
+        if (bad && lane == 0) flag_failure(info, d, b);
+      }
+      __syncthreads();
+      const double* Wb = Wd + jb * 16 * 17;
+      for (int it = jb + 1 + wave; it < nb; it += nwave) {  // L21 = A21 W'
+        acc4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                     Wb[li * 17 + 4 * q + lk], acc, 0, 0, 0);
+        double* Ct = S + (16 * it + lk) * ns + j0 + li;
+        Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+      }
+      __syncthreads();
+      for (int item = wave; item < rem * rem; item += nwave) {  // trailing rank-16 update
+        const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
+        if (ct > it) continue;  // lower triangle of tiles only
+        double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
+        acc4 acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                     S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+      }
+      if (rem > 0) __syncthreads();
+    }
+    // substitutions, block rows at a time: X_blk <- W X_blk, rows below -= L[rows, blk] X_blk;
+    // then X_blk <- W' X_blk, rows above -= L[blk, rows]' X_blk
+    const int ctl = (ncols + 15) / 16;
+    for (int jb = 0; jb < nb; ++jb) {
+      const int j0 = 16 * jb;
+      const double* Wb = Wd + jb * 16 * 17;
+      for (int ct = wave; ct < ctl; ct += nwave) {
+        acc4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[li * 17 + 4 * q + lk],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      __syncthreads();
+      const int rem = nb - 1 - jb;
+      for (int item = wave; item < rem * ctl; item += nwave) {
+        const int it = jb + 1 + item / ctl, ct = item % ctl;
+        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      if (rem > 0) __syncthreads();
+    }
+    for (int jb = nb - 1; jb >= 0; --jb) {
+      const int j0 = 16 * jb;
+      const double* Wb = Wd + jb * 16 * 17;
+      for (int ct = wave; ct < ctl; ct += nwave) {
+        acc4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[(4 * q + lk) * 17 + li],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      __syncthreads();
+      for (int item = wave; item < jb * ctl; item += nwave) {
+        const int it = item / ctl, ct = item % ctl;
+        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(j0 + 4 * q + lk) * ns + 16 * it + li],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      if (jb > 0) __syncthreads();
+    }
+    __syncthreads();
+  } else {
   for (int j = 0; j < n; ++j) {
     const double pivot = S[j * ns + j];
     if (!(pivot > 0.0)) {  // uniform: every thread reads the same LDS word
@@ -245,6 +383,8 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       __syncthreads();
     }
   }
+
+  }  // per-pivot path
 
   // ---- store into the lambda rows of knot s+1 (columns l, a, bb) and of the rhs
   double* outS = Fblk(F, d, b, l, s + 1);

@@ -27,12 +27,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// value of `v` in lane `src` (src must be wave-uniform): two v_readlane_b32
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
 
 // One factor-block row (NX doubles, 16-byte aligned when NX is even) <-> registers, as
 // 16-byte vector accesses (global_load/store_dwordx4).

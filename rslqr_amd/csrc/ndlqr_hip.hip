@@ -184,18 +184,24 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
                        c->AB, c->QR, c->rhs, c->F, c->z, c->info);
   }
   // S (n x (n+1)) + right-hand-side panel (n x pitch; pitch = 2n+1 padded to whole 16-column tiles + 1)
-  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (((2 * d.n + 1 + 15) / 16) * 16 + 1));
+  // (+ on the matrix-core path the inverses of the 16x16 diagonal blocks of the factor, pitch 17)
+  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (((2 * d.n + 1 + 15) / 16) * 16 + 1) +
+                                       (size_t)d.n * 17);
   if (lds > 160 * 1024) {
     g_last_error = "nstates too large for the generic separator kernel's LDS staging";
     return NDLQR_ERR_INVALID;
   }
+  // matrix-core separator: one wavefront per 16x16 tile of the products / updates, so the number of
+  // useful wavefronts grows with (n/16)^2 (measured at n = 64: 256 / 512 / 1024 threads -> 14.6 / 11.5 / 9.9 ms)
+  const int sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS"))
+                          : (d.n >= 64 ? 1024 : (d.n >= 32 ? 512 : 256));
   for (int l = 0; l < d.K; ++l) {
     const int nsub = d.N >> (l + 1);
     {
       ScopedSlot t(c, SLOT_SEP);
       const bool p1mfma = !STRICT && d.n % 16 == 0 && d.w % 4 == 0 && !c->no_mfma;
       if (p1mfma)
-        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, true>), dim3(nsub, d.batch), dim3(256), lds,
+        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, true>), dim3(nsub, d.batch), dim3(sep_threads), lds,
                            c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
       else
         hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, false>), dim3(nsub, d.batch), dim3(256), lds,
