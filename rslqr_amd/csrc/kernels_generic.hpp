@@ -610,27 +610,28 @@ __global__ void rhs_update_generic(Dims d, int l, const double* __restrict__ F, 
 //   y_s = z_sep(s) - f_a(s) y_A - f_bb(s) y_B     (record of s; y_A, y_B final in z(A+1), z(B+1))
 // written to the lambda rows of knot s+1, then states and inputs of every knot from the problem
 // data. Fast mode without KEEP: the Schur passes then only touch the boundary knots.
-//   multipliers: grid (ceil((N >> (l+1)) * n / 256), batch), block 256, once per level K-1 .. 0
+//   multipliers: grid (N >> (l+1), batch), block 64, once per level K-1 .. 0
 //   states:      grid (ceil(N * rows / 256), batch), block 256
 static __global__ void backsub_multipliers_generic(Dims d, int l, const double* __restrict__ recs, double* z) {
-  const int n = d.n, rows = d.rows, N = d.N, b = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (N >> (l + 1)) * n) return;
-  const int q = e / n, r = e - q * n;
-  const int T = 2 << l, base = q * T, s = base + (1 << l) - 1;
+  // one wavefront per separator: lanes walk the columns of a record row (coalesced), the row sum
+  // is a wavefront reduction
+  const int n = d.n, rows = d.rows, N = d.N, b = blockIdx.y, lane = threadIdx.x;
+  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
   const double* rc = recs + ((size_t)b * N + s) * (2 * n * n + n);
-  double acc = rc[2 * n * n + r];
-  if (base > 0) {
-    const double* f = rc + (size_t)r * n;
-    const double* y = z + ((size_t)b * N + base) * rows;  // y_A lives in the lambda rows of knot A+1 = base
-    for (int c = 0; c < n; ++c) acc = fma(-f[c], y[c], acc);
+  const bool hasA = base > 0, hasB = base + T < N;
+  const double* yA = z + ((size_t)b * N + base) * rows;      // y_A lives in the lambda rows of knot A+1 = base
+  const double* yB = z + ((size_t)b * N + base + T) * rows;
+  double* out = z + ((size_t)b * N + s + 1) * rows;
+  for (int r = 0; r < n; ++r) {
+    double part = 0.0;
+    for (int c = lane; c < n; c += 64) {
+      if (hasA) part = fma(rc[(size_t)r * n + c], yA[c], part);
+      if (hasB) part = fma(rc[(size_t)n * n + (size_t)r * n + c], yB[c], part);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) out[r] = rc[2 * n * n + r] - part;
   }
-  if (base + T < N) {
-    const double* f = rc + (size_t)n * n + (size_t)r * n;
-    const double* y = z + ((size_t)b * N + base + T) * rows;
-    for (int c = 0; c < n; ++c) acc = fma(-f[c], y[c], acc);
-  }
-  z[((size_t)b * N + s + 1) * rows + r] = acc;
 }
 
 static __global__ void backsub_states_generic(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,

@@ -233,8 +233,7 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
   if (lean) {
     ScopedSlot t(c, SLOT_APPLY);
     for (int l = d.K - 1; l >= 0; --l) {
-      const int work = (d.N >> (l + 1)) * d.n;
-      hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3((work + 255) / 256, d.batch), dim3(256), 0, c->stream,
+      hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
                          d, l, c->rec, c->z);
     }
     const int work = d.N * d.rows;
