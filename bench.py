@@ -154,8 +154,8 @@ def cpu_baseline(n, m, N, probs, gpu_solutions):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nx", type=int, default=12)
     ap.add_argument("--nu", type=int, default=4)
     ap.add_argument("--horizon", type=int, default=256)

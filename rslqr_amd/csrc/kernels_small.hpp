@@ -288,6 +288,51 @@ __device__ __forceinline__ void row_update(double (&E)[NX], double (&Ca)[NX], do
   for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], zsp[k * zstride], zz);
 }
 
+// The same level step for a row that carries only its LIVE outer column C (column a for a
+// left-half knot, bb for a right-half one) between levels: the other outer column is created
+// here (D, from zero) -- one register array less across the separator than (E, Ca, Cb).
+//   C <- C - E f_live,  D <- -E f_new,  zz <- zz - E z_sep,  then the roles of level l+1:
+//   E <- (left == left child) ? D : C,  C <- the other one.
+// f_live / f_new: f_a / f_bb for a left-half knot, swapped for a right-half one (the pointers may
+// differ between the two knots of a wavefront: two LDS addresses per read, distinct banks).
+template <int NX, int LDF, bool STRICT>
+__device__ __forceinline__ void row_update_live(double (&E)[NX], double (&C)[NX], double& zz,
+                                                const double* f_live, const double* f_new, const double* zsp,
+                                                const bool has_live, const bool has_new, const bool active,
+                                                const bool take_sep, const int r, const bool e_is_created) {
+  double D[NX];
+#pragma unroll
+  for (int c = 0; c < NX; ++c) { E[c] = active ? E[c] : 0.0; D[c] = 0.0; }
+  if (has_live) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) C[c] = mad<STRICT>(-E[k], f_live[k * LDF + c], C[c]);
+  }
+  if (has_new) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) D[c] = mad<STRICT>(-E[k], f_new[k * LDF + c], D[c]);
+  }
+#pragma unroll
+  for (int k = 0; k < NX; ++k) zz = mad<STRICT>(-E[k], zsp[k * LDF], zz);
+  if (take_sep) {  // lambda rows of knot s+1 receive the separator's results (its own panel rows)
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      if (has_live) C[c] = f_live[r * LDF + c];
+      if (has_new) D[c] = f_new[r * LDF + c];
+    }
+    zz = zsp[r * LDF];
+  }
+#pragma unroll
+  for (int c = 0; c < NX; ++c) {
+    const double cn = C[c], dn = D[c];
+    E[c] = e_is_created ? dn : cn;
+    C[c] = e_is_created ? cn : dn;
+  }
+}
+
 // Column roles of level l+1: a left child's right outer column is column l+1 (it becomes E),
 // a right child's left outer column is. `left_child` must be wave-uniform (scalar branch).
 template <int NX>
@@ -1155,8 +1200,10 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
   __syncthreads();
   SEG(20);
 
-  // ---- leaf phase in registers (ndlqr_SolveLeaf): own block O, block P towards the previous knot
-  double E[NX], Ca[NX], Cb[NX], zz;
+  // ---- leaf phase in registers (ndlqr_SolveLeaf): own block O, block P towards the previous knot.
+  //      State of a row between levels: E (column l) and C, its LIVE outer column -- column a for
+  //      a knot in the left half of the next subtree, column bb for one in the right half.
+  double E[NX], C[NX], zz;
   {
     const double* abk = me.ab[has_knot ? kn : 1];
     const bool last = (i == N - 1);
@@ -1186,8 +1233,7 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
       E[c] = even ? O[c] : P[c];
-      Ca[c] = (even && i > 0) ? P[c] : 0.0;
-      Cb[c] = even ? 0.0 : O[c];
+      C[c] = even ? (i > 0 ? P[c] : 0.0) : O[c];  // even knot: left half at level 0 (column a), odd: right (bb)
     }
     if (i == 0) {
       if (lam) zz = mad<STRICT>(-qv_in, rv, -r0[NX + r]);
@@ -1222,14 +1268,14 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     // publish what the separator needs from knots s and s+1
     if (has_knot && i == s && !lam) {
 #pragma unroll
-      for (int c = 0; c < NX; ++c) { xc.Exu[(r - NX) * NX + c] = E[c]; xc.Axu[(r - NX) * NX + c] = Ca[c]; }
+      for (int c = 0; c < NX; ++c) { xc.Exu[(r - NX) * NX + c] = E[c]; xc.Axu[(r - NX) * NX + c] = C[c]; }
       xc.zxu[r - NX] = zz;
     }
     if (has_knot && i == s + 1) {
       if (lam) xc.z1[r] = zz;
       else if (r < 2 * NX) {
 #pragma unroll
-        for (int c = 0; c < NX; ++c) { xc.E1x[(r - NX) * NX + c] = E[c]; xc.B1x[(r - NX) * NX + c] = Cb[c]; }
+        for (int c = 0; c < NX; ++c) { xc.E1x[(r - NX) * NX + c] = E[c]; xc.B1x[(r - NX) * NX + c] = C[c]; }
         xc.z1[NX + (r - NX)] = zz;
       }
     }
@@ -1283,16 +1329,12 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
     const double* fb = sout.X + NX;      // f_bb(k, c) = X[k * LD + NX + c]
     const double* zsp = sout.X + 2 * NX; // z_sep(k)   = X[k * LD + 2 NX]
     if (KEEP && has_knot && active) store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
-    row_update<NX, LD, STRICT>(E, Ca, Cb, zz, fa, fb, zsp, LD, a >= 0, bb >= 0, left, active);
-    if (!active && i == s + 1) {  // lambda rows of knot s+1 receive the separator's results
-#pragma unroll
-      for (int c = 0; c < NX; ++c) {
-        if (a >= 0) Ca[c] = fa[r * LD + c];
-        if (bb >= 0) Cb[c] = fb[r * LD + c];
-      }
-      zz = zsp[r * LD];
+    {
+      const bool leftchild = (base & T) == 0;
+      row_update_live<NX, LD, STRICT>(E, C, zz, left ? fa : fb, left ? fb : fa, zsp, left ? a >= 0 : bb >= 0,
+                                      left ? bb >= 0 : a >= 0, active, !active && i == s + 1, r,
+                                      left == leftchild);
     }
-    rotate_roles<NX>(E, Ca, Cb, (base & T) == 0);
     SEG(25);
     __syncthreads();  // xs / pv are reused by the next level
     SEG(26);
@@ -1315,8 +1357,8 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       // the zeros is harmless and keeps re-solves free of stale data
       store_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
     }
-    if (i <= s) { if (a >= 0) store_row<NX>(Fblk(F, d, b, a, i) + r * NX, Ca); }
-    else        { if (bb >= 0) store_row<NX>(Fblk(F, d, b, bb, i) + r * NX, Cb); }
+    const int cc = (i <= s) ? a : bb;
+    if (cc >= 0) store_row<NX>(Fblk(F, d, b, cc, i) + r * NX, C);
     z[((size_t)b * N + i) * ROWS + r] = zz;
   }
 #ifdef NDLQR_SEGTIME
