@@ -85,17 +85,71 @@ struct alignas(16) SepOut {
 // lanes < NX (KEEPL: entries above the diagonal keep their S-bar values, like the reference's
 // in-place factorisation). Returns true when a pivot was not positive. The caller issues the
 // workgroup barrier that makes the solved panel visible to other wavefronts.
+// Products of the separator on the matrix cores (fast mode, NX <= 16, NX + NU a multiple of 4):
+// [S-bar | rhs_z] = [A_s | B_s] [Exu | zxu] - [E1x | z1], rhs_a = [A_s | B_s] Axu as two 16x16 tiles
+// of v_mfma_f64_16x16x4_f64. fp64 MFMA has no rate advantage on MI355X; what this buys is LDS
+// traffic: every operand element is read once per tile (~45 LDS instructions) instead of once
+// per lane row (~130), and LDS is the busiest pipe of the fused kernel.
+template <int NX, int NU>
+struct P1OnMatrixCores {
+  static constexpr bool value = NX <= 16 && NX % 2 == 0 && (NX + NU) % 4 == 0 && NX + 1 <= 16;
+};
+
 template <int NX, int NU, bool STRICT, bool KEEPL, int SEGB = 0>
 __device__ __forceinline__ bool separator_core(const int lane, const double (&ab)[NX + NU],
                                                const SepIn<NX, NU>& in, SepOut<NX>& out,
-                                               double (&Lrow)[NX]) {
+                                               double (&Lrow)[NX], const double* abmat = nullptr,
+                                               const int abpitch = 0) {
   constexpr int W = NX + NU, LD = SepOut<NX>::LD;
   static_assert(2 * NX + 1 <= SepOut<NX>::NC && 2 * NX <= 64, "panel too narrow");
   const int grp = lane / NX, gi = lane - grp * NX;
   SEG_INIT();
 
-  // P1: row gi of S-bar (group 0) / of f_a (group 1)
   double acc[NX];
+  if constexpr (!STRICT && P1OnMatrixCores<NX, NU>::value) {
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    constexpr int KS = W / 4, SP = NX + 2;  // k-steps; pitch of the transposition scratch
+    const int li = lane & 15, lk = lane >> 4;
+    const int ri = li < NX ? li : NX - 1;  // rows / columns >= NX are padding: any finite data
+    double af[KS], b0[KS], b1[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int k = 4 * q + lk;
+      af[q] = abmat[ri * abpitch + k];
+      b0[q] = li < NX ? in.Exu[k * NX + li] : (li == NX ? in.zxu[k] : 0.0);
+      b1[q] = li < NX ? in.Axu[k * NX + li] : 0.0;
+    }
+    acc4 c0, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+      c0[g] = li < NX ? -in.E1x[ic * NX + ri] : (li == NX ? -in.z1[ic] - in.z1[NX + ic] : 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], b0[q], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], b1[q], c1, 0, 0, 0);
+    }
+    // S-bar goes through a scratch over the consumed operands to get one row per lane; the
+    // right-hand sides go straight to the panel
+    double* scr = const_cast<double*>(in.Exu);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = lk + 4 * g;
+      if (i < NX) {
+        if (li < NX) { scr[i * SP + li] = c0[g]; out.X[i * LD + li] = c1[g]; }
+        else if (li == NX) out.X[i * LD + 2 * NX] = c0[g];
+      }
+    }
+    for (int e = lane; e < NX * NX; e += 64) {
+      const int i = e / NX, j = e - i * NX;
+      out.X[i * LD + NX + j] = -in.B1x[e];  // f_bb = -(state rows of F(s+1, bb))
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = scr[gi * SP + j];
+  } else {
+  // P1: row gi of S-bar (group 0) / of f_a (group 1)
 #pragma unroll
   for (int j = 0; j < NX; ++j) acc[j] = 0.0;
   const double* M = (grp == 1) ? in.Axu : in.Exu;
@@ -118,6 +172,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
       out.X[gi * LD + NX + j] = -in.B1x[gi * NX + j];  // f_bb = -(state rows of F(s+1, bb))
     }
   }
+  }  // vector-ALU products
 
   SEG(SEGB + 1);
   // P2: left-looking Cholesky on the registers of group 0 (every lane runs it; rows of other
@@ -220,7 +275,8 @@ __device__ __forceinline__ void separator_wave(const Dims& d, const int l, const
   wave_lds_sync();
   SEG(0);
   double Lrow[NX];
-  const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, ab, in, out, Lrow);
+  const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, ab, in, out, Lrow,
+                                                       AB + ((size_t)b * N + s) * NX * W, W);
   if (bad && lane == 0) flag_failure(info, d, b);
   SEG(6);  // re-arms the clock after the core's own marks
 
@@ -1300,7 +1356,8 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
           for (int k = 0; k < W; ++k) ab[k] = abs_[k];
         }
       }
-      const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow);
+      const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
+                                                                pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP);
       if (bad && lane == 0) flag_failure(info, d, b);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
       if constexpr (!STRICT) {

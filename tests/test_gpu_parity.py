@@ -395,18 +395,31 @@ def test_short_horizons_specialised_shapes(ndlqr, oracle, n, m, N):
 
 def test_device_side_packing_matches_host_packing(ndlqr):
     """ndlqr_InitializeBatchFlatDevice (pack kernel, inputs already in HBM -- device memory comes
-    from torch here) gives the same bits as the host-packed upload."""
-    import torch
-    n, m, N, batch = 12, 4, 64, 6
-    probs = [synth(ndlqr, n, m, N, 60 + p) for p in range(batch)]
-    flat = stack(probs)
-    host = ndlqr.BatchSolver(n, m, N, batch, device=0)
-    host.initialize_flat(*flat)
-    assert host.solve() == 0
-    dev = ndlqr.BatchSolver(n, m, N, batch, device=0)
-    tens = [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in flat]
-    torch.cuda.synchronize()
-    dev.initialize_flat_device(*[t.data_ptr() for t in tens])
-    assert dev.solve() == 0
-    assert np.array_equal(dev.solutions(), host.solutions())
-    host.close(); dev.close()
+    from torch here) gives the same bits as the host-packed upload. Runs in a fresh process: torch
+    ships its own HIP runtime next to the system one this library links, and which of the two may
+    still open the device depends on what the test process did before."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import rslqr_amd as R
+n, m, N, batch = 12, 4, 64, 6
+gen = [R.generate_synthetic(n, m, N, 60 + p) for p in range(batch)]
+flat = [np.stack([g[k] for g in gen]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
+tens = [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in flat]
+torch.cuda.synchronize()
+host = R.BatchSolver(n, m, N, batch, device=0)
+host.initialize_flat(*flat)
+assert host.solve() == 0
+dev = R.BatchSolver(n, m, N, batch, device=0)
+dev.initialize_flat_device(*[t.data_ptr() for t in tens])
+assert dev.solve() == 0
+assert np.array_equal(dev.solutions(), host.solutions())
+res, bn = dev.kkt_residuals()
+assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+print("DEVICE_PACKING_OK")
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DEVICE_PACKING_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
