@@ -85,14 +85,15 @@ struct alignas(16) SepOut {
 // lanes < NX (KEEPL: entries above the diagonal keep their S-bar values, like the reference's
 // in-place factorisation). Returns true when a pivot was not positive. The caller issues the
 // workgroup barrier that makes the solved panel visible to other wavefronts.
-// Products of the separator on the matrix cores (fast mode, NX <= 16, NX + NU a multiple of 4):
+// Products of the separator on the matrix cores (fast mode, 6 <= NX <= 15; NX + NU is padded
+// with zeros to a multiple of 4):
 // [S-bar | rhs_z] = [A_s | B_s] [Exu | zxu] - [E1x | z1], rhs_a = [A_s | B_s] Axu as two 16x16 tiles
 // of v_mfma_f64_16x16x4_f64. fp64 MFMA has no rate advantage on MI355X; what this buys is LDS
 // traffic: every operand element is read once per tile (~45 LDS instructions) instead of once
 // per lane row (~130), and LDS is the busiest pipe of the fused kernel.
 template <int NX, int NU>
 struct P1OnMatrixCores {
-  static constexpr bool value = NX <= 16 && NX % 2 == 0 && (NX + NU) % 4 == 0 && NX + 1 <= 16;
+  static constexpr bool value = NX >= 6 && NX + 1 <= 16;  // smaller blocks are mostly tile padding
 };
 
 template <int NX, int NU, bool STRICT, bool KEEPL, int SEGB = 0>
@@ -108,16 +109,17 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
   double acc[NX];
   if constexpr (!STRICT && P1OnMatrixCores<NX, NU>::value) {
     typedef double acc4 __attribute__((ext_vector_type(4)));
-    constexpr int KS = W / 4, SP = NX + 2;  // k-steps; pitch of the transposition scratch
+    constexpr int KS = (W + 3) / 4, SP = NX + 2;  // k-steps; pitch of the transposition scratch
     const int li = lane & 15, lk = lane >> 4;
     const int ri = li < NX ? li : NX - 1;  // rows / columns >= NX are padding: any finite data
     double af[KS], b0[KS], b1[KS];
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
-      const int k = 4 * q + lk;
-      af[q] = abmat[ri * abpitch + k];
-      b0[q] = li < NX ? in.Exu[k * NX + li] : (li == NX ? in.zxu[k] : 0.0);
-      b1[q] = li < NX ? in.Axu[k * NX + li] : 0.0;
+      const int kk = 4 * q + lk, k = kk < W ? kk : W - 1;  // k >= W: zero padding of the last step
+      const bool kin = kk < W;
+      af[q] = kin ? abmat[ri * abpitch + k] : 0.0;
+      b0[q] = !kin ? 0.0 : (li < NX ? in.Exu[k * NX + li] : (li == NX ? in.zxu[k] : 0.0));
+      b1[q] = (kin && li < NX) ? in.Axu[k * NX + li] : 0.0;
     }
     acc4 c0, c1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
