@@ -51,6 +51,8 @@ struct NdlqrHipCtx {
                       // launch per level (level_small); 2: all upper levels in one launch (upper_small)
   bool no_backsub;    // NDLQR_NO_BACKSUB=1: fast mode keeps hand-off + finish_small (A/B timing)
   bool no_finish;     // NDLQR_NO_FINISH=1: fast mode keeps apply_small instead of finish_small (A/B timing)
+  int sep_threads;    // NDLQR_SEP_THREADS: workgroup size of the matrix-core separator (0 = by block size)
+  int bottom_lds_pad; // NDLQR_BOTTOM_LDS_PAD: extra dynamic LDS bytes for bottom_small (lowers its occupancy; A/B timing)
   int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
   int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;

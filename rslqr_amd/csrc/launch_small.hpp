@@ -14,7 +14,7 @@ template <int NX, int NU, bool STRICT, bool KEEP, int JB>
 static void launch_bottom(NdlqrHipCtx* c, bool lean) {
   const ndlqr::Dims& d = c->d;
   ScopedSlot t(c, SLOT_BOTTOM);
-  const size_t pad = getenv("NDLQR_BOTTOM_LDS_PAD") ? (size_t)atoi(getenv("NDLQR_BOTTOM_LDS_PAD")) : 0;  // occupancy experiments
+  const size_t pad = (size_t)c->bottom_lds_pad;  // occupancy experiments (NDLQR_BOTTOM_LDS_PAD)
   hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), pad,
                      c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0,
                      (lean || (KEEP && !STRICT)) ? 1 : 0);

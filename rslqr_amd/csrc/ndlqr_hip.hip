@@ -71,6 +71,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->no_finish = getenv("NDLQR_NO_FINISH") != nullptr;
   c->no_backsub = getenv("NDLQR_NO_BACKSUB") != nullptr;
+  c->bottom_lds_pad = getenv("NDLQR_BOTTOM_LDS_PAD") ? atoi(getenv("NDLQR_BOTTOM_LDS_PAD")) : 0;
+  c->sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS")) : 0;
   c->upper_mode = getenv("NDLQR_UPPER") ? atoi(getenv("NDLQR_UPPER")) : 1;
   c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
@@ -193,8 +195,7 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
   }
   // matrix-core separator: one wavefront per 16x16 tile of the products / updates, so the number of
   // useful wavefronts grows with (n/16)^2 (measured at n = 64: 256 / 512 / 1024 threads -> 14.6 / 11.5 / 9.9 ms)
-  const int sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS"))
-                          : (d.n >= 64 ? 1024 : (d.n >= 32 ? 512 : 256));
+  const int sep_threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 64 ? 1024 : (d.n >= 32 ? 512 : 256));
   for (int l = 0; l < d.K; ++l) {
     const int nsub = d.N >> (l + 1);
     {
