@@ -1,6 +1,6 @@
 /*
  * mpc_batch.c -- the batch API in an MPC-style loop: many independent LQR problems factored once
- * on the GPU (NDLQR_FLAG_KEEP_FACT), then re-solved for new right-hand sides (new initial state
+ * on the GPU (NDLQR_FLAG_KEEP_RECORDS / NDLQR_FLAG_KEEP_FACT), then re-solved for new right-hand sides (new initial state
  * and linear cost / dynamics offsets, same A, B, Q, R) without refactoring. Every solution is
  * checked on the device against its raw problem data (KKT residual).
  *
@@ -30,7 +30,9 @@ int main(int argc, char** argv) {
 
   NdLqrBatchSolver* bs = ndlqr_NewBatchSolver(n, m, N, batch, -1);
   if (!bs) { fprintf(stderr, "no solver (is a HIP device visible?)\n"); return 2; }
-  ndlqr_BatchSetFlags(bs, NDLQR_FLAG_KEEP_FACT);
+  /* keep what a re-solve needs: the separator records are enough on size-specialised shapes
+   * (cheaper than the whole factor array); other shapes fall back to NDLQR_FLAG_KEEP_FACT below */
+  ndlqr_BatchSetFlags(bs, NDLQR_FLAG_KEEP_RECORDS);
 
   /* flat host arrays of the whole batch: A [batch][N][n*n] (column-major per knot), B, Q, R, q, r, d, x0 */
   const size_t sA = (size_t)N * n * n, sB = (size_t)N * n * m, sn = (size_t)N * n, sm = (size_t)N * m;
@@ -57,7 +59,13 @@ int main(int argc, char** argv) {
     for (int p = 0; p < batch; ++p)
       memcpy(x0 + (size_t)p * n, soln + (size_t)p * nvars + (2 * n + m) + n, sizeof(double) * n);
     if (ndlqr_BatchSetRhsFlat(bs, q, r, d, x0) != 0) return 7;
-    if (ndlqr_SolveBatchRhsOnly(bs) != 0) return 8;
+    if (ndlqr_SolveBatchRhsOnly(bs) != 0) {
+      if (it > 0) return 8;
+      /* no record-based re-solve for this shape: keep the factor array instead and factor again */
+      ndlqr_BatchSetFlags(bs, NDLQR_FLAG_KEEP_FACT);
+      if (ndlqr_SolveBatch(bs) != 0) return 8;
+      if (ndlqr_SolveBatchRhsOnly(bs) != 0) return 8;
+    }
     const double worst = worst_relative_residual(bs, batch, res, bn);
     printf("re-solve %2d    : %8.3f ms, worst KKT residual %.2e\n", it, ndlqr_BatchSolveTimeMs(bs), worst);
     if (!(worst < 1e-9)) return 9;

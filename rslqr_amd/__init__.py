@@ -9,6 +9,7 @@ from .api import (  # noqa: F401
     BatchSolver,
     FLAG_GENERIC,
     FLAG_KEEP_FACT,
+    FLAG_KEEP_RECORDS,
     FLAG_PROFILE,
     FLAG_STRICT_FP,
     LQRData,

@@ -17,6 +17,7 @@ FLAG_STRICT_FP = 1
 FLAG_GENERIC = 2
 FLAG_PROFILE = 4
 FLAG_KEEP_FACT = 8
+FLAG_KEEP_RECORDS = 16
 
 ERR_INVALID = -1
 ERR_NO_DEVICE = -2
@@ -335,7 +336,8 @@ class BatchSolver:
             raise RuntimeError("ndlqr_BatchSetRhsFlat failed: %d" % err)
 
     def solve_rhs_only(self):
-        """Solution sweep against the cached factorisation (needs FLAG_KEEP_FACT on the solve)."""
+        """Solution sweep against the cached factorisation (needs FLAG_KEEP_FACT, or FLAG_KEEP_RECORDS
+        in fast mode on a size-specialised shape, on the solve)."""
         return self.L.ndlqr_SolveBatchRhsOnly(self.h)
 
     def solve_async(self):

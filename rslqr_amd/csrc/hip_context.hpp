@@ -45,7 +45,8 @@ struct NdlqrHipCtx {
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   int* info;
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
-  bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP)
+  bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
+  bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)
   const void* big_lds_kernel;  // last kernel whose dynamic-LDS limit was raised on this device
   int upper_mode;     // NDLQR_UPPER=0: separator_one + schur_small<BOUNDARY> per level; 1 (default): one
                       // launch per level (level_small); 2: all upper levels in one launch (upper_small)

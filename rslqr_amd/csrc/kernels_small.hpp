@@ -242,7 +242,10 @@ template <int NX, int NU, bool STRICT, bool KEEP, bool LAMBDA_OUT>
 __device__ __forceinline__ void separator_wave(const Dims& d, const int l, const int sub, const int b,
                                                const int lane, const double* __restrict__ AB, double* F,
                                                double* z, double* __restrict__ rec, int* __restrict__ info,
-                                               SepIn<NX, NU>& in, SepOut<NX>& out) {
+                                               SepIn<NX, NU>& in, SepOut<NX>& out,
+                                               const bool store_l = false) {
+  // store_l: write the Cholesky factor of this separator (lambda rows of knot s+1, column l) even
+  // without LAMBDA_OUT -- what a record-based right-hand-side re-solve needs (KEEP_RECORDS)
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, LD = SepOut<NX>::LD;
   const int N = d.N;
   const int half = 1 << l, base = sub * (2 << l), s = base + half - 1;
@@ -299,7 +302,7 @@ __device__ __forceinline__ void separator_wave(const Dims& d, const int l, const
     myrec[2 * NN + gi] = v;
     z[((size_t)b * N + s + 1) * ROWS + gi] = v;
   }
-  if constexpr (LAMBDA_OUT) { if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow); }
+  if (LAMBDA_OUT || store_l) { if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow); }
   SEG(4);
 }
 
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, dou
 template <int NX, int NU, bool STRICT, bool KEEP>
 __global__ __launch_bounds__(512) void upper_small(Dims d, int l0, const double* __restrict__ AB, double* F,
                                                    double* z, double* __restrict__ rec,
-                                                   int* __restrict__ info) {
+                                                   int* __restrict__ info, const int store_l) {
   constexpr int ROWS = 2 * NX + NU, LD = SepOut<NX>::LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char upper_lds[];
   const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(512) void upper_small(Dims d, int l0, const double*
   for (int l = l0; l < K; ++l) {
     const int nsub = d.N >> (l + 1), T = 2 << l;
     for (int sub = wave; sub < nsub; sub += nw) {
-      separator_wave<NX, NU, STRICT, KEEP, KEEP>(d, l, sub, b, lane, AB, F, z, rec, info, in, out);
+      separator_wave<NX, NU, STRICT, KEEP, KEEP>(d, l, sub, b, lane, AB, F, z, rec, info, in, out, store_l != 0);
       if (l < K - 1 && kn < 2) {
         const int i = sub * T + (kn == 0 ? 0 : T - 1);
         schur_rows<NX, NU, STRICT, LD, LD>(d, l, i, r, b, F, z, out.X, out.X + NX, out.X + 2 * NX);
@@ -604,12 +607,13 @@ __global__ __launch_bounds__(512) void upper_small(Dims d, int l0, const double*
 // (the loop body of upper_small with chip-wide parallelism).  grid (N >> (l+1), batch), block 64.
 template <int NX, int NU, bool STRICT, bool KEEP>
 __global__ __launch_bounds__(64) void level_small(Dims d, int l, const double* __restrict__ AB, double* F,
-                                                  double* z, double* __restrict__ rec, int* __restrict__ info) {
+                                                  double* z, double* __restrict__ rec, int* __restrict__ info,
+                                                  const int store_l) {
   constexpr int ROWS = 2 * NX + NU, LD = SepOut<NX>::LD;
   __shared__ SepIn<NX, NU> in;
   __shared__ SepOut<NX> out;
   const int lane = threadIdx.x, sub = blockIdx.x, b = blockIdx.y;
-  separator_wave<NX, NU, STRICT, KEEP, KEEP>(d, l, sub, b, lane, AB, F, z, rec, info, in, out);
+  separator_wave<NX, NU, STRICT, KEEP, KEEP>(d, l, sub, b, lane, AB, F, z, rec, info, in, out, store_l != 0);
   SEG_INIT();
   const int kn = lane / ROWS, r = lane - kn * ROWS;
   if (l < d.K - 1 && kn < 2) {
@@ -1207,8 +1211,8 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
   // lean (fast mode without KEEP only): the solution comes from backsub_small, which needs the
   // records of the on-chip separators but nothing of the interior knots -- hand off only the
   // first and the last knot of the workgroup (what the upper levels read).
-  // recout (fast mode): write the records of the on-chip separators (lean, or KEEP for the
-  // record-based right-hand-side re-solve).
+  // recout bit 0 (fast mode): write the records of the on-chip separators (lean, or KEEP for the
+  // record-based right-hand-side re-solve); bit 1: also their Cholesky factors (KEEP_RECORDS).
   constexpr int W = NX + NU, ROWS = 2 * NX + NU;
   constexpr int NK = 1 << JB, NWAVE = NK / 2;
   static_assert(2 * ROWS <= 64 && 3 * NX <= 64, "two knots per wavefront, three lane groups of NX");
@@ -1361,9 +1365,9 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
                                                                 pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP);
       if (bad && lane == 0) flag_failure(info, d, b);
-      if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
+      if ((KEEP || (recout & 2)) && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
       if constexpr (!STRICT) {
-        if (recout) {  // record f_a | f_bb | z_sep of this separator (layout of separator_wave)
+        if (recout & 1) {  // record f_a | f_bb | z_sep of this separator (layout of separator_wave)
           double* myrec = rec + ((size_t)b * N + s) * (2 * NX * NX + NX);
           const int grp = lane / NX;
           if (grp < 2) {

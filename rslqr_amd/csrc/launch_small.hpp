@@ -17,7 +17,7 @@ static void launch_bottom(NdlqrHipCtx* c, bool lean) {
   const size_t pad = (size_t)c->bottom_lds_pad;  // occupancy experiments (NDLQR_BOTTOM_LDS_PAD)
   hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), pad,
                      c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0,
-                     (lean || (KEEP && !STRICT)) ? 1 : 0);
+                     ((lean || (KEEP && !STRICT)) ? 1 : 0) | ((c->flags & NDLQR_FLAG_KEEP_RECORDS) ? 2 : 0));
 }
 
 template <int NX, int NU, bool STRICT, bool KEEP>
@@ -33,6 +33,10 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   // boundary-first schedule right after the bottom kernel, so that no level reads interior knots)
   const bool lean = !STRICT && !KEEP && JB >= J && JB >= 1 && JB < d.K && c->upper_mode != 0 &&
                     (d.K + 4) * NX <= 256 && !c->no_backsub;
+  const int store_l = (c->flags & NDLQR_FLAG_KEEP_RECORDS) ? 1 : 0;  // factors for a record-based re-solve
+  // the record-based re-solve needs every separator's record and factor: KEEP writes them all,
+  // KEEP_RECORDS adds the factors to the lean schedule
+  c->rec_complete = !STRICT && (KEEP || (lean && store_l));
   switch (JB) {
     case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c, lean); break;
     case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c, lean); break;
@@ -48,7 +52,7 @@ static int launch_small(NdlqrHipCtx* c, int J) {
     for (int l = JB; l < d.K; ++l) {
       ScopedSlot t(c, SLOT_UPPER);
       hipLaunchKernelGGL((ndlqr::level_small<NX, NU, STRICT, KEEP>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0,
-                         c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info);
+                         c->stream, d, l, c->AB, c->F, c->z, c->rec, c->info, store_l);
     }
   } else if (JB >= J && JB >= 1 && JB < d.K && c->upper_mode == 2) {
     // no full-level Schur pass left: all remaining levels of a problem in one launch
@@ -63,7 +67,7 @@ static int launch_small(NdlqrHipCtx* c, int J) {
       c->big_lds_kernel = reinterpret_cast<const void*>(kern);
     }
     hipLaunchKernelGGL(kern, dim3(d.batch), dim3(64 * nw), lds, c->stream, d, JB, c->AB, c->F, c->z, c->rec,
-                       c->info);
+                       c->info, store_l);
   } else
   for (int l = JB; l < d.K; ++l) {
     {

@@ -299,7 +299,6 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
   if (J < Jmin) J = Jmin;
   if (J > d.K) J = d.K;
   *err = inst->solve(c, strict, keep, J);
-  c->rec_complete = !strict && keep;  // every separator's record f_a | f_bb | z_sep is in rec
   return true;
 }
 
@@ -344,8 +343,10 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
       if (e != hipSuccess) { c->graph_exec = nullptr; return fail("hipGraphInstantiate", e); }
       c->graph_flags = c->flags; c->graph_J = c->fuse_level; c->graph_JB = c->bottom_levels;
       c->graph_stream = c->stream;
+      c->graph_rec_complete = c->rec_complete;  // what the captured sequence leaves behind
     }
     HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    c->rec_complete = c->graph_rec_complete;
   }
   if (err) return err;
   HIP_TRY(hipGetLastError());
@@ -402,14 +403,20 @@ static bool try_launch_rhs_records(NdlqrHipCtx* c) {
 
 int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
-  if (!c->fact_valid) {
-    g_last_error = "rhs-only solve needs a previous solve with NDLQR_FLAG_KEEP_FACT (cached factorisation)";
+  if (!c->fact_valid && !c->rec_complete) {
+    g_last_error = "rhs-only solve needs a previous solve with NDLQR_FLAG_KEEP_FACT or "
+                   "NDLQR_FLAG_KEEP_RECORDS (cached factorisation)";
     fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
     return NDLQR_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   if (!try_launch_rhs_records(c)) {
+    if (!c->fact_valid) {  // records only, but this shape / horizon has no record-based re-solve
+      g_last_error = "rhs-only solve: this configuration needs NDLQR_FLAG_KEEP_FACT";
+      fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+      return NDLQR_ERR_INVALID;
+    }
     if (c->flags & NDLQR_FLAG_STRICT_FP) launch_rhs_sweep<true>(c); else launch_rhs_sweep<false>(c);
   }
   HIP_TRY(hipGetLastError());

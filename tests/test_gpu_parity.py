@@ -209,6 +209,41 @@ def test_env_variants_agree(ndlqr, oracle):
         assert np.array_equal(o, outs[0])
 
 
+@pytest.mark.parametrize("n,m,N", [(12, 4, 64), (12, 4, 256), (6, 3, 32), (13, 4, 16), (4, 1, 8), (10, 4, 128)])
+def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
+    """NDLQR_FLAG_KEEP_RECORDS: the lean fast-mode solve keeps just the separator records and
+    factors; new right-hand sides are then solved without the factor array -- also after the
+    matrices were replaced and the (graph-replayed) solve ran again."""
+    batch = 3
+    first = [synth(ndlqr, n, m, N, 300 + p) for p in range(batch)]
+    other = [synth(ndlqr, n, m, N, 700 + p) for p in range(batch)]
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=ndlqr.FLAG_KEEP_RECORDS)
+    for mats, rhs in ((first, other), (other, first)):
+        mixed = [Problem(n, m, N, f.A, f.B, f.Q, f.R, o.q, o.r, o.d, o.x0) for f, o in zip(mats, rhs)]
+        bs.initialize_flat(*stack(mats))
+        assert bs.solve() == 0
+        for p, prob in enumerate(mats):
+            ref = oracle.solve(prob, 1)[0][: prob.nvars]
+            assert np.linalg.norm(bs.solution(p) - ref) / np.linalg.norm(ref) <= REL_TOL
+        bs.set_rhs_flat(*[np.stack([getattr(p, k) for p in mixed]) for k in ("q", "r", "d", "x0")])
+        assert bs.solve_rhs_only() == 0
+        sol = bs.solutions()
+        for p, prob in enumerate(mixed):
+            ref = oracle.solve(prob, 1)[0][: prob.nvars]
+            assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+            ok, detail = _kkt_ok(oracle, prob, sol[p])
+            assert ok, detail
+    with pytest.raises(RuntimeError):  # no factor array in this mode
+        bs.factors(0)
+    bs.close()
+    # a shape without a size-specialised instance cannot re-solve from records
+    bs = ndlqr.BatchSolver(7, 2, 16, 2, flags=ndlqr.FLAG_KEEP_RECORDS)
+    bs.initialize_synthetic(5)
+    assert bs.solve() == 0
+    assert bs.solve_rhs_only() == -1
+    bs.close()
+
+
 def test_env_variants_fast_mode(ndlqr, oracle):
     """Fast mode has three solution sweeps (back-substitution from the records, finish kernel on the
     hand-off columns, apply pass) and three schedules of the upper levels: each stays within the
