@@ -100,7 +100,10 @@ template <int NX, int NU, bool STRICT, bool KEEPL, int SEGB = 0>
 __device__ __forceinline__ bool separator_core(const int lane, const double (&ab)[NX + NU],
                                                const SepIn<NX, NU>& in, SepOut<NX>& out,
                                                double (&Lrow)[NX], const double* abmat = nullptr,
-                                               const int abpitch = 0) {
+                                               const int abpitch = 0, double* lstore = nullptr) {
+  // lstore: where to put the Cholesky factor (row gi at lstore + gi * NX) when only a run-time
+  // flag asks for it (KEEP_RECORDS) -- stored right after the factorisation, so that no
+  // register copy of it has to live until the caller gets round to storing it
   constexpr int W = NX + NU, LD = SepOut<NX>::LD;
   static_assert(2 * NX + 1 <= SepOut<NX>::NC && 2 * NX <= 64, "panel too narrow");
   const int grp = lane / NX, gi = lane - grp * NX;
@@ -200,6 +203,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
   }
 #pragma unroll
   for (int j = 0; j < NX; ++j) Lrow[j] = acc[j];
+  if (lstore && lane < NX) store_row<NX>(lstore + gi * NX, acc);
   wave_lds_sync();
   SEG(SEGB + 2);
 
@@ -281,7 +285,8 @@ __device__ __forceinline__ void separator_wave(const Dims& d, const int l, const
   SEG(0);
   double Lrow[NX];
   const bool bad = separator_core<NX, NU, STRICT, KEEP>(lane, ab, in, out, Lrow,
-                                                       AB + ((size_t)b * N + s) * NX * W, W);
+                                                       AB + ((size_t)b * N + s) * NX * W, W,
+                                                       (!LAMBDA_OUT && store_l) ? Fblk(F, d, b, l, s + 1) : nullptr);
   if (bad && lane == 0) flag_failure(info, d, b);
   SEG(6);  // re-arms the clock after the core's own marks
 
@@ -302,7 +307,7 @@ __device__ __forceinline__ void separator_wave(const Dims& d, const int l, const
     myrec[2 * NN + gi] = v;
     z[((size_t)b * N + s + 1) * ROWS + gi] = v;
   }
-  if (LAMBDA_OUT || store_l) { if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow); }
+  if constexpr (LAMBDA_OUT) { if (lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow); }
   SEG(4);
 }
 
@@ -1363,9 +1368,10 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
         }
       }
       const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
-                                                                pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP);
+                                                                pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP,
+                                                                (!KEEP && (recout & 2)) ? Fblk(F, d, b, l, s + 1) : nullptr);
       if (bad && lane == 0) flag_failure(info, d, b);
-      if ((KEEP || (recout & 2)) && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
+      if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
       if constexpr (!STRICT) {
         if (recout & 1) {  // record f_a | f_bb | z_sep of this separator (layout of separator_wave)
           double* myrec = rec + ((size_t)b * N + s) * (2 * NX * NX + NX);
