@@ -4,12 +4,18 @@
 // Same arithmetic (and, with STRICT, the same operation order) as kernels_generic.hpp; see that
 // file for the mapping to the reference functions and DESIGN.md section 2 for the schedule:
 //
-//   bottom_small     leaf phase + tree levels 0..JB-1 fused on chip (registers + LDS exchange)
-//   separator_core   S-bar, f_a, f_bb, z_sep of one separator by one wavefront (device function)
-//   separator_one    standalone separator kernel for the upper levels
-//   schur_small      Schur update of all knots of a level, or (BOUNDARY) of the first and last
-//                    knot of every subtree only
-//   apply_small      every knot through all upper levels in registers, one pass
+//   bottom_small       leaf phase + tree levels 0..JB-1 fused on chip (registers + LDS exchange)
+//   separator_core     S-bar, f_a, f_bb, z_sep of one separator by one wavefront (device function;
+//                      products on the matrix cores in fast mode)
+//   level_small        one upper level: separator (separator_wave) + Schur update of the first and
+//                      last knot of every subtree (schur_rows), one wavefront per subtree
+//   backsub_small      fast mode without KEEP: solution by back-substitution over the separator
+//                      records and the problem data
+//   apply_small        strict / KEEP: every knot through all upper levels in registers, one pass
+//   rhs_forward_small, rhs_forward_upper
+//                      new right-hand side against cached records + factors (then backsub_small)
+//   separator_one, schur_small, upper_small, finish_small
+//                      alternative schedules kept for A/B timing and for J > JB
 //
 // Variants that were measured and dropped (numbers in DESIGN.md, "Tried and dropped"): two separators per
 // wavefront with L broadcast from LDS, an LDS-resident Cholesky/substitution with rolled pivot
