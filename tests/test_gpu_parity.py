@@ -244,6 +244,32 @@ def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
     bs.close()
 
 
+@pytest.mark.parametrize("n,m,N", [(12, 4, 256), (6, 3, 512)])
+@pytest.mark.parametrize("a_scale,q_scale", [(1.15, 1.0), (1.0, 1e-4), (1.3, 1e-3)])
+def test_harder_problem_families(ndlqr, oracle, n, m, N, a_scale, q_scale):
+    """Unstable dynamics (A scaled past the unit circle) and weak state costs: less benign than the
+    benchmark family. Strict mode stays bit-identical, fast mode (back-substitution, matrix-core
+    products) stays within the stated tolerance and at the oracle's own KKT residual level."""
+    g = ndlqr.generate_synthetic(n, m, N, 11)
+    g["A"] = g["A"] * a_scale
+    g["Q"] = g["Q"] * q_scale
+    prob = Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+    ref = oracle.solve(prob, 8)[0][: prob.nvars]
+    ores, obn = oracle.kkt_residual(prob, ref)
+    for strict in (True, False):
+        bs = ndlqr.BatchSolver(n, m, N, 1, flags=ndlqr.FLAG_STRICT_FP if strict else 0)
+        bs.initialize_flat(*[g[k][None] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+        assert bs.solve() == 0
+        sol = bs.solutions()[0]
+        if strict:
+            assert np.array_equal(sol, ref)
+        else:
+            assert np.linalg.norm(sol - ref) / np.linalg.norm(ref) <= REL_TOL
+            res, bn = oracle.kkt_residual(prob, sol)
+            assert res / max(1.0, bn) <= 10.0 * ores / max(1.0, obn) + 1e-12
+        bs.close()
+
+
 def test_env_variants_fast_mode(ndlqr, oracle):
     """Fast mode has three solution sweeps (back-substitution from the records, finish kernel on the
     hand-off columns, apply pass) and three schedules of the upper levels: each stays within the
