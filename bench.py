@@ -228,6 +228,15 @@ def main():
     prof = bs.profile()
     bs.set_flags(args.flags)
 
+    # per-solve device times (HIP events around the replayed launch sequence, one solve at a time):
+    # median and minimum next to the mean of the timed region
+    per_solve = []
+    for _ in range(min(args.steps, 50)):
+        bs.solve()
+        per_solve.append(bs.solve_ms())
+    per_solve.sort()
+    dev_median, dev_min = per_solve[len(per_solve) // 2], per_solve[0]
+
     # every problem of the shard, checked on the device against its raw data (outside the timed
     # region): worst ||K z - b|| / max(1, ||b||) -- SURVEY.md 8(d) "KKT residual of every problem"
     kres, kbn = bs.kkt_residuals()
@@ -284,6 +293,8 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
             "ms_per_solve": 1e3 / value,
+            "device_ms_per_step": {"median": dev_median, "min": dev_min, "reps": len(per_solve),
+                                   "note": "rank 0, HIP events per solve, one solve in flight"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (seeded splitmix64 family of SURVEY.md 8d, time-varying A,B,Q,R)",
             "config": {"workload": "nx=%d nu=%d N=%d batch=%d per GPU, fp64, factor+solve per step"
