@@ -9,6 +9,7 @@
  * NDLQR_ERR_NO_DEVICE on stderr and leave the operands untouched.
  */
 #include <stdio.h>
+#include <string.h>
 #include <time.h>
 
 #include "ndlqr.h"
@@ -89,7 +90,10 @@ void MatrixSymmetricMultiply(Matrix* Asym, Matrix* B, Matrix* C, double alpha, d
 }
 
 void MatrixCopyDiagonal(Matrix* dest, Matrix* src) {
-  /* src is a vector of diagonal entries, dest a square matrix (linalg.c:222-232) */
-  const int n = dest->rows;
-  for (int i = 0; i < n; ++i) dest->data[i + n * i] = src->data[i];
+  /* dest = diag(src): src is a vector of diagonal entries; everything else in dest is cleared
+   * (src/linalg.c:215-221) */
+  if (!dest || !src) return;
+  const int n = dest->rows, len = src->rows * src->cols;
+  memset(dest->data, 0, sizeof(double) * (size_t)dest->rows * dest->cols);
+  for (int i = 0; i < len && i < n && i < dest->cols; ++i) dest->data[i + n * i] = src->data[i];
 }

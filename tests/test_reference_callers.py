@@ -1,15 +1,16 @@
 """The reference's own test programs, compiled unchanged against the drop-in.
 
 `oracle/Makefile` target `reftests` compiles test/{matrix,utils,binarytree,lqrdata,nddata,solver,
-linalg,nested_dissection}_test.c of the reference from where they lie (never copied) against
+linalg,nested_dissection,riccati_solver,sample_problem}_test.c of the reference from where they lie (never copied) against
 `include/` and links them with `rslqr_amd/librslqr_amd.so`; the binaries land in
 `oracle/_ref/tests/` (git-ignored, they travel to the GPU box like `oracle/_ref/libref.so`).
 Their fixture macros (test/CMakeLists.txt:42-46 of the reference) point at the data copies in
 `tests/golden/`, so they run from the repo root.
 
 * host-only programs (containers, tree, JSON readers) run on the CPU here;
-* `solver_test`, `linalg_test`, `nested_dissection_test` run on the GPU: they call the stage
-  functions, the dense helpers and `ndlqr_Solve`, and assert the reference's literal golden
+* `solver_test`, `linalg_test`, `nested_dissection_test`, `riccati_solver_test` and
+  `sample_problem_test` run on the GPU: they call the stage functions, the dense helpers,
+  `ndlqr_Solve` and the Riccati baseline, and assert the reference's literal golden
   values (nested_dissection_test.c:44-105,133,166-229,277,299,307; linalg_test.c:19,55).
 """
 import os
@@ -20,7 +21,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "tests")
 HOST_ONLY = ["matrix", "utils", "binarytree", "lqrdata", "nddata"]
-DEVICE = ["solver", "linalg", "nested_dissection"]
+DEVICE = ["solver", "linalg", "nested_dissection", "riccati_solver"]
 
 
 def _build_if_possible():
@@ -58,7 +59,7 @@ def test_reference_device_programs_link(built):
     """On the CPU box the device programs must at least have linked against the drop-in."""
     if not os.path.isdir("/root/reference/test"):
         pytest.skip("reference absent")
-    for name in DEVICE:
+    for name in DEVICE + ["sample_problem"]:
         assert os.access(os.path.join(BIN, name + "_test"), os.X_OK), name
 
 
@@ -69,3 +70,21 @@ def test_reference_program_on_gpu(name):
     if name == "nested_dissection":
         # the program prints its own final-solution error against lqr_prob.json's soln
         assert "Accuracy of final solution" in text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("length", ["8", "256"])
+def test_reference_sample_problem_program(length):
+    """test/sample_problem_test.c (the reference's end-to-end harness: rsLQR against the stored
+    solution and against its Riccati baseline, N = 8 and N = 256): it only prints, so the two
+    verdict lines are checked here."""
+    exe = os.path.join(BIN, "sample_problem_test")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tests not built (needs /root/reference at build time)")
+    out = subprocess.run([exe, length], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert "Using a trajectory length of %s" % length in text
+    assert "Got the right answer? 1" in text, text[-3000:]
+    assert "Got the same answer? 1" in text, text[-3000:]
+
