@@ -63,6 +63,7 @@ def build(force=False, verbose=False):
     me = os.path.abspath(__file__)
     hipcc = _hipcc()
     hip_flags = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-Wall",
+                 "-Wno-pass-failed",  # (13,4) with three fused levels misses its occupancy hint: expected
                  "-I" + INCLUDE, "-I" + CSRC] + os.environ.get("NDLQR_EXTRA_HIPFLAGS", "").split()
     hip_deps = [me] + headers + [os.path.join(CSRC, h) for h in HIP_DEPS]
     jobs, objs = [], []   # (label, command) for everything out of date
