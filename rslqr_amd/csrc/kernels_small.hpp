@@ -91,6 +91,75 @@ struct alignas(16) SepOut {
 // lanes < NX (KEEPL: entries above the diagonal keep their S-bar values, like the reference's
 // in-place factorisation). Returns true when a pivot was not positive. The caller issues the
 // workgroup barrier that makes the solved panel visible to other wavefronts.
+// Cholesky of S-bar (rows in acc, lanes 0..NX-1) and both substitutions of the 2 NX + 1 panel
+// columns: the second half of a separator, shared by separator_core (products formed from the two
+// neighbouring knots) and reduced_level (products assembled from the separator-only accumulators).
+// after_forward(x): called with the lane's forward-substituted column between the two sweeps.
+struct NoHook { template <class T> __device__ __forceinline__ void operator()(T&) const {} };
+
+template <int NX, bool STRICT, bool KEEPL, int SEGB, class Hook>
+__device__ __forceinline__ bool factor_solve(const int lane, double (&acc)[NX], SepOut<NX>& out,
+                                             double (&Lrow)[NX], double* lstore, Hook after_forward) {
+  constexpr int LD = SepOut<NX>::LD;
+  const int gi = lane % NX;
+  SEG_INIT();
+  // P2: left-looking Cholesky on the registers of group 0 (every lane runs it; rows of other
+  // groups are don't-cares), row j broadcast with v_readlane; finished columns go to LDS.
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v = mad<STRICT>(-acc[k], readlane_f64(acc[k], j), v);
+    if constexpr (KEEPL) { if (gi >= j) acc[j] = v; } else { acc[j] = v; }
+    const double pivot = readlane_f64(acc[j], j);
+    bad = bad || !(pivot > 0.0);
+    if constexpr (STRICT) {
+      const double root = sqrt(pivot);
+      if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] / root; } else { acc[j] = acc[j] / root; }
+    } else {
+      const double rinv = rsqrt(pivot);
+      if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] * rinv; } else { acc[j] = acc[j] * rinv; }
+      if (lane == 0) out.rdiag[j] = rinv;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the row-j broadcasts (SGPRs) local to their column
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) Lrow[j] = acc[j];
+  if (lstore && lane < NX) store_row<NX>(lstore + gi * NX, acc);
+  wave_lds_sync();
+  SEG(SEGB + 2);
+
+  // P3: one right-hand-side column per lane (lanes >= LD repeat a column: same values)
+  const int col = lane & (SepOut<NX>::NC - 1);
+  double x[NX];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) x[k] = out.X[k * LD + col];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
+#pragma unroll
+    for (int r = j + 1; r < NX; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[j], r), x[j], x[r]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  after_forward(x);  // x = L^-1 (right-hand side): what the separator-only schedule pushes upwards
+#pragma unroll
+  for (int j = NX - 1; j >= 0; --j) {
+    if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
+#pragma unroll
+    for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[r], j), x[j], x[r]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_lds_sync();
+  if (lane < SepOut<NX>::NC) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) out.X[k * LD + col] = x[k];
+  }
+  wave_lds_sync();
+  SEG(SEGB + 3);
+  return bad;
+}
+
 // Products of the separator on the matrix cores (fast mode, 6 <= NX <= 15; NX + NU is padded
 // with zeros to a multiple of 4):
 // [S-bar | rhs_z] = [A_s | B_s] [Exu | zxu] - [E1x | z1], rhs_a = [A_s | B_s] Axu as two 16x16 tiles
@@ -186,60 +255,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
   }  // vector-ALU products
 
   SEG(SEGB + 1);
-  // P2: left-looking Cholesky on the registers of group 0 (every lane runs it; rows of other
-  // groups are don't-cares), row j broadcast with v_readlane; finished columns go to LDS.
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    double v = acc[j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) v = mad<STRICT>(-acc[k], readlane_f64(acc[k], j), v);
-    if constexpr (KEEPL) { if (gi >= j) acc[j] = v; } else { acc[j] = v; }
-    const double pivot = readlane_f64(acc[j], j);
-    bad = bad || !(pivot > 0.0);
-    if constexpr (STRICT) {
-      const double root = sqrt(pivot);
-      if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] / root; } else { acc[j] = acc[j] / root; }
-    } else {
-      const double rinv = rsqrt(pivot);
-      if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] * rinv; } else { acc[j] = acc[j] * rinv; }
-      if (lane == 0) out.rdiag[j] = rinv;
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the row-j broadcasts (SGPRs) local to their column
-  }
-#pragma unroll
-  for (int j = 0; j < NX; ++j) Lrow[j] = acc[j];
-  if (lstore && lane < NX) store_row<NX>(lstore + gi * NX, acc);
-  wave_lds_sync();
-  SEG(SEGB + 2);
-
-  // P3: one right-hand-side column per lane (lanes >= LD repeat a column: same values)
-  const int col = lane & (SepOut<NX>::NC - 1);
-  double x[NX];
-#pragma unroll
-  for (int k = 0; k < NX; ++k) x[k] = out.X[k * LD + col];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
-#pragma unroll
-    for (int r = j + 1; r < NX; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[j], r), x[j], x[r]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int j = NX - 1; j >= 0; --j) {
-    if constexpr (STRICT) x[j] = x[j] / readlane_f64(Lrow[j], j); else x[j] = x[j] * out.rdiag[j];
-#pragma unroll
-    for (int r = 0; r < j; ++r) x[r] = mad<STRICT>(-readlane_f64(Lrow[r], j), x[j], x[r]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  wave_lds_sync();
-  if (lane < SepOut<NX>::NC) {
-#pragma unroll
-    for (int k = 0; k < NX; ++k) out.X[k * LD + col] = x[k];
-  }
-  wave_lds_sync();
-  SEG(SEGB + 3);
-  return bad;
+  return factor_solve<NX, STRICT, KEEPL, SEGB>(lane, acc, out, Lrow, lstore, NoHook());
 }
 
 // One wavefront per separator: stage the operands (whole rows, 16-byte loads), run the core,
