@@ -171,11 +171,12 @@ struct P1OnMatrixCores {
   static constexpr bool value = NX >= 6 && NX + 1 <= 16;  // smaller blocks are mostly tile padding
 };
 
-template <int NX, int NU, bool STRICT, bool KEEPL, int SEGB = 0>
+template <int NX, int NU, bool STRICT, bool KEEPL, int SEGB = 0, class Hook = NoHook>
 __device__ __forceinline__ bool separator_core(const int lane, const double (&ab)[NX + NU],
                                                const SepIn<NX, NU>& in, SepOut<NX>& out,
                                                double (&Lrow)[NX], const double* abmat = nullptr,
-                                               const int abpitch = 0, double* lstore = nullptr) {
+                                               const int abpitch = 0, double* lstore = nullptr,
+                                               Hook after_forward = Hook()) {
   // lstore: where to put the Cholesky factor (row gi at lstore + gi * NX) when only a run-time
   // flag asks for it (KEEP_RECORDS) -- stored right after the factorisation, so that no
   // register copy of it has to live until the caller gets round to storing it
@@ -255,7 +256,7 @@ __device__ __forceinline__ bool separator_core(const int lane, const double (&ab
   }  // vector-ALU products
 
   SEG(SEGB + 1);
-  return factor_solve<NX, STRICT, KEEPL, SEGB>(lane, acc, out, Lrow, lstore, NoHook());
+  return factor_solve<NX, STRICT, KEEPL, SEGB>(lane, acc, out, Lrow, lstore, after_forward);
 }
 
 // One wavefront per separator: stage the operands (whole rows, 16-byte loads), run the core,
@@ -341,6 +342,201 @@ __global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double*
   __shared__ SepIn<NX, NU> in;
   __shared__ SepOut<NX> out;
   separator_wave<NX, NU, STRICT, KEEP, true>(d, l, blockIdx.x, blockIdx.y, threadIdx.x, AB, F, z, rec, info, in, out);
+}
+
+// leaf-phase rhs entry rr of knot i from the raw right-hand side (the rhs part of ndlqr_SolveLeaf)
+template <int NX, int NU>
+__device__ __forceinline__ double leaf_rhs_entry(const Dims& d, const int b, const int i, const int rr,
+                                                 const double* __restrict__ QR, const double* __restrict__ rhs) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU;
+  const double* r0 = rhs + ((size_t)b * d.N + i) * ROWS;
+  const double* qr = QR + ((size_t)b * d.N + i) * W;
+  const bool lam = rr < NX, last = (i == d.N - 1);
+  if (i == 0) {
+    if (lam) return fma(-qr[rr], r0[rr], -r0[NX + rr]);
+    if (rr < 2 * NX) return -r0[rr - NX];
+    return r0[rr] / qr[rr - NX];
+  }
+  if (lam) return r0[rr];
+  if (rr < 2 * NX || !last) return r0[rr] / qr[rr - NX];
+  return r0[rr];
+}
+
+// ------------------------------------------------------------------------------------- separator-only schedule
+// Fast mode without KEEP, upper levels: instead of keeping the first and last knot of every
+// subtree up to date (28-row states that the next separator re-reads), every eliminated
+// separator s' pushes the Schur-complement contributions of the REDUCED system -- block cyclic
+// reduction on the separators alone -- to its two neighbours A (left of its subtree) and B (right):
+//     DR[A] += Y_a' Y_a     gR[A] += Y_a' y_z      DL[B] += Y_bb' Y_bb    gL[B] += Y_bb' y_z
+//     coupling of the lower-level neighbour (the parent) to the other one:
+//        left child  (parent B):  CA[B] = Y_bb' Y_a        right child (parent A):  CB[A] = Y_a' Y_bb
+// with Y = L^-1 [r_a | r_bb | b~] the forward-substituted panel (f' r = Y' Y by symmetry). A
+// separator s of a later level then starts from
+//     S-bar = leafS_s - DL[s] - DR[s],   r_a = -CA[s],   r_bb = -CB[s],   b~ = leaf_s - gL[s] - gR[s]
+// (leafS_s = A Q^-1 A' + B R^-1 B' + Q_{s+1}^-1, leaf_s as in rhs_forward_*): the same S-bar, f_a,
+// f_bb, z_sep as the knot-based schedule up to rounding, from 12x12 blocks instead of knot rows.
+// One slot per separator of level >= 2 (s = 3 mod 4): DL | DR | CA | CB | gL | gR.
+template <int NX>
+struct RedSlot {
+  static constexpr int NN = NX * NX, SIZE = 4 * NN + 2 * NX;
+  double* p;
+  __device__ __forceinline__ double* DL() const { return p; }
+  __device__ __forceinline__ double* DR() const { return p + NN; }
+  __device__ __forceinline__ double* CA() const { return p + 2 * NN; }
+  __device__ __forceinline__ double* CB() const { return p + 3 * NN; }
+  __device__ __forceinline__ double* gL() const { return p + 4 * NN; }
+  __device__ __forceinline__ double* gR() const { return p + 4 * NN + NX; }
+};
+template <int NX>
+__device__ __forceinline__ RedSlot<NX> red_slot(double* red, const Dims& d, const int b, const int t) {
+  return RedSlot<NX>{red + ((size_t)b * (d.N >> 2) + (t >> 2)) * RedSlot<NX>::SIZE};
+}
+
+// Gram blocks of the forward-substituted panel Y on the matrix cores. The lanes first re-file
+// their columns in the panel as [a (NX) | z | pad] [bb (NX) | pad] -- two 16-column tiles --, so
+// that the products fall apart cleanly:
+//   tile 00: Y_a' Y_a and Y_a' y_z    (aa(r, c, v), c = NX is the rhs column)
+//   tile 11: Y_bb' Y_bb               (bb(r, c, v))
+//   tile 01: Y_a' Y_bb and y_z' Y_bb  (ab(r, c, v), r = NX is the rhs row)
+// each fragment read from LDS once and used as A and as B operand; tiles that are not needed
+// (need_* false) cost nothing.
+template <int NX, bool need_aa, bool need_bb, bool need_ab, class EmitAA, class EmitBB, class EmitAB>
+__device__ __forceinline__ void gram_mfma(const int lane, double (&x)[NX], SepOut<NX>& out, EmitAA aa, EmitBB bb,
+                                          EmitAB ab) {
+  constexpr int LD = SepOut<NX>::LD, NC = SepOut<NX>::NC, KS = (NX + 3) / 4;
+  static_assert(NC == 32 && NX + 1 <= 16, "two column tiles of 16: [a | z], [bb]");
+  typedef double acc4 __attribute__((ext_vector_type(4)));
+  if (lane <= 2 * NX) {  // panel column `lane`: a, bb or z
+    const int dst = lane < NX ? lane : (lane < 2 * NX ? 16 + (lane - NX) : NX);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) out.X[k * LD + dst] = x[k];
+  } else if (lane < NC) {  // the padding columns of both tiles
+    const int pad = lane - (2 * NX + 1);  // 0 .. 30 - 2 NX
+    const int dst = pad < 15 - NX ? NX + 1 + pad : 16 + NX + (pad - (15 - NX));
+#pragma unroll
+    for (int k = 0; k < NX; ++k) out.X[k * LD + dst] = 0.0;
+  }
+  wave_lds_sync();
+  const int li = lane & 15, lk = lane >> 4;
+  acc4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = {0.0, 0.0, 0.0, 0.0}, g11 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int kk = 4 * q + lk, k = kk < NX ? kk : NX - 1;
+    const double f0 = kk < NX ? out.X[k * LD + li] : 0.0;
+    const double f1 = kk < NX ? out.X[k * LD + 16 + li] : 0.0;
+    if constexpr (need_aa) g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, g00, 0, 0, 0);
+    if constexpr (need_ab) g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, g01, 0, 0, 0);
+    if constexpr (need_bb) g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, g11, 0, 0, 0);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = lk + 4 * g;
+    if constexpr (need_aa) { if (r < NX && li <= NX) aa(r, li, g00[g]); }
+    if constexpr (need_bb) { if (r < NX && li < NX) bb(r, li, g11[g]); }
+    if constexpr (need_ab) { if (r <= NX && li < NX) ab(r, li, g01[g]); }
+  }
+  wave_lds_sync();
+}
+
+// One level of the separator-only schedule, one wavefront per separator.
+//   grid (N >> (l+1), batch), block 64; l >= 2; instances with matrix-core products only.
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void reduced_level(Dims d, int l, const double* __restrict__ AB,
+                                                    const double* __restrict__ QR,
+                                                    const double* __restrict__ rhs, double* red,
+                                                    double* __restrict__ rec, double* F, int* __restrict__ info,
+                                                    const int store_l) {
+  constexpr int W = NX + NU, NN = NX * NX, LD = SepOut<NX>::LD, KS = (W + 3) / 4, SP = NX + 2;
+  typedef double acc4 __attribute__((ext_vector_type(4)));
+  __shared__ SepOut<NX> out;
+  __shared__ double scr[NX * SP];
+  const int lane = threadIdx.x, b = blockIdx.y, N = d.N;
+  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
+  const bool hasA = base > 0, hasB = base + T < N;
+  const RedSlot<NX> my = red_slot<NX>(red, d, b, s);
+  const int li = lane & 15, lk = lane >> 4;
+  const int ri = li < NX ? li : NX - 1, rc = lane < NX ? lane : NX - 1;
+  const double* abm = AB + ((size_t)b * N + s) * NX * W;
+  const double* qr = QR + ((size_t)b * N + s) * W;
+  const double* qr1 = QR + ((size_t)b * N + s + 1) * W;
+
+  // S-bar = A Q^-1 A' + B R^-1 B' + Q_{s+1}^-1 - DL - DR as one 16x16 tile
+  acc4 c0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+    double v = 0.0;
+    if (li < NX && i < NX) {
+      v = -(my.DL()[ic * NX + ri] + my.DR()[ic * NX + ri]);
+      if (i == li) v += 1.0 / qr1[ic];
+    }
+    c0[g] = v;
+  }
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int kk = 4 * q + lk, k = kk < W ? kk : W - 1;
+    const double af = kk < W ? abm[ri * W + k] : 0.0;
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, af / qr[k], c0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = lk + 4 * g;
+    if (i < NX && li < NX) scr[i * SP + li] = c0[g];
+  }
+  // panel [r_a | r_bb | b~]
+  for (int e = lane; e < NN; e += 64) {
+    const int i = e / NX, j = e - i * NX;
+    out.X[i * LD + j] = hasA ? -my.CA()[e] : 0.0;
+    out.X[i * LD + NX + j] = hasB ? -my.CB()[e] : 0.0;
+  }
+  {
+    const double zxu = lane < W ? leaf_rhs_entry<NX, NU>(d, b, s, NX + lane, QR, rhs) : 0.0;
+    double accz = -leaf_rhs_entry<NX, NU>(d, b, s + 1, rc, QR, rhs);
+#pragma unroll
+    for (int k = 0; k < W; ++k) accz = fma(abm[rc * W + k], readlane_f64(zxu, k), accz);
+    accz -= leaf_rhs_entry<NX, NU>(d, b, s + 1, NX + rc, QR, rhs);
+    accz -= my.gL()[rc] + my.gR()[rc];
+    if (lane < NX) out.X[lane * LD + 2 * NX] = accz;
+  }
+  wave_lds_sync();
+  const int grp = lane / NX, gi = lane - grp * NX;
+  double acc[NX], Lrow[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) acc[j] = scr[gi * SP + j];
+
+  // pushes to the two neighbours
+  const bool leftchild = (base & T) == 0;
+  const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
+  const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
+  auto hook = [&](double (&x)[NX]) {
+    gram_mfma<NX, true, true, true>(
+        lane, x, out,
+        [&](int r, int c, double v) {  // Y_a' [Y_a | y_z]
+          if (!hasA) return;
+          if (c < NX) atomicAdd(sa.DR() + r * NX + c, v); else atomicAdd(sa.gR() + r, v);
+        },
+        [&](int r, int c, double v) { if (hasB) atomicAdd(sb.DL() + r * NX + c, v); },  // Y_bb' Y_bb
+        [&](int r, int c, double v) {  // [Y_a | y_z]' Y_bb
+          if (!hasB) return;
+          if (r == NX) atomicAdd(sb.gL() + c, v);
+          else if (hasA) { if (leftchild) sb.CA()[c * NX + r] = v; else sa.CB()[r * NX + c] = v; }
+        });
+  };
+  const bool bad = factor_solve<NX, false, false, 0>(lane, acc, out, Lrow,
+                                                     store_l ? Fblk(F, d, b, l, s + 1) : nullptr, hook);
+  if (bad && lane == 0) flag_failure(info, d, b);
+
+  double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
+  if (grp < 2) {
+    if (grp == 0 ? hasA : hasB) {
+      double row[NX];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) row[c] = out.X[gi * LD + grp * NX + c];
+      store_row<NX>(myrec + grp * NN + gi * NX, row);
+    }
+  } else if (grp == 2) {
+    myrec[2 * NN + gi] = out.X[gi * LD + 2 * NX];
+  }
 }
 
 // ------------------------------------------------------------------------------------- row update helpers
@@ -976,23 +1172,6 @@ __global__ __launch_bounds__(256) void backsub_small(Dims d, const double* __res
 // end / start at s -- by symmetry of the reduced system their coupling to s is the transpose
 // of their own f_bb / f_a. Reads per separator: its record and factor, nothing of the knots'
 // factor columns (the level-by-level sweep streams all N K of them).
-template <int NX, int NU>
-__device__ __forceinline__ double leaf_rhs_entry(const Dims& d, const int b, const int i, const int rr,
-                                                 const double* __restrict__ QR, const double* __restrict__ rhs) {
-  constexpr int W = NX + NU, ROWS = 2 * NX + NU;
-  const double* r0 = rhs + ((size_t)b * d.N + i) * ROWS;
-  const double* qr = QR + ((size_t)b * d.N + i) * W;
-  const bool lam = rr < NX, last = (i == d.N - 1);
-  if (i == 0) {
-    if (lam) return fma(-qr[rr], r0[rr], -r0[NX + rr]);
-    if (rr < 2 * NX) return -r0[rr - NX];
-    return r0[rr] / qr[rr - NX];
-  }
-  if (lam) return r0[rr];
-  if (rr < 2 * NX || !last) return r0[rr] / qr[rr - NX];
-  return r0[rr];
-}
-
 // (L L')^-1 applied to one vector by one wavefront: lane r < NX holds entry r of the vector, row
 // r of L (Lrow[j] = L(r, j), j <= r) and column r of L (Lcol[j] = L(j, r), j >= r).
 template <int NX>
@@ -1228,13 +1407,18 @@ __global__ __launch_bounds__(512) void rhs_forward_upper(Dims d, const double* _
 // 0..JB-1. Arithmetic and order per element are those of leaf_generic + separator_one +
 // schur_small run level by level.
 //   grid (N >> JB, batch), block 32 << JB threads. Requires N > 2^JB.
-template <int NX, int NU, bool STRICT, bool KEEP, int JB>
+// REDUCED (fast mode without KEEP, JB = 2): the workgroup feeds the separator-only schedule of the
+// upper levels (reduced_level) -- its three separators push their Gram blocks to the two
+// separators next to the workgroup, and neither the last level's Schur update nor any hand-off
+// of knot rows is needed.
+template <int NX, int NU, bool STRICT, bool KEEP, int JB, bool REDUCED = false>
 __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double* __restrict__ AB,
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
                                                          double* z, int* __restrict__ info,
                                                          double* __restrict__ rec, const int lean,
-                                                         const int recout) {
+                                                         const int recout, double* red = nullptr) {
+  static_assert(!REDUCED || (JB == 2 && !STRICT && !KEEP), "separator-only feed: fast mode, two fused levels");
   // lean (fast mode without KEEP only): the solution comes from backsub_small, which needs the
   // records of the on-chip separators but nothing of the interior knots -- hand off only the
   // first and the last knot of the workgroup (what the upper levels read).
@@ -1389,9 +1573,56 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
           for (int k = 0; k < W; ++k) ab[k] = abs_[k];
         }
       }
-      const bool bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
-                                                                pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP,
-                                                                (!KEEP && (recout & 2)) ? Fblk(F, d, b, l, s + 1) : nullptr);
+      bool bad;
+      if constexpr (REDUCED) {
+        // Gram pushes: level 0 parks the outward blocks of its two separators in the [A|B]
+        // staging areas they have finished with (knot 0 / knot 2); level 1 adds its own and
+        // writes the workgroup's contribution to the separators left (A) and right (B) of it
+        double* park_a = &pv[0].ab[0][0];  // Y_a'Y_a (NX x NX) | Y_a'y_z of separator wgbase
+        double* park_b = &pv[1].ab[0][0];  // Y_bb'Y_bb | Y_bb'y_z of separator wgbase + 2
+        static_assert(NX * WP >= NX * NX + NX, "parking area too small");
+        const bool hasA = wgbase > 0, hasB = wgbase + NK < N;
+        const bool leftchild = (wgbase & NK) == 0;
+        const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? wgbase - 1 : 3);
+        const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? wgbase + NK - 1 : 3);
+        auto hook = [&](double (&x)[NX]) {
+          if (l == 0) {
+            // separator wgbase (sub 0): its a-side faces the left neighbour; separator
+            // wgbase + 2 (sub 1): its bb-side faces the right neighbour
+            auto none = [](int, int, double) {};
+            if (sub == 0)
+              gram_mfma<NX, true, false, false>(
+                  lane, x, sout,
+                  [&](int r, int c, double v) { if (c < NX) park_a[r * NX + c] = v; else park_a[NX * NX + r] = v; },
+                  none, none);
+            else
+              gram_mfma<NX, false, true, true>(
+                  lane, x, sout, none, [&](int r, int c, double v) { park_b[r * NX + c] = v; },
+                  [&](int r, int c, double v) { if (r == NX) park_b[NX * NX + c] = v; });
+          } else {
+            gram_mfma<NX, true, true, true>(
+                lane, x, sout,
+                [&](int r, int c, double v) {
+                  if (!hasA) return;
+                  if (c < NX) sa.DR()[r * NX + c] = v + park_a[r * NX + c];
+                  else sa.gR()[r] = v + park_a[NX * NX + r];
+                },
+                [&](int r, int c, double v) { if (hasB) sb.DL()[r * NX + c] = v + park_b[r * NX + c]; },
+                [&](int r, int c, double v) {
+                  if (!hasB) return;
+                  if (r == NX) sb.gL()[c] = v + park_b[NX * NX + c];
+                  else if (hasA) { if (leftchild) sb.CA()[c * NX + r] = v; else sa.CB()[r * NX + c] = v; }
+                });
+          }
+        };
+        bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
+                                                       pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP,
+                                                       (recout & 2) ? Fblk(F, d, b, l, s + 1) : nullptr, hook);
+      } else {
+        bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
+                                                       pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP,
+                                                       (!KEEP && (recout & 2)) ? Fblk(F, d, b, l, s + 1) : nullptr);
+      }
       if (bad && lane == 0) flag_failure(info, d, b);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
       if constexpr (!STRICT) {
@@ -1412,6 +1643,7 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       }
     }
     SEG(23);
+    if constexpr (REDUCED) { if (l == JB - 1) return; }  // no Schur update, no hand-off: the upper levels work on the pushed blocks
     __syncthreads();
     SEG(24);
 

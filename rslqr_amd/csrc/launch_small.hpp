@@ -10,11 +10,17 @@
 // Levels J..K-1 ("boundary-first"): separator + Schur on the two boundary knots of every subtree
 // (tiny grids), then ONE apply_small pass that takes every knot through all those levels in
 // registers. J = K disables the second form (pure level-by-level streaming).
-template <int NX, int NU, bool STRICT, bool KEEP, int JB>
+template <int NX, int NU, bool STRICT, bool KEEP, int JB, bool REDUCED = false>
 static void launch_bottom(NdlqrHipCtx* c, bool lean) {
   const ndlqr::Dims& d = c->d;
   ScopedSlot t(c, SLOT_BOTTOM);
   const size_t pad = (size_t)c->bottom_lds_pad;  // occupancy experiments (NDLQR_BOTTOM_LDS_PAD)
+  if constexpr (REDUCED) {
+    hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB, true>), dim3(d.N >> JB, d.batch),
+                       dim3(32 << JB), pad, c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, 1,
+                       1 | ((c->flags & NDLQR_FLAG_KEEP_RECORDS) ? 2 : 0), c->red);
+    return;
+  }
   hipLaunchKernelGGL((ndlqr::bottom_small<NX, NU, STRICT, KEEP, JB>), dim3(d.N >> JB, d.batch), dim3(32 << JB), pad,
                      c->stream, d, c->AB, c->QR, c->rhs, c->F, c->z, c->info, c->rec, lean ? 1 : 0,
                      ((lean || (KEEP && !STRICT)) ? 1 : 0) | ((c->flags & NDLQR_FLAG_KEEP_RECORDS) ? 2 : 0));
@@ -37,6 +43,22 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   // the record-based re-solve needs every separator's record and factor: KEEP writes them all,
   // KEEP_RECORDS adds the factors to the lean schedule
   c->rec_complete = !STRICT && (KEEP || (lean && store_l));
+  // separator-only schedule of the upper levels (see reduced_level): the bottom kernel pushes
+  // 12x12 blocks instead of handing knot rows over
+  if constexpr (!STRICT && !KEEP && ndlqr::P1OnMatrixCores<NX, NU>::value) {
+    if (lean && c->reduced && JB == 2 && d.K > 2 && c->red) {
+      launch_bottom<NX, NU, STRICT, KEEP, 2, true>(c, true);
+      for (int l = 2; l < d.K; ++l) {
+        ScopedSlot t(c, SLOT_UPPER);
+        hipLaunchKernelGGL((ndlqr::reduced_level<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
+                           c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+      }
+      ScopedSlot t(c, SLOT_APPLY);
+      hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+                         c->QR, c->rhs, c->rec, c->z);
+      return NDLQR_OK;
+    }
+  }
   switch (JB) {
     case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c, lean); break;
     case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c, lean); break;

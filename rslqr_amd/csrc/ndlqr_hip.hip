@@ -34,6 +34,8 @@ int ndlqr_hip_device_count(void) {
 
 static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom", "upper"};
 
+static bool has_small_instance(int nstates, int ninputs);  // defined with the instance table below
+
 static size_t bytes_AB(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.n * d.w; }
 static size_t bytes_QR(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.w; }
 static size_t bytes_z(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.rows; }
@@ -66,7 +68,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.K = 0; while ((1 << d.K) < nhorizon) ++d.K;
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
-  c->AB = c->QR = c->rhs = c->F = c->z = c->rec = nullptr; c->info = nullptr;
+  c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr;
+  c->reduced = getenv("NDLQR_REDUCED") ? atoi(getenv("NDLQR_REDUCED")) != 0 : true;
   c->fuse_level = getenv("NDLQR_FUSE_LEVEL") ? atoi(getenv("NDLQR_FUSE_LEVEL")) : -1;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->no_finish = getenv("NDLQR_NO_FINISH") != nullptr;
@@ -85,6 +88,10 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
             hipMalloc(&c->rhs, bytes_z(d)) == hipSuccess && hipMalloc(&c->z, bytes_z(d)) == hipSuccess &&
             hipMalloc(&c->F, bytes_F(d)) == hipSuccess && hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
             hipMalloc(&c->info, sizeof(int) * ((size_t)batch + 1)) == hipSuccess;
+  if (ok && nhorizon >= 8 && has_small_instance(nstates, ninputs)) {
+    const size_t red_bytes = sizeof(double) * (size_t)batch * (nhorizon / 4) * (4 * (size_t)nstates * nstates + 2 * nstates);
+    ok = hipMalloc(&c->red, red_bytes) == hipSuccess && hipMemsetAsync(c->red, 0, red_bytes, c->stream) == hipSuccess;
+  }
   if (ok) {
     // Structural zeros of F are never written by the kernels; zero once so that the factor
     // download matches the reference's calloc'ed array (src/nddata.c:34).
@@ -109,7 +116,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
-  (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->info);
+  (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->info);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -277,6 +284,12 @@ static const SmallInstance kSmallInstances[] = {
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 };
+
+static bool has_small_instance(int nstates, int ninputs) {
+  for (const SmallInstance& s : kSmallInstances)
+    if (s.nx == nstates && s.nu == ninputs) return true;
+  return false;
+}
 
 static const SmallInstance* find_small(const ndlqr::Dims& d) {
   for (const SmallInstance& s : kSmallInstances)
