@@ -7,6 +7,8 @@
 //   bottom_small       leaf phase + tree levels 0..JB-1 fused on chip (registers + LDS exchange)
 //   separator_core     S-bar, f_a, f_bb, z_sep of one separator by one wavefront (device function;
 //                      products on the matrix cores in fast mode)
+//   reduced_level      fast mode without KEEP: one upper level on the reduced (separator-only)
+//                      system -- assemble from pushed 12x12 blocks, factor, solve, push (gram_mfma)
 //   level_small        one upper level: separator (separator_wave) + Schur update of the first and
 //                      last knot of every subtree (schur_rows), one wavefront per subtree
 //   backsub_small      fast mode without KEEP: solution by back-substitution over the separator
