@@ -412,12 +412,8 @@ __device__ __forceinline__ void gram_mfma(const int lane, double (&x)[NX], SepOu
     const int dst = lane < NX ? lane : (lane < 2 * NX ? 16 + (lane - NX) : NX);
 #pragma unroll
     for (int k = 0; k < NX; ++k) out.X[k * LD + dst] = x[k];
-  } else if (lane < NC) {  // the padding columns of both tiles
-    const int pad = lane - (2 * NX + 1);  // 0 .. 30 - 2 NX
-    const int dst = pad < 15 - NX ? NX + 1 + pad : 16 + NX + (pad - (15 - NX));
-#pragma unroll
-    for (int k = 0; k < NX; ++k) out.X[k * LD + dst] = 0.0;
-  }
+  }  // the padding columns of both tiles keep whatever they hold: they only reach products that
+     // nobody reads (every output element depends on its own pair of columns alone)
   wave_lds_sync();
   const int li = lane & 15, lk = lane >> 4;
   acc4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = {0.0, 0.0, 0.0, 0.0}, g11 = {0.0, 0.0, 0.0, 0.0};
@@ -457,48 +453,75 @@ __global__ __launch_bounds__(64) void reduced_level(Dims d, int l, const double*
   const bool hasA = base > 0, hasB = base + T < N;
   const RedSlot<NX> my = red_slot<NX>(red, d, b, s);
   const int li = lane & 15, lk = lane >> 4;
-  const int ri = li < NX ? li : NX - 1, rc = lane < NX ? lane : NX - 1;
+  const int ri = li < NX ? li : NX - 1;
+  SEG_INIT();
   const double* abm = AB + ((size_t)b * N + s) * NX * W;
   const double* qr = QR + ((size_t)b * N + s) * W;
   const double* qr1 = QR + ((size_t)b * N + s + 1) * W;
 
-  // S-bar = A Q^-1 A' + B R^-1 B' + Q_{s+1}^-1 - DL - DR as one 16x16 tile
-  acc4 c0;
+  // [S-bar | b~] = [A | B] diag(1/Q, 1/R) [A | B]' + Q_{s+1}^-1 - DL - DR  |  [A | B] z(s).xu - z(s+1)
+  // - gL - gR as ONE 16x16 tile: column NX of the B operand carries the leaf-phase rhs of knot s.
+  // (Knots s and s+1 of a level >= 2 are never the first or the last knot: no special cases.)
+  // Every global operand is requested first, in straight-line code with clamped indices, so that
+  // the wavefront pays one memory round trip before it starts computing.
+  const double* r0 = rhs + ((size_t)b * N + s) * (2 * NX + NU);
+  const double* r1 = r0 + (2 * NX + NU);
+  constexpr int QP = (NN + 63) / 64;
+  double pca[QP], pcb[QP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int e = lane + 64 * q, ec = e < NN ? e : NN - 1;
+    pca[q] = my.CA()[ec];
+    pcb[q] = my.CB()[ec];
+  }
+  double dlr[4], extra[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+    dlr[g] = my.DL()[ic * NX + ri] + my.DR()[ic * NX + ri];
+    // diagonal term of S-bar (lanes li < NX) / rhs terms (lane li == NX)
+    extra[g] = li == NX ? r1[ic] + r1[NX + ic] / qr1[ic] + my.gL()[ic] + my.gR()[ic] : 1.0 / qr1[ic];
+  }
+  double afr[KS], bfr[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int kk = 4 * q + lk, k = kk < W ? kk : W - 1;
+    const bool kin = kk < W;
+    const double wk = 1.0 / qr[k];
+    const double av = abm[ri * W + k], zv = r0[NX + k];
+    afr[q] = kin ? av : 0.0;
+    bfr[q] = !kin ? 0.0 : (li < NX ? av * wk : (li == NX ? zv * wk : 0.0));
+  }
+  acc4 c0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = lk + 4 * g;
     double v = 0.0;
-    if (li < NX && i < NX) {
-      v = -(my.DL()[ic * NX + ri] + my.DR()[ic * NX + ri]);
-      if (i == li) v += 1.0 / qr1[ic];
+    if (i < NX) {
+      if (li < NX) v = (i == li ? extra[g] : 0.0) - dlr[g];
+      else if (li == NX) v = -extra[g];
     }
     c0[g] = v;
   }
 #pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    const int kk = 4 * q + lk, k = kk < W ? kk : W - 1;
-    const double af = kk < W ? abm[ri * W + k] : 0.0;
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, af / qr[k], c0, 0, 0, 0);
-  }
+  for (int q = 0; q < KS; ++q) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[q], bfr[q], c0, 0, 0, 0);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int i = lk + 4 * g;
-    if (i < NX && li < NX) scr[i * SP + li] = c0[g];
+    if (i < NX) {
+      if (li < NX) scr[i * SP + li] = c0[g];
+      else if (li == NX) out.X[i * LD + 2 * NX] = c0[g];
+    }
   }
-  // panel [r_a | r_bb | b~]
-  for (int e = lane; e < NN; e += 64) {
-    const int i = e / NX, j = e - i * NX;
-    out.X[i * LD + j] = hasA ? -my.CA()[e] : 0.0;
-    out.X[i * LD + NX + j] = hasB ? -my.CB()[e] : 0.0;
-  }
-  {
-    const double zxu = lane < W ? leaf_rhs_entry<NX, NU>(d, b, s, NX + lane, QR, rhs) : 0.0;
-    double accz = -leaf_rhs_entry<NX, NU>(d, b, s + 1, rc, QR, rhs);
+  // panel columns [r_a | r_bb]
 #pragma unroll
-    for (int k = 0; k < W; ++k) accz = fma(abm[rc * W + k], readlane_f64(zxu, k), accz);
-    accz -= leaf_rhs_entry<NX, NU>(d, b, s + 1, NX + rc, QR, rhs);
-    accz -= my.gL()[rc] + my.gR()[rc];
-    if (lane < NX) out.X[lane * LD + 2 * NX] = accz;
+  for (int q = 0; q < QP; ++q) {
+    const int e = lane + 64 * q;
+    if (e < NN) {
+      const int i = e / NX, j = e - i * NX;
+      out.X[i * LD + j] = hasA ? -pca[q] : 0.0;
+      out.X[i * LD + NX + j] = hasB ? -pcb[q] : 0.0;
+    }
   }
   wave_lds_sync();
   const int grp = lane / NX, gi = lane - grp * NX;
@@ -524,9 +547,11 @@ __global__ __launch_bounds__(64) void reduced_level(Dims d, int l, const double*
           else if (hasA) { if (leftchild) sb.CA()[c * NX + r] = v; else sa.CB()[r * NX + c] = v; }
         });
   };
-  const bool bad = factor_solve<NX, false, false, 0>(lane, acc, out, Lrow,
+  SEG(9);
+  const bool bad = factor_solve<NX, false, false, 8>(lane, acc, out, Lrow,
                                                      store_l ? Fblk(F, d, b, l, s + 1) : nullptr, hook);
   if (bad && lane == 0) flag_failure(info, d, b);
+  SEG(13);  // re-arms the clock after factor_solve's own marks
 
   double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
   if (grp < 2) {
@@ -539,6 +564,10 @@ __global__ __launch_bounds__(64) void reduced_level(Dims d, int l, const double*
   } else if (grp == 2) {
     myrec[2 * NN + gi] = out.X[gi * LD + 2 * NX];
   }
+#ifdef NDLQR_SEGTIME
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SEG(12);
 }
 
 // ------------------------------------------------------------------------------------- row update helpers

@@ -22,6 +22,8 @@ SEGLIB = os.path.join(ROOT, "rslqr_amd", "librslqr_amd_seg.so")
 NAMES = {0: "level: stage operands", 1: "level core: P1", 2: "level core: P2 (Cholesky)",
          3: "level core: P3 (substitutions)", 6: "level: (re-arm)", 4: "level: record stores",
          5: "level: boundary Schur rows",
+         9: "reduced: assemble (loads, S-bar tile, panel)", 10: "reduced: Cholesky", 11: "reduced: substitutions + Gram pushes",
+         13: "reduced: (re-arm)", 12: "reduced: record stores + drain",
          17: "bottom core: P1", 18: "bottom core: P2", 19: "bottom core: P3",
          20: "bottom: stage AB", 21: "bottom: leaf", 22: "bottom: publish + barrier",
          23: "bottom: separator (owner) / skip", 24: "bottom: barrier after separator",
