@@ -5,6 +5,7 @@
 #include "hip_context.hpp"
 #include "kernels_leaf.hpp"
 #include "kernels_small.hpp"
+#include "kernels_bottom_reduced.hpp"
 
 // Size-specialised launch sequence. Levels below J: one separator + one Schur launch each.
 // Levels J..K-1 ("boundary-first"): separator + Schur on the two boundary knots of every subtree
@@ -47,7 +48,13 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   // 12x12 blocks instead of handing knot rows over
   if constexpr (!STRICT && !KEEP && ndlqr::P1OnMatrixCores<NX, NU>::value) {
     if (lean && c->reduced && JB == 2 && d.K > 2 && c->red) {
-      launch_bottom<NX, NU, STRICT, KEEP, 2, true>(c, true);
+      if (c->bottom_reduced) {
+        ScopedSlot t(c, SLOT_BOTTOM);
+        hipLaunchKernelGGL((ndlqr::bottom_reduced<NX, NU>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream, d, c->AB,
+                           c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+      } else {
+        launch_bottom<NX, NU, STRICT, KEEP, 2, true>(c, true);
+      }
       for (int l = 2; l < d.K; ++l) {
         ScopedSlot t(c, SLOT_UPPER);
         hipLaunchKernelGGL((ndlqr::reduced_level<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
