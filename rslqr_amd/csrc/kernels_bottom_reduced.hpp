@@ -261,4 +261,482 @@ __global__ __launch_bounds__(64, 4) void bottom_reduced(Dims d, const double* __
   SEG(22);
 }
 
+// ===================================================================================== matrix-core core
+// Second form of the separator core, used by bottom_reduced_mc / reduced_level_mc: only the
+// Cholesky of S-bar and the inverse W = L^-1 of its factor run on the vector ALU (row / column per
+// lane, v_readlane broadcasts; step j broadcasts row j of L once and uses it for both); the two
+// substitutions become 16x16x4 matrix-core products
+//     Y = W [r_a | b~ | r_bb]        X = W' Y
+// and the Gram blocks Y'Y take Y straight from the accumulator registers: component q of lane
+// (li, lk) of a v_mfma_f64_16x16x4_f64 result is element (4 q + lk, li) -- exactly the element that
+// lane supplies in k-step q when the tile is the B operand (or, transposed, the A operand) of the
+// next product. No panel in LDS, no re-filing; LDS only transposes S-bar (accumulator layout ->
+// one row per lane) and W (one column per lane -> operand layout). Per separator about 160
+// v_readlane + 130 FMAs instead of 420 + 235, the rest on the matrix pipe.
+// Everything is written branch-free: loads are unconditional with clamped indices, the tiles are
+// padded to 16 x 16 in LDS (pad rows / columns of W are zero, so padding never reaches a result),
+// conditions only select values.
+template <int NX>
+struct alignas(16) McScratch {
+  static constexpr int SP = 18, WP = 17;
+  double scr[16 * SP];  // S-bar tile, row i at scr + i * SP
+  double W[16 * WP];    // W = L^-1, zero outside the leading NX x NX block
+  // rows NX..15 of W are zeroed once; the core only rewrites rows < NX
+  __device__ __forceinline__ void init(const int lane) {
+#pragma unroll
+    for (int e0 = 0; e0 < (16 - NX) * WP; e0 += 64) {
+      const int e = e0 + lane;
+      if (e < (16 - NX) * WP) W[NX * WP + e] = 0.0;
+    }
+  }
+};
+
+// c: [S-bar | b~] tile (column NX = rhs). ra / rb: B-operand fragments of r_a / r_bb, i.e.
+// ra[q] = r_a(4 q + lk, li) (any finite value outside the block). On return X0 = [f_a | z_sep],
+// X1 = [f_bb] in accumulator layout. hook(Y0, Y1) runs between the two products.
+template <int NX, class Hook>
+__device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
+                                                const double (&rb)[(NX + 3) / 4], McScratch<NX>& m,
+                                                double* lstore, acc4_t& X0, acc4_t& X1, Hook hook) {
+  constexpr int KS = (NX + 3) / 4, SP = McScratch<NX>::SP, WP = McScratch<NX>::WP;
+  // the lane id is made opaque here so that the lane predicates of one core are recomputed (one
+  // v_cmp) instead of being kept in scalar registers across the whole kernel (spills)
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  const int li = lane & 15, lk = lane >> 4, gi = lane % NX;
+  SEG_INIT();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) m.scr[(lk + 4 * g) * SP + li] = c[g];
+  wave_lds_sync();
+  double acc[NX], w[NX];
+  if constexpr (NX % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < NX; j += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(&m.scr[gi * SP + j]);
+      acc[j] = t.x; acc[j + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = m.scr[gi * SP + j];
+  }
+  // Left-looking Cholesky, one row per lane, fused with the forward substitution of the unit
+  // vectors (lane c < NX: column c of W = L^-1)
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    double v = acc[j], sacc = (j == lane) ? 1.0 : 0.0;  // lanes >= NX: zero columns (the padding of W)
+    // row j of L, broadcast in groups of three: each value feeds the row's own elimination and the
+    // column of W; the scheduling barriers keep the two uses next to the broadcast (otherwise the
+    // compiler defers the W updates and parks the broadcasts in spill lanes)
+#pragma unroll
+    for (int k0 = 0; k0 < j; k0 += 3) {
+#pragma unroll
+      for (int k = k0; k < k0 + 3 && k < j; ++k) {
+        const double bc = readlane_f64(acc[k], j);
+        v = fma(-acc[k], bc, v);
+        sacc = fma(-bc, w[k], sacc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const double pivot = readlane_f64(v, j);
+    bad |= !(pivot > 0.0);  // no short-circuit: the loop body stays one basic block
+    const double rinv = rsqrt(pivot);
+    acc[j] = v * rinv;
+    w[j] = sacc * rinv;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  SEG(30);
+  {  // every lane stores (lanes >= 16 their zeros into the pad column): a store under a lane
+     // predicate makes the compiler sink the whole W recurrence behind it, away from the broadcasts
+    const int wc = lane < 16 ? lane : 16;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) m.W[r * WP + wc] = w[r];
+  }
+  if (lstore && lane < NX) store_row<NX>(lstore + gi * NX, acc);
+  wave_lds_sync();
+  double wa[KS], wt[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    wa[q] = m.W[li * WP + 4 * q + lk];    // A(i, k) = W(i, k)
+    wt[q] = m.W[(4 * q + lk) * WP + li];  // A(i, k) = W(k, i)
+  }
+  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+  acc4_t Y0 = zero, Y1 = zero;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    // columns beyond the blocks carry finite don't-cares: they only reach tile elements nobody reads
+    const double b0 = li == NX ? c[q] : ra[q];
+    Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], b0, Y0, 0, 0, 0);
+    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], rb[q], Y1, 0, 0, 0);
+  }
+  SEG(31);
+  hook(Y0, Y1);
+  SEG(32);
+  X0 = zero; X1 = zero;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y0[q], X0, 0, 0, 0);
+    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y1[q], X1, 0, 0, 0);
+  }
+  SEG(33);
+  return bad;
+}
+
+// Gram tiles of Y = [Y0 | Y1] (accumulator layout in, accumulator layout out):
+//   g00 = Y0'Y0   g01 = Y0'Y1   g10 = Y1'Y0   g11 = Y1'Y1
+template <int NX, bool N00, bool N01, bool N10, bool N11>
+__device__ __forceinline__ void gram_mc(const acc4_t& Y0, const acc4_t& Y1, acc4_t& g00, acc4_t& g01, acc4_t& g10,
+                                        acc4_t& g11) {
+  constexpr int KS = (NX + 3) / 4;
+  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+  g00 = zero; g01 = zero; g10 = zero; g11 = zero;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    if constexpr (N00) g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y0[q], Y0[q], g00, 0, 0, 0);
+    if constexpr (N01) g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y0[q], Y1[q], g01, 0, 0, 0);
+    if constexpr (N10) g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y1[q], Y0[q], g10, 0, 0, 0);
+    if constexpr (N11) g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y1[q], Y1[q], g11, 0, 0, 0);
+  }
+}
+
+// record f_a | f_bb | z_sep of separator s from the solved tiles
+template <int NX>
+__device__ __forceinline__ void store_record_mc(double* __restrict__ myrec, const int lane, const bool ha,
+                                                const bool hb, const acc4_t& X0, const acc4_t& X1) {
+  constexpr int NN = NX * NX;
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = lk + 4 * g;
+    if (r < NX) {
+      if (li < NX) {
+        if (ha) myrec[r * NX + li] = X0[g];
+        if (hb) myrec[NN + r * NX + li] = X1[g];
+      } else if (li == NX) {
+        myrec[2 * NN + r] = X0[g];
+      }
+    }
+  }
+}
+
+// [S-bar | b~] of a separator from the problem data staged in LDS, as ONE 16x16 tile: column NX of
+// the B operand carries the leaf-phase rhs of knot s.
+//   am: [A_s | B_s] (row pitch WP), q0: 1 / [Q_s | R_s], q1: 1 / Q_{s+1}, z0: rhs(s), z1: rhs(s+1).
+// first: s == 0 -- knot 0 has its state fixed: its state columns drop out of S-bar and carry x0 in
+// the rhs (leaf phase of knot 0, src/nested_dissection.c:24-59). init(g): what else goes into
+// element (lk + 4 g, li) (the pushed blocks of an upper level).
+template <int NX, int NU, int WP, class Init>
+__device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first, const double* am, const double* q0,
+                                               const double* q1, const double* z0, const double* z1, Init init) {
+  constexpr int W = NX + NU, KS = (W + 3) / 4;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ri = li < NX ? li : NX - 1;  // rows / columns >= NX of a tile are padding: any finite data
+  acc4_t c;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+    const double w1 = q1[ic], za = z1[ic], zb = z1[NX + ic];
+    // rows / columns beyond the block: finite don't-cares
+    c[g] = (li == NX ? -fma(zb, w1, za) : ((i == li) ? w1 : 0.0)) + init(g);
+  }
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int kq = 4 * q + lk, k = kq < W ? kq : W - 1;
+    const bool kin = kq < W, fx = first && k < NX;
+    const double av = am[ri * WP + k], wk = q0[k], zraw = z0[fx ? k : NX + k];
+    const double sv = fx ? 0.0 : av * wk;      // S-bar columns
+    const double zc = fx ? -zraw : zraw * wk;  // rhs column
+    const double bsel = li == NX ? zc : sv;
+    if constexpr (W % 4 == 0) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bsel, c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? av : 0.0, bsel, c, 0, 0, 0);
+  }
+  return c;
+}
+
+//   grid (N / 4, batch), block 64; N >= 8; instances with matrix-core products only.
+template <int NX, int NU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bottom_reduced_mc(Dims d, const double* __restrict__ AB,
+                                                           const double* __restrict__ QR,
+                                                           const double* __restrict__ rhs, double* red,
+                                                           double* __restrict__ rec, double* F,
+                                                           int* __restrict__ info, const int store_l) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
+  constexpr int REC = 2 * NN + NX;
+  // row pitch of the staged [A | B]: even W padded by two doubles so that the 16 rows an operand
+  // fragment touches fall into distinct LDS banks
+  constexpr int WP = (W % 2 == 0) ? W + 2 : W;
+  // the staged [A | B] is dead once the leaf tiles and coupling fragments are in registers: the
+  // core's scratch lies over it
+  constexpr int NBUF = 4 * NX * WP > (int)(sizeof(McScratch<NX>) / 8) ? 4 * NX * WP : (int)(sizeof(McScratch<NX>) / 8);
+  __shared__ __attribute__((aligned(16))) double buf[NBUF];
+  double* abs_ = buf;                                          // [A | B] of the four knots
+  McScratch<NX>& m = *reinterpret_cast<McScratch<NX>*>(buf);
+  __shared__ double rq[4 * W];      // 1 / [Q | R] of the four knots
+  __shared__ double rh[4 * ROWS];   // their raw right-hand sides
+  const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = blockIdx.x * 4;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ri = li < NX ? li : NX - 1;
+  const bool hasA = k0 > 0, hasB = k0 + 4 < N;  // separators k0 - 1 / k0 + 3 exist
+  SEG_INIT();
+
+  // ---- the wavefront's whole input (6.9 KB at (12, 4)) in ONE round of coalesced loads -- every
+  //      load is issued before the first one is waited for --, staged in LDS; the operand fragments
+  //      of the matrix-core products are gathered from there
+  {
+    const double* abm = AB + ((size_t)b * N + k0) * NX * W;  // four knots, contiguous, 16-byte aligned
+    const double* q0 = QR + ((size_t)b * N + k0) * W;
+    const double* r0 = rhs + ((size_t)b * N + k0) * ROWS;
+    constexpr int NQ = 4 * W, IQ = (NQ + 63) / 64, NR = 4 * ROWS, IR = (NR + 63) / 64;
+    double qv[IQ], rv[IR];
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; qv[it] = q0[e < NQ ? e : NQ - 1]; }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; rv[it] = r0[e < NR ? e : NR - 1]; }
+    if constexpr (W % 2 == 0) {
+      constexpr int NA = 4 * NX * W / 2, IA = (NA + 63) / 64;
+      double2 t[IA];
+#pragma unroll
+      for (int it = 0; it < IA; ++it) {
+        const int e = lane + 64 * it;
+        t[it] = reinterpret_cast<const double2*>(abm)[e < NA ? e : NA - 1];
+      }
+#pragma unroll
+      for (int it = 0; it < IA; ++it) {
+        const int e = lane + 64 * it, row = e / (W / 2), c2 = e - row * (W / 2);
+        if (e < NA) reinterpret_cast<double2*>(&abs_[row * WP])[c2] = t[it];
+      }
+    } else {
+      constexpr int NA = 4 * NX * W, IA = (NA + 63) / 64;
+      double t[IA];
+#pragma unroll
+      for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; t[it] = abm[e < NA ? e : NA - 1]; }
+#pragma unroll
+      for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; if (e < NA) abs_[e] = t[it]; }
+    }
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) {
+      const int e = lane + 64 * it, kn = e / W, c = e - kn * W;
+      if (e < NQ) {
+        rq[e] = 1.0 / qv[it];
+        if (!(qv[it] > 0.0) && !(k0 + kn == N - 1 && c >= NX)) flag_failure(info, d, b);  // terminal R is unused
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; if (e < NR) rh[e] = rv[it]; }
+  }
+  wave_lds_sync();
+  SEG(20);
+
+  auto none = [](int) { return 0.0; };
+  acc4_t c_s0 = leaf_tile_mc<NX, NU, WP>(lane, k0 == 0, abs_, rq, rq + W, rh, rh + ROWS, none);
+  acc4_t c_t = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + NX * WP, rq + W, rq + 2 * W, rh + ROWS, rh + 2 * ROWS, none);
+  acc4_t c_s2 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + 2 * NX * WP, rq + 2 * W, rq + 3 * W, rh + 2 * ROWS,
+                                         rh + 3 * ROWS, none);
+  // operand fragments of the couplings: r_a(i, j) = -A_s(i, j) / Q_s(j), r_bb(i, j) = -A_{s+1}(j, i) / Q_{s+1}(i)
+  double ra0[KSN], rb0[KSN], ra2[KSN], rb2[KSN];
+#pragma unroll
+  for (int q = 0; q < KSN; ++q) {
+    const int kq = 4 * q + lk, i = kq < NX ? kq : NX - 1;
+    const double a0 = abs_[i * WP + ri], b0 = abs_[(NX + ri) * WP + i];
+    const double a2 = abs_[(2 * NX + i) * WP + ri], b2 = abs_[(3 * NX + ri) * WP + i];
+    const double s0 = rq[ri], s1 = rq[W + i], s2 = rq[2 * W + ri], s3 = rq[3 * W + i];
+    ra0[q] = hasA ? -a0 * s0 : 0.0;
+    rb0[q] = -b0 * s1;
+    ra2[q] = -a2 * s2;
+    rb2[q] = hasB ? -b2 * s3 : 0.0;
+  }
+  wave_lds_sync();  // last read of the staged [A | B]
+  m.init(lane);
+  SEG(21);
+
+  acc4_t X0, X1, unused;
+  double* myrec = rec + ((size_t)b * N + k0) * REC;
+
+  // ---- s0 = k0 (level 0, left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
+  acc4_t park_a, ca_t;
+  if (factor_solve_mc<NX>(lane, c_s0, ra0, rb0, m, store_l ? Fblk(F, d, b, 0, k0 + 1) : nullptr, X0, X1,
+                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                            acc4_t g11;
+                            gram_mc<NX, true, false, true, true>(Y0, Y1, park_a, unused, ca_t, g11);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
+                          }) &&
+      lane == 0)
+    flag_failure(info, d, b);
+  SEG(34);  // re-arms the clock after the core's own marks
+  store_record_mc<NX>(myrec, lane, hasA, true, X0, X1);
+  SEG(35);
+
+  // ---- s2 = k0 + 2 (level 0, right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
+  acc4_t park_b11, cb_t;
+  if (factor_solve_mc<NX>(lane, c_s2, ra2, rb2, m, store_l ? Fblk(F, d, b, 0, k0 + 3) : nullptr, X0, X1,
+                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                            acc4_t g00;
+                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, cb_t, unused, park_b11);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
+                          }) &&
+      lane == 0)
+    flag_failure(info, d, b);
+  SEG(34);
+  store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
+  SEG(35);
+
+  // ---- t = k0 + 1 (level 1): r_a = -CA[t] = -Y_bb'Y_a of s0, r_bb = -CB[t] = -Y_a'Y_bb of s2;
+  //      pushes of the whole group to the separators k0 - 1 (A) and k0 + 3 (B)
+  double rat[KSN], rbt[KSN];
+#pragma unroll
+  for (int q = 0; q < KSN; ++q) { rat[q] = -ca_t[q]; rbt[q] = -cb_t[q]; }
+  const bool leftchild = (k0 & 4) == 0;
+  const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
+  const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
+  if (factor_solve_mc<NX>(lane, c_t, rat, rbt, m, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr, X0, X1,
+                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                            acc4_t g00, g01, g11;
+                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                              const int r = lk + 4 * g;
+                              if (hasA && r < NX && li <= NX) {
+                                const double v = g00[g] + park_a[g];
+                                if (li < NX) sa.DR()[r * NX + li] = v; else sa.gR()[r] = v;
+                              }
+                              if (hasB && li < NX) {
+                                if (r < NX) {
+                                  sb.DL()[r * NX + li] = g11[g] + park_b11[g];
+                                  if (hasA) { if (leftchild) sb.CA()[li * NX + r] = g01[g]; else sa.CB()[r * NX + li] = g01[g]; }
+                                } else if (r == NX) {
+                                  sb.gL()[li] = g01[g] + cb_t[g];
+                                }
+                              }
+                            }
+                          }) &&
+      lane == 0)
+    flag_failure(info, d, b);
+  SEG(34);
+  store_record_mc<NX>(myrec + REC, lane, hasA, hasB, X0, X1);
+#ifdef NDLQR_SEGTIME
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SEG(36);
+}
+
+// One upper level of the separator-only schedule on the matrix-core core (see reduced_level).
+//   grid (N >> (l+1), batch), block 64; l >= 2.
+template <int NX, int NU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void reduced_level_mc(Dims d, int l, const double* __restrict__ AB,
+                                                          const double* __restrict__ QR,
+                                                          const double* __restrict__ rhs, double* red,
+                                                          double* __restrict__ rec, double* F,
+                                                          int* __restrict__ info, const int store_l) {
+  constexpr int W = NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
+  constexpr int WP = (W % 2 == 0) ? W + 2 : W, SLOT = RedSlot<NX>::SIZE;
+  // slot and [A | B] are dead once the tile and the coupling fragments are in registers: the
+  // core's scratch lies over them
+  constexpr int NIN = SLOT + NX * WP, NSC = (int)(sizeof(McScratch<NX>) / 8), NBUF = NIN > NSC ? NIN : NSC;
+  __shared__ __attribute__((aligned(16))) double buf[NBUF];
+  double* slot = buf;          // DL | DR | CA | CB | gL | gR of this separator
+  double* abs_ = buf + SLOT;   // [A_s | B_s]
+  McScratch<NX>& m = *reinterpret_cast<McScratch<NX>*>(buf);
+  __shared__ double rq[W + NX];                               // 1 / [Q_s | R_s], 1 / Q_{s+1}
+  __shared__ double zs[NX + W + 2 * NX];                      // rhs(s), rhs(s+1).lambda | x
+  const int lane = threadIdx.x, b = blockIdx.y, N = d.N;
+  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
+  const bool hasA = base > 0, hasB = base + T < N;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ri = li < NX ? li : NX - 1;
+  SEG_INIT();
+
+  // ---- ONE round of coalesced loads into LDS (the slot is contiguous and 16-byte aligned); the
+  //      operand fragments are gathered from there. (Knots s and s+1 of a level >= 2 are never the
+  //      first or the last knot: no special cases.)
+  {
+    const double* sl = red_slot<NX>(red, d, b, s).p;
+    const double* abm = AB + ((size_t)b * N + s) * NX * W;
+    const double* qr = QR + ((size_t)b * N + s) * W;             // knot s: W entries, then the Q of knot s + 1
+    const double* r0 = rhs + ((size_t)b * N + s) * (2 * NX + NU);  // rhs(s) | rhs(s+1).lambda | rhs(s+1).x
+    constexpr int NS = SLOT / 2, IS = (NS + 63) / 64, NA = NX * W, IA = (NA + 63) / 64;
+    constexpr int NQ = W + NX, IQ = (NQ + 63) / 64, NR = NX + W + 2 * NX, IR = (NR + 63) / 64;
+    static_assert(SLOT % 2 == 0, "slot copied as 16-byte words");
+    double2 ts[IS];
+    double ta[IA], tq[IQ], tr[IR];
+#pragma unroll
+    for (int it = 0; it < IS; ++it) {
+      const int e = lane + 64 * it;
+      ts[it] = reinterpret_cast<const double2*>(sl)[e < NS ? e : NS - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; ta[it] = abm[e < NA ? e : NA - 1]; }
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; tq[it] = qr[e < NQ ? e : NQ - 1]; }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; tr[it] = r0[e < NR ? e : NR - 1]; }
+#pragma unroll
+    for (int it = 0; it < IS; ++it) { const int e = lane + 64 * it; if (e < NS) reinterpret_cast<double2*>(slot)[e] = ts[it]; }
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+      const int e = lane + 64 * it, row = e / W, c = e - row * W;
+      if (e < NA) abs_[row * WP + c] = ta[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; if (e < NQ) rq[e] = 1.0 / tq[it]; }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; if (e < NR) zs[e] = tr[it]; }
+  }
+  wave_lds_sync();
+  const double *DL = slot, *DR = slot + NN, *CA = slot + 2 * NN, *CB = slot + 3 * NN;
+  const double *gL = slot + 4 * NN, *gR = slot + 4 * NN + NX;
+
+  // [S-bar | b~] = leaf tile - DL - DR | - gL - gR
+  double ra[KSN], rb[KSN];
+#pragma unroll
+  for (int q = 0; q < KSN; ++q) {
+    const int kq = 4 * q + lk, i = kq < NX ? kq : NX - 1;
+    const double ca = CA[i * NX + ri], cb = CB[i * NX + ri];
+    ra[q] = hasA ? -ca : 0.0;
+    rb[q] = hasB ? -cb : 0.0;
+  }
+  const acc4_t c0 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_, rq, rq + W, zs, zs + NX + W, [&](int g) {
+    const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+    const double dd = DL[ic * NX + ri] + DR[ic * NX + ri], gg = gL[ic] + gR[ic];
+    return -(li == NX ? gg : dd);
+  });
+  wave_lds_sync();  // last read of the staged operands
+  m.init(lane);
+  SEG(9);
+
+  const bool leftchild = (base & T) == 0;
+  const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
+  const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
+  acc4_t X0, X1, unused;
+  if (factor_solve_mc<NX>(lane, c0, ra, rb, m, store_l ? Fblk(F, d, b, l, s + 1) : nullptr, X0, X1,
+                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                            acc4_t g00, g01, g11;
+                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                              const int r = lk + 4 * g;
+                              if (hasA && r < NX && li <= NX) {
+                                if (li < NX) atomicAdd(sa.DR() + r * NX + li, g00[g]); else atomicAdd(sa.gR() + r, g00[g]);
+                              }
+                              if (hasB && li < NX) {
+                                if (r < NX) {
+                                  atomicAdd(sb.DL() + r * NX + li, g11[g]);
+                                  if (hasA) { if (leftchild) sb.CA()[li * NX + r] = g01[g]; else sa.CB()[r * NX + li] = g01[g]; }
+                                } else if (r == NX) {
+                                  atomicAdd(sb.gL() + li, g01[g]);
+                                }
+                              }
+                            }
+                          }) &&
+      lane == 0)
+    flag_failure(info, d, b);
+  SEG(13);
+  store_record_mc<NX>(rec + ((size_t)b * N + s) * (2 * NN + NX), lane, hasA, hasB, X0, X1);
+#ifdef NDLQR_SEGTIME
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SEG(12);
+}
+
 }  // namespace ndlqr

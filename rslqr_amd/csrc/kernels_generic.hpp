@@ -54,7 +54,7 @@ __device__ __forceinline__ bool chol16_and_inverse(double* Sblk, const int ns, d
     for (int k = 0; k < j; ++k) v = fma(-acc[k], readlane_f64(acc[k], j), v);
     acc[j] = v;
     const double pivot = readlane_f64(acc[j], j);
-    bad = bad || !(pivot > 0.0);
+    bad |= !(pivot > 0.0);  // no short-circuit: keeps the pivot loop one basic block
     const double rinv = rsqrt(pivot);
     acc[j] = acc[j] * rinv;
     rinvs[j] = rinv;

@@ -115,7 +115,7 @@ __device__ __forceinline__ bool factor_solve(const int lane, double (&acc)[NX], 
     for (int k = 0; k < j; ++k) v = mad<STRICT>(-acc[k], readlane_f64(acc[k], j), v);
     if constexpr (KEEPL) { if (gi >= j) acc[j] = v; } else { acc[j] = v; }
     const double pivot = readlane_f64(acc[j], j);
-    bad = bad || !(pivot > 0.0);
+    bad |= !(pivot > 0.0);  // no short-circuit: keeps the pivot loop one basic block
     if constexpr (STRICT) {
       const double root = sqrt(pivot);
       if constexpr (KEEPL) { if (gi >= j) acc[j] = acc[j] / root; } else { acc[j] = acc[j] / root; }

@@ -50,15 +50,24 @@ static int launch_small(NdlqrHipCtx* c, int J) {
     if (lean && c->reduced && JB == 2 && d.K > 2 && c->red) {
       if (c->bottom_reduced) {
         ScopedSlot t(c, SLOT_BOTTOM);
-        hipLaunchKernelGGL((ndlqr::bottom_reduced<NX, NU>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream, d, c->AB,
-                           c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+        if (c->mcore)
+          hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU>), dim3(d.N >> 2, d.batch), dim3(64),
+                             (size_t)c->bottom_lds_pad, c->stream, d,
+                             c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+        else
+          hipLaunchKernelGGL((ndlqr::bottom_reduced<NX, NU>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream, d,
+                             c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
       } else {
         launch_bottom<NX, NU, STRICT, KEEP, 2, true>(c, true);
       }
       for (int l = 2; l < d.K; ++l) {
         ScopedSlot t(c, SLOT_UPPER);
-        hipLaunchKernelGGL((ndlqr::reduced_level<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
-                           c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+        if (c->mcore)
+          hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
+                             d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+        else
+          hipLaunchKernelGGL((ndlqr::reduced_level<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d,
+                             l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
       }
       ScopedSlot t(c, SLOT_APPLY);
       hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,

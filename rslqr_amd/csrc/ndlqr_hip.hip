@@ -70,6 +70,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr;
   c->reduced = getenv("NDLQR_REDUCED") ? atoi(getenv("NDLQR_REDUCED")) != 0 : true;
+  c->mcore = getenv("NDLQR_MCORE") ? atoi(getenv("NDLQR_MCORE")) != 0 : true;
   c->bottom_reduced = getenv("NDLQR_BOTTOM_REDUCED") ? atoi(getenv("NDLQR_BOTTOM_REDUCED")) != 0 : true;
   c->fuse_level = getenv("NDLQR_FUSE_LEVEL") ? atoi(getenv("NDLQR_FUSE_LEVEL")) : -1;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;

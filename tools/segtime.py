@@ -27,6 +27,9 @@ NAMES = {0: "level: stage operands", 1: "level core: P1", 2: "level core: P2 (Ch
          17: "bottom core: P1", 18: "bottom core: P2", 19: "bottom core: P3",
          20: "bottom: stage AB", 21: "bottom: leaf", 22: "bottom: publish + barrier",
          23: "bottom: separator (owner) / skip", 24: "bottom: barrier after separator",
+         30: "mc core: S-bar rows, Cholesky + inverse", 31: "mc core: W to operands, Y = W R",
+         32: "mc core: hook (Gram tiles, pushes)", 33: "mc core: X = W'Y", 34: "mc: (re-arm)",
+         35: "bottom_mc: record store", 36: "bottom_mc: last record store + drain",
          25: "bottom: row update + rotate", 26: "bottom: barrier end of level", 27: "bottom: hand-off"}
 
 
