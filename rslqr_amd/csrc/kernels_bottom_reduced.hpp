@@ -325,22 +325,22 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
 #pragma unroll
   for (int j = 0; j < NX; ++j) {
     double v = acc[j], sacc = (j == lane) ? 1.0 : 0.0;  // lanes >= NX: zero columns (the padding of W)
-    // row j of L, broadcast in groups of three: each value feeds the row's own elimination and the
-    // column of W; the scheduling barriers keep the two uses next to the broadcast (otherwise the
-    // compiler defers the W updates and parks the broadcasts in spill lanes)
+    // row j of L, broadcast once: each value feeds the row's own elimination and the column of W.
+    // (Reading the row back from LDS instead -- an LDS broadcast read is no vector-ALU instruction --
+    // was measured: fewer instructions but the per-step round trip is exposed, 10 % slower.)
 #pragma unroll
-    for (int k0 = 0; k0 < j; k0 += 3) {
-#pragma unroll
-      for (int k = k0; k < k0 + 3 && k < j; ++k) {
-        const double bc = readlane_f64(acc[k], j);
-        v = fma(-acc[k], bc, v);
-        sacc = fma(-bc, w[k], sacc);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < j; ++k) {
+      const double bc = readlane_f64(acc[k], j);
+      v = fma(-acc[k], bc, v);
+      sacc = fma(-bc, w[k], sacc);
     }
     const double pivot = readlane_f64(v, j);
     bad |= !(pivot > 0.0);  // no short-circuit: the loop body stays one basic block
-    const double rinv = rsqrt(pivot);
+    // 1 / sqrt(pivot): hardware estimate + one third-order correction (what rsqrt() expands to,
+    // without its special-case selects: a non-positive pivot is flagged and may propagate NaN)
+    const double y0 = __builtin_amdgcn_rsq(pivot);
+    const double e = fma(-pivot * y0, y0, 1.0);
+    const double rinv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
     acc[j] = v * rinv;
     w[j] = sacc * rinv;
     __builtin_amdgcn_sched_barrier(0);
@@ -399,21 +399,74 @@ __device__ __forceinline__ void gram_mc(const acc4_t& Y0, const acc4_t& Y1, acc4
   }
 }
 
+// Component g of an accumulator tile holds row lk + 4 g: rows_all(g) -- the row is inside the
+// block for every lane; rows_none(g) -- for no lane (both known at compile time, so that the
+// stores below sit in as few predicated regions as possible).
+template <int NX> __device__ __forceinline__ constexpr bool rows_all(int g) { return 4 * g + 3 < NX; }
+template <int NX> __device__ __forceinline__ constexpr bool rows_none(int g) { return 4 * g >= NX; }
+
 // record f_a | f_bb | z_sep of separator s from the solved tiles
 template <int NX>
 __device__ __forceinline__ void store_record_mc(double* __restrict__ myrec, const int lane, const bool ha,
                                                 const bool hb, const acc4_t& X0, const acc4_t& X1) {
   constexpr int NN = NX * NX;
   const int li = lane & 15, lk = lane >> 4;
+  if (li < NX) {
+    if (ha) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int r = lk + 4 * g;
-    if (r < NX) {
-      if (li < NX) {
-        if (ha) myrec[r * NX + li] = X0[g];
-        if (hb) myrec[NN + r * NX + li] = X1[g];
-      } else if (li == NX) {
-        myrec[2 * NN + r] = X0[g];
+      for (int g = 0; g < 4; ++g) {
+        const int r = lk + 4 * g;
+        if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) myrec[r * NX + li] = X0[g];
+      }
+    }
+    if (hb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = lk + 4 * g;
+        if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) myrec[NN + r * NX + li] = X1[g];
+      }
+    }
+  } else if (li == NX) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = lk + 4 * g;
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) myrec[2 * NN + r] = X0[g];
+    }
+  }
+}
+
+// What a separator contributes to the reduced system of its two neighbours (see reduced_level),
+// from its Gram tiles g00 = Y_a'[Y_a | y_z], g01 = [Y_a | y_z]'Y_bb, g11 = Y_bb'Y_bb plus whatever
+// its children parked (pa, pb01, pb11; zero tiles for none):
+//   A: DR += g00 (columns < NX), gR += g00 (column NX)      B: DL += g11, gL += g01 (row NX)
+//   coupling of the parent to the other neighbour: CA[B] = g01' (left child) or CB[A] = g01.
+// put(p, v): plain store (first writer of the launch) or atomic add.
+template <int NX, class Put>
+__device__ __forceinline__ void push_mc(const int lane, const bool hasA, const bool hasB, const bool leftchild,
+                                        const RedSlot<NX>& sa, const RedSlot<NX>& sb, const acc4_t& g00,
+                                        const acc4_t& g01, const acc4_t& g11, const acc4_t& pa, const acc4_t& pb01,
+                                        const acc4_t& pb11, Put put) {
+  const int li = lane & 15, lk = lane >> 4;
+  if (hasA && li <= NX) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = lk + 4 * g;
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) put(li < NX ? sa.DR() + r * NX + li : sa.gR() + r, g00[g] + pa[g]);
+    }
+  }
+  if (hasB && li < NX) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = lk + 4 * g;
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) put(sb.DL() + r * NX + li, g11[g] + pb11[g]);
+    }
+    if (lk == NX % 4) put(sb.gL() + li, g01[NX / 4] + pb01[NX / 4]);  // row NX of g01: y_z' Y_bb
+    if (hasA) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = lk + 4 * g;
+        if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX))
+          *(leftchild ? sb.CA() + li * NX + r : sa.CB() + r * NX + li) = g01[g];
       }
     }
   }
@@ -594,22 +647,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
                           [&](const acc4_t& Y0, const acc4_t& Y1) {
                             acc4_t g00, g01, g11;
                             gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                              const int r = lk + 4 * g;
-                              if (hasA && r < NX && li <= NX) {
-                                const double v = g00[g] + park_a[g];
-                                if (li < NX) sa.DR()[r * NX + li] = v; else sa.gR()[r] = v;
-                              }
-                              if (hasB && li < NX) {
-                                if (r < NX) {
-                                  sb.DL()[r * NX + li] = g11[g] + park_b11[g];
-                                  if (hasA) { if (leftchild) sb.CA()[li * NX + r] = g01[g]; else sa.CB()[r * NX + li] = g01[g]; }
-                                } else if (r == NX) {
-                                  sb.gL()[li] = g01[g] + cb_t[g];
-                                }
-                              }
-                            }
+                            push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
+                                        [](double* p, double v) { *p = v; });
                           }) &&
       lane == 0)
     flag_failure(info, d, b);
@@ -713,21 +752,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void re
                           [&](const acc4_t& Y0, const acc4_t& Y1) {
                             acc4_t g00, g01, g11;
                             gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                              const int r = lk + 4 * g;
-                              if (hasA && r < NX && li <= NX) {
-                                if (li < NX) atomicAdd(sa.DR() + r * NX + li, g00[g]); else atomicAdd(sa.gR() + r, g00[g]);
-                              }
-                              if (hasB && li < NX) {
-                                if (r < NX) {
-                                  atomicAdd(sb.DL() + r * NX + li, g11[g]);
-                                  if (hasA) { if (leftchild) sb.CA()[li * NX + r] = g01[g]; else sa.CB()[r * NX + li] = g01[g]; }
-                                } else if (r == NX) {
-                                  atomicAdd(sb.gL() + li, g01[g]);
-                                }
-                              }
-                            }
+                            const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+                            push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero,
+                                        [](double* p, double v) { atomicAdd(p, v); });
                           }) &&
       lane == 0)
     flag_failure(info, d, b);
