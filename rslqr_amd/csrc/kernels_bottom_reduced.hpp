@@ -440,12 +440,23 @@ __device__ __forceinline__ void store_record_mc(double* __restrict__ myrec, cons
 // its children parked (pa, pb01, pb11; zero tiles for none):
 //   A: DR += g00 (columns < NX), gR += g00 (column NX)      B: DL += g11, gL += g01 (row NX)
 //   coupling of the parent to the other neighbour: CA[B] = g01' (left child) or CB[A] = g01.
-// put(p, v): plain store (first writer of the launch) or atomic add.
-template <int NX, class Put>
+// put(p, v): store (first writer of the launch) or atomic add; set(p, v): store of a single-writer
+// block (the couplings). Under the tree schedule the stores are write-through (agent-scope
+// relaxed atomic stores, `sc1`): the reader may sit on another XCD, whose L2 is not coherent with
+// the writer's.
+struct StorePlain { __device__ __forceinline__ void operator()(double* p, double v) const { *p = v; } };
+struct StoreThrough {
+  __device__ __forceinline__ void operator()(double* p, double v) const {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+struct AddAtomic { __device__ __forceinline__ void operator()(double* p, double v) const { atomicAdd(p, v); } };
+
+template <int NX, class Put, class Set>
 __device__ __forceinline__ void push_mc(const int lane, const bool hasA, const bool hasB, const bool leftchild,
                                         const RedSlot<NX>& sa, const RedSlot<NX>& sb, const acc4_t& g00,
                                         const acc4_t& g01, const acc4_t& g11, const acc4_t& pa, const acc4_t& pb01,
-                                        const acc4_t& pb11, Put put) {
+                                        const acc4_t& pb11, Put put, Set set) {
   const int li = lane & 15, lk = lane >> 4;
   if (hasA && li <= NX) {
 #pragma unroll
@@ -466,7 +477,7 @@ __device__ __forceinline__ void push_mc(const int lane, const bool hasA, const b
       for (int g = 0; g < 4; ++g) {
         const int r = lk + 4 * g;
         if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX))
-          *(leftchild ? sb.CA() + li * NX + r : sa.CB() + r * NX + li) = g01[g];
+          set(leftchild ? sb.CA() + li * NX + r : sa.CB() + r * NX + li, g01[g]);
       }
     }
   }
@@ -506,26 +517,182 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
   return c;
 }
 
-//   grid (N / 4, batch), block 64; N >= 8; instances with matrix-core products only.
+// LDS of one wavefront working on the reduced system: a buffer that first holds the staged inputs
+// and then, once the tiles and coupling fragments are in registers, the core's scratch; plus the
+// reciprocal weights and right-hand sides of the knots involved. Sized for both users: four knots
+// of the bottom levels, or slot + one knot of an upper level.
 template <int NX, int NU>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bottom_reduced_mc(Dims d, const double* __restrict__ AB,
-                                                           const double* __restrict__ QR,
-                                                           const double* __restrict__ rhs, double* red,
-                                                           double* __restrict__ rec, double* F,
-                                                           int* __restrict__ info, const int store_l) {
+struct alignas(16) ReducedLds {
+  static constexpr int W = NX + NU, ROWS = 2 * NX + NU, WP = (W % 2 == 0) ? W + 2 : W;
+  static constexpr int SLOT = RedSlot<NX>::SIZE, NSC = (int)(sizeof(McScratch<NX>) / 8);
+  static constexpr int NB0 = 4 * NX * WP, NB1 = SLOT + NX * WP;
+  static constexpr int NBUF = (NB0 > NB1 ? NB0 : NB1) > NSC ? (NB0 > NB1 ? NB0 : NB1) : NSC;
+  double buf[NBUF];
+  double rq[4 * W];
+  double rh[4 * ROWS];
+  __device__ __forceinline__ McScratch<NX>& scratch() { return *reinterpret_cast<McScratch<NX>*>(buf); }
+};
+
+// One separator of an upper level (l >= 2) of the separator-only schedule on the matrix-core core
+// (see reduced_level): subtree [base, base + 2^(l+1)) of problem b, by one wavefront.
+// TREE: called from the tree schedule -- the slot was written by wavefronts of this launch, possibly
+// on another XCD: it is read with L1-bypassing (`sc1`) loads and the couplings are stored through.
+template <int NX, int NU, bool TREE>
+__device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l, const int base, const int b,
+                                                     const int lane, const double* __restrict__ AB,
+                                                     const double* __restrict__ QR,
+                                                     const double* __restrict__ rhs, double* red,
+                                                     double* __restrict__ rec, double* F, int* __restrict__ info,
+                                                     const int store_l, ReducedLds<NX, NU>& lds) {
+  constexpr int W = NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
+  constexpr int WP = ReducedLds<NX, NU>::WP, SLOT = RedSlot<NX>::SIZE;
+  // slot and [A | B] are dead once the tile and the coupling fragments are in registers: the
+  // core's scratch lies over them
+  double* slot = lds.buf;          // DL | DR | CA | CB | gL | gR of this separator
+  double* abs_ = lds.buf + SLOT;   // [A_s | B_s]
+  McScratch<NX>& m = lds.scratch();
+  double* rq = lds.rq;             // 1 / [Q_s | R_s], 1 / Q_{s+1}
+  double* zs = lds.rh;             // rhs(s), rhs(s+1).lambda | x
+  static_assert(4 * W >= W + NX && 4 * (2 * NX + NU) >= NX + W + 2 * NX, "shared arrays of the bottom levels are large enough");
+  const int N = d.N;
+  const int T = 2 << l, s = base + (1 << l) - 1;
+  const bool hasA = base > 0, hasB = base + T < N;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ri = li < NX ? li : NX - 1;
+  SEG_INIT();
+
+  // ---- ONE round of coalesced loads into LDS (the slot is contiguous and 16-byte aligned); the
+  //      operand fragments are gathered from there. (Knots s and s+1 of a level >= 2 are never the
+  //      first or the last knot: no special cases.)
+  {
+    const double* sl = red_slot<NX>(red, d, b, s).p;
+    const double* abm = AB + ((size_t)b * N + s) * NX * W;
+    const double* qr = QR + ((size_t)b * N + s) * W;             // knot s: W entries, then the Q of knot s + 1
+    const double* r0 = rhs + ((size_t)b * N + s) * (2 * NX + NU);  // rhs(s) | rhs(s+1).lambda | rhs(s+1).x
+    constexpr int NS = SLOT / 2, IS = (NS + 63) / 64, NA = NX * W, IA = (NA + 63) / 64;
+    constexpr int NQ = W + NX, IQ = (NQ + 63) / 64, NR = NX + W + 2 * NX, IR = (NR + 63) / 64;
+    static_assert(SLOT % 2 == 0, "slot copied as 16-byte words");
+    double2 ts[IS];
+    double ta[IA], tq[IQ], tr[IR];
+#pragma unroll
+    for (int it = 0; it < IS; ++it) {
+      const int e = lane + 64 * it, ec = e < NS ? e : NS - 1;
+      if constexpr (TREE) {
+        ts[it].x = __hip_atomic_load(sl + 2 * ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ts[it].y = __hip_atomic_load(sl + 2 * ec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        ts[it] = reinterpret_cast<const double2*>(sl)[ec];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; ta[it] = abm[e < NA ? e : NA - 1]; }
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; tq[it] = qr[e < NQ ? e : NQ - 1]; }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; tr[it] = r0[e < NR ? e : NR - 1]; }
+#pragma unroll
+    for (int it = 0; it < IS; ++it) { const int e = lane + 64 * it; if (e < NS) reinterpret_cast<double2*>(slot)[e] = ts[it]; }
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+      const int e = lane + 64 * it, row = e / W, c = e - row * W;
+      if (e < NA) abs_[row * WP + c] = ta[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; if (e < NQ) rq[e] = 1.0 / tq[it]; }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; if (e < NR) zs[e] = tr[it]; }
+  }
+  wave_lds_sync();
+  const double *DL = slot, *DR = slot + NN, *CA = slot + 2 * NN, *CB = slot + 3 * NN;
+  const double *gL = slot + 4 * NN, *gR = slot + 4 * NN + NX;
+
+  // [S-bar | b~] = leaf tile - DL - DR | - gL - gR
+  double ra[KSN], rb[KSN];
+#pragma unroll
+  for (int q = 0; q < KSN; ++q) {
+    const int kq = 4 * q + lk, i = kq < NX ? kq : NX - 1;
+    const double ca = CA[i * NX + ri], cb = CB[i * NX + ri];
+    ra[q] = hasA ? -ca : 0.0;
+    rb[q] = hasB ? -cb : 0.0;
+  }
+  const acc4_t c0 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_, rq, rq + W, zs, zs + NX + W, [&](int g) {
+    const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+    const double dd = DL[ic * NX + ri] + DR[ic * NX + ri], gg = gL[ic] + gR[ic];
+    return -(li == NX ? gg : dd);
+  });
+  wave_lds_sync();  // last read of the staged operands
+  m.init(lane);
+  SEG(9);
+
+  const bool leftchild = (base & T) == 0;
+  const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
+  const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
+  acc4_t X0, X1, unused;
+  if (factor_solve_mc<NX>(lane, c0, ra, rb, m, store_l ? Fblk(F, d, b, l, s + 1) : nullptr, X0, X1,
+                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                            acc4_t g00, g01, g11;
+                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
+                            const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+                            if constexpr (TREE)
+                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
+                                          StoreThrough());
+                            else
+                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
+                                          StorePlain());
+                          }) &&
+      lane == 0)
+    flag_failure(info, d, b);
+  SEG(13);
+  store_record_mc<NX>(rec + ((size_t)b * N + s) * (2 * NN + NX), lane, hasA, hasB, X0, X1);
+#ifdef NDLQR_SEGTIME
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SEG(12);
+}
+
+//   grid (N >> (l+1), batch), block 64; l >= 2.
+template <int NX, int NU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void reduced_level_mc(
+    Dims d, int l, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
+    double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l) {
+  __shared__ ReducedLds<NX, NU> lds;
+  reduced_separator_mc<NX, NU, false>(d, l, blockIdx.x * (2 << l), blockIdx.y, threadIdx.x, AB, QR, rhs, red, rec, F,
+                                      info, store_l, lds);
+}
+
+
+//   grid (N / 4, batch), block 64; N >= 8; instances with matrix-core products only.
+// TREE: the wavefront does not stop after its level-1 separator. Every separator of level >= 2 has
+// an arrival counter; a wavefront that has finished a subtree bumps the counter of the parent
+// separator, and the one that arrives second -- both child subtrees are then eliminated and their
+// pushes visible -- goes on to eliminate the parent (reduced_separator_mc), and so on up to the
+// root. Nobody ever waits: the first arriver simply exits. One launch for the whole factorisation
+// instead of 1 + (K - 2); the thinly populated upper levels of one problem overlap with the bottom
+// levels of the next ones. The counters advance by two per solve (tested for parity, never reset).
+// Correct on every placement (write-through pushes, L1-bypassing slot loads, slots padded to whole
+// lines; no fences: an agent-scope fence writes back / invalidates a whole L2 and made this 18 ms),
+// but MEASURED SLOWER than one launch per level (1.07 vs 0.61 ms at (12,4,256)x1024: a climbing
+// wavefront waits for its store acknowledgements, the counter round trip and the slot coming from
+// memory, ~15 us per separator while it holds its SIMD slot) -- kept behind NDLQR_TREE=1.
+// Every accumulator element still receives its additions in a fixed order: its contributors are
+// the separators along one spine of the subtree below it, and each of them finishes its pushes
+// before its parent starts.
+template <int NX, int NU, bool TREE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bottom_reduced_mc(
+    Dims d, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
+    double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l, int* cnt) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
   constexpr int REC = 2 * NN + NX;
   // row pitch of the staged [A | B]: even W padded by two doubles so that the 16 rows an operand
   // fragment touches fall into distinct LDS banks
-  constexpr int WP = (W % 2 == 0) ? W + 2 : W;
+  constexpr int WP = ReducedLds<NX, NU>::WP;
   // the staged [A | B] is dead once the leaf tiles and coupling fragments are in registers: the
   // core's scratch lies over it
-  constexpr int NBUF = 4 * NX * WP > (int)(sizeof(McScratch<NX>) / 8) ? 4 * NX * WP : (int)(sizeof(McScratch<NX>) / 8);
-  __shared__ __attribute__((aligned(16))) double buf[NBUF];
-  double* abs_ = buf;                                          // [A | B] of the four knots
-  McScratch<NX>& m = *reinterpret_cast<McScratch<NX>*>(buf);
-  __shared__ double rq[4 * W];      // 1 / [Q | R] of the four knots
-  __shared__ double rh[4 * ROWS];   // their raw right-hand sides
+  __shared__ ReducedLds<NX, NU> lds;
+  double* abs_ = lds.buf;            // [A | B] of the four knots
+  McScratch<NX>& m = lds.scratch();
+  double* rq = lds.rq;               // 1 / [Q | R] of the four knots
+  double* rh = lds.rh;               // their raw right-hand sides
   const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = blockIdx.x * 4;
   const int li = lane & 15, lk = lane >> 4;
   const int ri = li < NX ? li : NX - 1;
@@ -647,8 +814,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
                           [&](const acc4_t& Y0, const acc4_t& Y1) {
                             acc4_t g00, g01, g11;
                             gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
-                            push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
-                                        [](double* p, double v) { *p = v; });
+                            if constexpr (TREE)
+                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
+                                          StoreThrough(), StoreThrough());
+                            else
+                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
+                                          StorePlain(), StorePlain());
                           }) &&
       lane == 0)
     flag_failure(info, d, b);
@@ -658,112 +829,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   __builtin_amdgcn_s_waitcnt(0);
 #endif
   SEG(36);
-}
 
-// One upper level of the separator-only schedule on the matrix-core core (see reduced_level).
-//   grid (N >> (l+1), batch), block 64; l >= 2.
-template <int NX, int NU>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void reduced_level_mc(Dims d, int l, const double* __restrict__ AB,
-                                                          const double* __restrict__ QR,
-                                                          const double* __restrict__ rhs, double* red,
-                                                          double* __restrict__ rec, double* F,
-                                                          int* __restrict__ info, const int store_l) {
-  constexpr int W = NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
-  constexpr int WP = (W % 2 == 0) ? W + 2 : W, SLOT = RedSlot<NX>::SIZE;
-  // slot and [A | B] are dead once the tile and the coupling fragments are in registers: the
-  // core's scratch lies over them
-  constexpr int NIN = SLOT + NX * WP, NSC = (int)(sizeof(McScratch<NX>) / 8), NBUF = NIN > NSC ? NIN : NSC;
-  __shared__ __attribute__((aligned(16))) double buf[NBUF];
-  double* slot = buf;          // DL | DR | CA | CB | gL | gR of this separator
-  double* abs_ = buf + SLOT;   // [A_s | B_s]
-  McScratch<NX>& m = *reinterpret_cast<McScratch<NX>*>(buf);
-  __shared__ double rq[W + NX];                               // 1 / [Q_s | R_s], 1 / Q_{s+1}
-  __shared__ double zs[NX + W + 2 * NX];                      // rhs(s), rhs(s+1).lambda | x
-  const int lane = threadIdx.x, b = blockIdx.y, N = d.N;
-  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
-  const bool hasA = base > 0, hasB = base + T < N;
-  const int li = lane & 15, lk = lane >> 4;
-  const int ri = li < NX ? li : NX - 1;
-  SEG_INIT();
-
-  // ---- ONE round of coalesced loads into LDS (the slot is contiguous and 16-byte aligned); the
-  //      operand fragments are gathered from there. (Knots s and s+1 of a level >= 2 are never the
-  //      first or the last knot: no special cases.)
-  {
-    const double* sl = red_slot<NX>(red, d, b, s).p;
-    const double* abm = AB + ((size_t)b * N + s) * NX * W;
-    const double* qr = QR + ((size_t)b * N + s) * W;             // knot s: W entries, then the Q of knot s + 1
-    const double* r0 = rhs + ((size_t)b * N + s) * (2 * NX + NU);  // rhs(s) | rhs(s+1).lambda | rhs(s+1).x
-    constexpr int NS = SLOT / 2, IS = (NS + 63) / 64, NA = NX * W, IA = (NA + 63) / 64;
-    constexpr int NQ = W + NX, IQ = (NQ + 63) / 64, NR = NX + W + 2 * NX, IR = (NR + 63) / 64;
-    static_assert(SLOT % 2 == 0, "slot copied as 16-byte words");
-    double2 ts[IS];
-    double ta[IA], tq[IQ], tr[IR];
-#pragma unroll
-    for (int it = 0; it < IS; ++it) {
-      const int e = lane + 64 * it;
-      ts[it] = reinterpret_cast<const double2*>(sl)[e < NS ? e : NS - 1];
+  if constexpr (TREE) {
+    int l = 1, base = k0;  // finished: the level-l separator of subtree [base, base + 2^(l+1))
+    for (;;) {
+      const int T = 2 << l;
+      if (T >= N) break;  // that was the root
+      const bool left = (base & T) == 0;
+      const int p = left ? base + T - 1 : base - 1;  // the parent separator (level l + 1)
+      // every push of this wavefront has left the chip-side caches (write-through stores, atomics)
+      // and is acknowledged before the arrival is counted
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int old = 0;
+      if (lane == 0) old = atomicAdd(cnt + (size_t)b * (N >> 2) + (p >> 2), 1);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if ((old & 1) == 0) break;  // the sibling subtree is still being eliminated: its wavefront goes on
+      asm volatile("" ::: "memory");
+      l = l + 1;
+      base = left ? base : base - T;
+      wave_lds_sync();
+      reduced_separator_mc<NX, NU, true>(d, l, base, b, lane, AB, QR, rhs, red, rec, F, info, store_l, lds);
     }
-#pragma unroll
-    for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; ta[it] = abm[e < NA ? e : NA - 1]; }
-#pragma unroll
-    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; tq[it] = qr[e < NQ ? e : NQ - 1]; }
-#pragma unroll
-    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; tr[it] = r0[e < NR ? e : NR - 1]; }
-#pragma unroll
-    for (int it = 0; it < IS; ++it) { const int e = lane + 64 * it; if (e < NS) reinterpret_cast<double2*>(slot)[e] = ts[it]; }
-#pragma unroll
-    for (int it = 0; it < IA; ++it) {
-      const int e = lane + 64 * it, row = e / W, c = e - row * W;
-      if (e < NA) abs_[row * WP + c] = ta[it];
-    }
-#pragma unroll
-    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; if (e < NQ) rq[e] = 1.0 / tq[it]; }
-#pragma unroll
-    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; if (e < NR) zs[e] = tr[it]; }
   }
-  wave_lds_sync();
-  const double *DL = slot, *DR = slot + NN, *CA = slot + 2 * NN, *CB = slot + 3 * NN;
-  const double *gL = slot + 4 * NN, *gR = slot + 4 * NN + NX;
-
-  // [S-bar | b~] = leaf tile - DL - DR | - gL - gR
-  double ra[KSN], rb[KSN];
-#pragma unroll
-  for (int q = 0; q < KSN; ++q) {
-    const int kq = 4 * q + lk, i = kq < NX ? kq : NX - 1;
-    const double ca = CA[i * NX + ri], cb = CB[i * NX + ri];
-    ra[q] = hasA ? -ca : 0.0;
-    rb[q] = hasB ? -cb : 0.0;
-  }
-  const acc4_t c0 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_, rq, rq + W, zs, zs + NX + W, [&](int g) {
-    const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
-    const double dd = DL[ic * NX + ri] + DR[ic * NX + ri], gg = gL[ic] + gR[ic];
-    return -(li == NX ? gg : dd);
-  });
-  wave_lds_sync();  // last read of the staged operands
-  m.init(lane);
-  SEG(9);
-
-  const bool leftchild = (base & T) == 0;
-  const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
-  const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
-  acc4_t X0, X1, unused;
-  if (factor_solve_mc<NX>(lane, c0, ra, rb, m, store_l ? Fblk(F, d, b, l, s + 1) : nullptr, X0, X1,
-                          [&](const acc4_t& Y0, const acc4_t& Y1) {
-                            acc4_t g00, g01, g11;
-                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
-                            const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-                            push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero,
-                                        [](double* p, double v) { atomicAdd(p, v); });
-                          }) &&
-      lane == 0)
-    flag_failure(info, d, b);
-  SEG(13);
-  store_record_mc<NX>(rec + ((size_t)b * N + s) * (2 * NN + NX), lane, hasA, hasB, X0, X1);
-#ifdef NDLQR_SEGTIME
-  __builtin_amdgcn_s_waitcnt(0);
-#endif
-  SEG(12);
 }
 
 }  // namespace ndlqr

@@ -380,7 +380,9 @@ __device__ __forceinline__ double leaf_rhs_entry(const Dims& d, const int b, con
 // One slot per separator of level >= 2 (s = 3 mod 4): DL | DR | CA | CB | gL | gR.
 template <int NX>
 struct RedSlot {
-  static constexpr int NN = NX * NX, SIZE = 4 * NN + 2 * NX;
+  // USED doubles of a slot; slots are padded to whole 128-byte lines (SIZE), so that a wavefront
+  // that reads its slot never pulls bytes of a neighbouring slot into its caches (tree schedule)
+  static constexpr int NN = NX * NX, USED = 4 * NN + 2 * NX, SIZE = (USED + 15) / 16 * 16;
   double* p;
   __device__ __forceinline__ double* DL() const { return p; }
   __device__ __forceinline__ double* DR() const { return p + NN; }

@@ -48,19 +48,24 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   // 12x12 blocks instead of handing knot rows over
   if constexpr (!STRICT && !KEEP && ndlqr::P1OnMatrixCores<NX, NU>::value) {
     if (lean && c->reduced && JB == 2 && d.K > 2 && c->red) {
+      const bool tree = c->bottom_reduced && c->mcore && c->tree && c->tree_cnt;
       if (c->bottom_reduced) {
         ScopedSlot t(c, SLOT_BOTTOM);
-        if (c->mcore)
-          hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU>), dim3(d.N >> 2, d.batch), dim3(64),
-                             (size_t)c->bottom_lds_pad, c->stream, d,
-                             c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+        if (tree)
+          hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, true>), dim3(d.N >> 2, d.batch), dim3(64),
+                             (size_t)c->bottom_lds_pad, c->stream, d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F,
+                             c->info, store_l, c->tree_cnt);
+        else if (c->mcore)
+          hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, false>), dim3(d.N >> 2, d.batch), dim3(64),
+                             (size_t)c->bottom_lds_pad, c->stream, d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F,
+                             c->info, store_l, nullptr);
         else
           hipLaunchKernelGGL((ndlqr::bottom_reduced<NX, NU>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream, d,
                              c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
       } else {
         launch_bottom<NX, NU, STRICT, KEEP, 2, true>(c, true);
       }
-      for (int l = 2; l < d.K; ++l) {
+      for (int l = 2; l < d.K && !tree; ++l) {
         ScopedSlot t(c, SLOT_UPPER);
         if (c->mcore)
           hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,

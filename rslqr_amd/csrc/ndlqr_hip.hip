@@ -68,7 +68,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.K = 0; while ((1 << d.K) < nhorizon) ++d.K;
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
-  c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr;
+  c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
+  c->tree = getenv("NDLQR_TREE") ? atoi(getenv("NDLQR_TREE")) != 0 : false;  // measured slower, see DESIGN.md
   c->reduced = getenv("NDLQR_REDUCED") ? atoi(getenv("NDLQR_REDUCED")) != 0 : true;
   c->mcore = getenv("NDLQR_MCORE") ? atoi(getenv("NDLQR_MCORE")) != 0 : true;
   c->bottom_reduced = getenv("NDLQR_BOTTOM_REDUCED") ? atoi(getenv("NDLQR_BOTTOM_REDUCED")) != 0 : true;
@@ -91,8 +92,13 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
             hipMalloc(&c->F, bytes_F(d)) == hipSuccess && hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
             hipMalloc(&c->info, sizeof(int) * ((size_t)batch + 1)) == hipSuccess;
   if (ok && nhorizon >= 8 && has_small_instance(nstates, ninputs)) {
-    const size_t red_bytes = sizeof(double) * (size_t)batch * (nhorizon / 4) * (4 * (size_t)nstates * nstates + 2 * nstates);
+    // slot = DL | DR | CA | CB | gL | gR, padded to whole 128-byte lines (RedSlot<NX>::SIZE)
+    const size_t slot_doubles = (4 * (size_t)nstates * nstates + 2 * nstates + 15) / 16 * 16;
+    const size_t red_bytes = sizeof(double) * (size_t)batch * (nhorizon / 4) * slot_doubles;
     ok = hipMalloc(&c->red, red_bytes) == hipSuccess && hipMemsetAsync(c->red, 0, red_bytes, c->stream) == hipSuccess;
+    const size_t cnt_bytes = sizeof(int) * (size_t)batch * (nhorizon / 4);
+    ok = ok && hipMalloc(&c->tree_cnt, cnt_bytes) == hipSuccess &&
+         hipMemsetAsync(c->tree_cnt, 0, cnt_bytes, c->stream) == hipSuccess;
   }
   if (ok) {
     // Structural zeros of F are never written by the kernels; zero once so that the factor
@@ -118,7 +124,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
-  (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->info);
+  (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

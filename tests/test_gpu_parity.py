@@ -285,7 +285,7 @@ def test_env_variants_fast_mode(ndlqr, oracle):
            n, m, N, batch, seed))
     probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
     ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
-    for env in ({}, {"NDLQR_MCORE": "0"}, {"NDLQR_BOTTOM_REDUCED": "0"}, {"NDLQR_REDUCED": "0"}, {"NDLQR_NO_BACKSUB": "1"}, {"NDLQR_NO_BACKSUB": "1", "NDLQR_NO_FINISH": "1"},
+    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}, {"NDLQR_BOTTOM_REDUCED": "0"}, {"NDLQR_REDUCED": "0"}, {"NDLQR_NO_BACKSUB": "1"}, {"NDLQR_NO_BACKSUB": "1", "NDLQR_NO_FINISH": "1"},
                 {"NDLQR_UPPER": "0"}, {"NDLQR_UPPER": "2"}, {"NDLQR_BOTTOM_LEVELS": "1"},
                 {"NDLQR_BOTTOM_LEVELS": "3", "NDLQR_FUSE_LEVEL": "3"}, {"NDLQR_BOTTOM_LEVELS": "0"}):
         e = dict(os.environ); e.update(env)
