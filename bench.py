@@ -280,11 +280,12 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # measured HBM bytes per launch of that kernel: committed PMC summary of the same config
         # (rocprofv3 cannot run inside this process; profiles/r01_traffic.json says how it was taken)
-        traffic = None
+        traffic, issue = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             if (n, m, N, batch, args.flags) == (12, 4, 256, 1024, 0) and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                issue = tj.get("issue", {}).get(dom)
         except (OSError, ValueError, KeyError):
             pass
         whole_solve_gbs = (leaf_b + sum(level_b)) * value / world / 1e9
@@ -315,7 +316,10 @@ def main():
                                   "achieved_tflops": model_flops(n, m, N) * value / world / 1e12,
                                   "peak_tflops": 78.6,
                                   "frac": model_flops(n, m, N) * value / world / 1e12 / 78.6},
-                         "model_b_bytes_per_solve": leaf_b + sum(level_b)},
+                         "model_b_bytes_per_solve": leaf_b + sum(level_b),
+                         # what actually bounds the dominant kernel (SQ counters of the committed
+                         # profile, not measured in this run): fp64 vector-ALU + matrix issue time
+                         "issue_bound_profile": issue},
             "kernel_ms": {k: {"total_ms": v[0], "launches": v[1]} for k, v in prof.items() if v[1]},
             "kernel_ms_note": "second pass of the same %d steps with per-launch HIP events (eager "
                               "launches): %.3f ms/step vs %.3f ms/step in the timed, graph-replayed region"
