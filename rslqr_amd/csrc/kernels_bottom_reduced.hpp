@@ -293,7 +293,7 @@ struct alignas(16) McScratch {
 
 // c: [S-bar | b~] tile (column NX = rhs). ra / rb: B-operand fragments of r_a / r_bb, i.e.
 // ra[q] = r_a(4 q + lk, li) (any finite value outside the block). On return X0 = [f_a | z_sep],
-// X1 = [f_bb] in accumulator layout. hook(Y0, Y1) runs between the two products.
+// X1 = [f_bb] in accumulator layout. hook(R0, R1, X0, X1) sees the panel fragments and the solution.
 template <int NX, class Hook>
 __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
                                                 const double (&rb)[(NX + 3) / 4], McScratch<NX>& m,
@@ -354,48 +354,48 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
   }
   if (lstore && lane < NX) store_row<NX>(lstore + gi * NX, acc);
   wave_lds_sync();
-  double wa[KS], wt[KS];
+  // S-bar^-1 = W'W as one tile; being symmetric, its accumulator components are at once its
+  // A-operand fragments: X = S-bar^-1 [r_a | b~ | r_bb] needs no further data movement
+  double wt[KS], b0[KS];
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
-    wa[q] = m.W[li * WP + 4 * q + lk];    // A(i, k) = W(i, k)
-    wt[q] = m.W[(4 * q + lk) * WP + li];  // A(i, k) = W(k, i)
+    wt[q] = m.W[(4 * q + lk) * WP + li];  // W(k, li): A operand of W'(i, k) and B operand of W(k, j)
+    // columns beyond the blocks carry finite don't-cares: they only reach tile elements nobody reads
+    b0[q] = li == NX ? c[q] : ra[q];
   }
   const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-  acc4_t Y0 = zero, Y1 = zero;
+  acc4_t Si = zero;
 #pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    // columns beyond the blocks carry finite don't-cares: they only reach tile elements nobody reads
-    const double b0 = li == NX ? c[q] : ra[q];
-    Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], b0, Y0, 0, 0, 0);
-    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], rb[q], Y1, 0, 0, 0);
-  }
+  for (int q = 0; q < KS; ++q) Si = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], wt[q], Si, 0, 0, 0);
   SEG(31);
-  hook(Y0, Y1);
-  SEG(32);
   X0 = zero; X1 = zero;
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
-    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y0[q], X0, 0, 0, 0);
-    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y1[q], X1, 0, 0, 0);
+    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], b0[q], X0, 0, 0, 0);
+    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], rb[q], X1, 0, 0, 0);
   }
+  SEG(32);
+  hook(b0, rb, X0, X1);
   SEG(33);
   return bad;
 }
 
-// Gram tiles of Y = [Y0 | Y1] (accumulator layout in, accumulator layout out):
-//   g00 = Y0'Y0   g01 = Y0'Y1   g10 = Y1'Y0   g11 = Y1'Y1
+// Schur-complement blocks R' S-bar^-1 R = R'X of the panel R = [R0 | R1] (operand fragments, the
+// same registers that fed X = S-bar^-1 R) and X = [X0 | X1] (accumulator layout = B operand):
+//   g00 = R0'X0   g01 = R0'X1   g10 = R1'X0   g11 = R1'X1
 template <int NX, bool N00, bool N01, bool N10, bool N11>
-__device__ __forceinline__ void gram_mc(const acc4_t& Y0, const acc4_t& Y1, acc4_t& g00, acc4_t& g01, acc4_t& g10,
+__device__ __forceinline__ void gram_mc(const double (&R0)[(NX + 3) / 4], const double (&R1)[(NX + 3) / 4],
+                                        const acc4_t& X0, const acc4_t& X1, acc4_t& g00, acc4_t& g01, acc4_t& g10,
                                         acc4_t& g11) {
   constexpr int KS = (NX + 3) / 4;
   const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
   g00 = zero; g01 = zero; g10 = zero; g11 = zero;
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
-    if constexpr (N00) g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y0[q], Y0[q], g00, 0, 0, 0);
-    if constexpr (N01) g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y0[q], Y1[q], g01, 0, 0, 0);
-    if constexpr (N10) g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y1[q], Y0[q], g10, 0, 0, 0);
-    if constexpr (N11) g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y1[q], Y1[q], g11, 0, 0, 0);
+    if constexpr (N00) g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(R0[q], X0[q], g00, 0, 0, 0);
+    if constexpr (N01) g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(R0[q], X1[q], g01, 0, 0, 0);
+    if constexpr (N10) g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(R1[q], X0[q], g10, 0, 0, 0);
+    if constexpr (N11) g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(R1[q], X1[q], g11, 0, 0, 0);
   }
 }
 
@@ -629,9 +629,9 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
   const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
   acc4_t X0, X1, unused;
   if (factor_solve_mc<NX>(lane, c0, ra, rb, m, store_l ? Fblk(F, d, b, l, s + 1) : nullptr, X0, X1,
-                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
                             acc4_t g00, g01, g11;
-                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
+                            gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
                             const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
                             if constexpr (TREE)
                               push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
@@ -775,9 +775,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   // ---- s0 = k0 (level 0, left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
   acc4_t park_a, ca_t;
   if (factor_solve_mc<NX>(lane, c_s0, ra0, rb0, m, store_l ? Fblk(F, d, b, 0, k0 + 1) : nullptr, X0, X1,
-                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
                             acc4_t g11;
-                            gram_mc<NX, true, false, true, true>(Y0, Y1, park_a, unused, ca_t, g11);
+                            gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
 #pragma unroll
                             for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
                           }) &&
@@ -790,9 +790,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   // ---- s2 = k0 + 2 (level 0, right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
   acc4_t park_b11, cb_t;
   if (factor_solve_mc<NX>(lane, c_s2, ra2, rb2, m, store_l ? Fblk(F, d, b, 0, k0 + 3) : nullptr, X0, X1,
-                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
                             acc4_t g00;
-                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, cb_t, unused, park_b11);
+                            gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
 #pragma unroll
                             for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
                           }) &&
@@ -811,9 +811,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
   const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
   if (factor_solve_mc<NX>(lane, c_t, rat, rbt, m, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr, X0, X1,
-                          [&](const acc4_t& Y0, const acc4_t& Y1) {
+                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
                             acc4_t g00, g01, g11;
-                            gram_mc<NX, true, true, false, true>(Y0, Y1, g00, g01, unused, g11);
+                            gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
                             if constexpr (TREE)
                               push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
                                           StoreThrough(), StoreThrough());
