@@ -1,5 +1,14 @@
-// kernels_bottom_reduced.hpp -- fast mode without KEEP: leaf phase + tree levels 0 and 1 on the
-// REDUCED (separator-only) system, one wavefront per four consecutive knots, no knot states at all.
+// kernels_bottom_reduced.hpp -- fast mode without KEEP: the whole factorisation on the REDUCED
+// (separator-only) system, no knot states at all. Default path of the batch API for the instances
+// with matrix-core products (6 <= nstates <= 15).
+//
+//   bottom_reduced_mc   leaf phase + tree levels 0 and 1, one wavefront per four consecutive knots
+//                       (TREE: the wavefront climbs on through the upper levels on arrival counters)
+//   reduced_level_mc    one upper level, one wavefront per separator (reduced_separator_mc)
+//   factor_solve_mc     the separator core: fused Cholesky + inverse on the vector ALU, everything
+//                       else as v_mfma_f64_16x16x4_f64 products chained through accumulator registers
+//   bottom_reduced      first form of the bottom kernel on the vector-ALU core (factor_solve of
+//                       kernels_small.hpp), kept for A/B timing (NDLQR_MCORE=0)
 //
 // Same mathematics as bottom_small<.., REDUCED> + reduced_level (kernels_small.hpp; DESIGN.md
 // section 2): eliminating the states and inputs of every knot (ndlqr_SolveLeaf,
@@ -14,8 +23,7 @@
 // t = k0+1 in registers (matrix-core accumulator layout) and pushes what t and its children
 // contribute to the two separators next to the group (k0-1, k0+3) into their RedSlot -- plain
 // stores, one writer per element. Compared with the knot-based bottom kernel this drops the 28-row
-// knot states, their Schur updates, the LDS publishing and every workgroup barrier: three
-// factor_solve cores and seven small matrix-core products per wavefront.
+// knot states, their Schur updates, the LDS publishing and every workgroup barrier.
 #pragma once
 #include "kernels_small.hpp"
 

@@ -270,28 +270,51 @@ def test_harder_problem_families(ndlqr, oracle, n, m, N, a_scale, q_scale):
         bs.close()
 
 
-def test_env_variants_fast_mode(ndlqr, oracle):
-    """Fast mode has three solution sweeps (back-substitution from the records, finish kernel on the
-    hand-off columns, apply pass) and three schedules of the upper levels: each stays within the
-    fast-mode tolerance of the oracle (relative l2 <= 1e-9, here ~1e-15)."""
+def _solve_in_subprocess(n, m, N, batch, seed, env):
+    """Solutions of a fresh process with `env` added to the environment (the tuning variables are
+    read once, at context creation)."""
     import subprocess, sys, json
-    n, m, N, batch, seed = 12, 4, 128, 3, 91
     code = (
         "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import rslqr_amd as R\n"
         "bs = R.BatchSolver(%d, %d, %d, %d); bs.initialize_synthetic(%d)\n"
-        "assert bs.solve() == 0; print(json.dumps(bs.solutions().tolist()))\n"
+        "assert bs.solve() == 0; assert bs.solve() == 0; print(json.dumps(bs.solutions().tolist()))\n"
         % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
            n, m, N, batch, seed))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (env, r.stderr[-2000:])
+    return np.array(json.loads(r.stdout.strip().splitlines()[-1]))
+
+
+def test_env_variants_fast_mode(ndlqr, oracle):
+    """Fast mode has three solution sweeps (back-substitution from the records, finish kernel on the
+    hand-off columns, apply pass), knot-based and separator-only schedules of the bottom and of the
+    upper levels, two separator cores and the tree schedule: each stays within the fast-mode
+    tolerance of the oracle (relative l2 <= 1e-9, here ~1e-15). Two solves per process: the second
+    one runs on what the first left in the accumulators and arrival counters."""
+    n, m, N, batch, seed = 12, 4, 128, 3, 91
     probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
     ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
-    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}, {"NDLQR_BOTTOM_REDUCED": "0"}, {"NDLQR_REDUCED": "0"}, {"NDLQR_NO_BACKSUB": "1"}, {"NDLQR_NO_BACKSUB": "1", "NDLQR_NO_FINISH": "1"},
+    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}, {"NDLQR_BOTTOM_REDUCED": "0"}, {"NDLQR_REDUCED": "0"},
+                {"NDLQR_NO_BACKSUB": "1"}, {"NDLQR_NO_BACKSUB": "1", "NDLQR_NO_FINISH": "1"},
                 {"NDLQR_UPPER": "0"}, {"NDLQR_UPPER": "2"}, {"NDLQR_BOTTOM_LEVELS": "1"},
                 {"NDLQR_BOTTOM_LEVELS": "3", "NDLQR_FUSE_LEVEL": "3"}, {"NDLQR_BOTTOM_LEVELS": "0"}):
-        e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, (env, r.stderr[-2000:])
-        got = np.array(json.loads(r.stdout.strip().splitlines()[-1]))
+        got = _solve_in_subprocess(n, m, N, batch, seed, env)
+        err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert err <= REL_TOL, (env, err)
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(6, 3, 64, 5), (13, 4, 32, 3), (9, 3, 8, 4), (8, 4, 256, 2), (10, 4, 16, 1)])
+def test_separator_only_schedules_other_shapes(ndlqr, oracle, n, m, N, batch):
+    """The separator-only schedules on the other matrix-core instances (odd row lengths, k-steps
+    with padding, shortest horizon with an upper level): default (bottom_reduced_mc +
+    reduced_level_mc), the tree schedule and the vector-ALU core against the oracle."""
+    seed = 500 + n
+    probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
+    ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
+    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}):
+        got = _solve_in_subprocess(n, m, N, batch, seed, env)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         assert err <= REL_TOL, (env, err)
 
