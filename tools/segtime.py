@@ -7,7 +7,9 @@ the GPU box, runs the default workload through it:
     python tools/segtime.py --build          # here
     gpurun -- python tools/segtime.py        # there
 
-Prints average cycles per wavefront per segment. The instrumented library is never shipped or
+Prints average cycles per wavefront per segment. (Elapsed cycles, not issue cycles: the SIMDs issue
+oldest-wavefront-first, so the first segments of a wavefront -- staging, leaf tiles -- look long
+because a young wavefront only gets the slots its elders leave.) The instrumented library is never shipped or
 loaded by the package itself (NDLQR_LIBRARY points the ctypes mirror at it for this run only).
 """
 import ctypes as C
@@ -27,8 +29,8 @@ NAMES = {0: "level: stage operands", 1: "level core: P1", 2: "level core: P2 (Ch
          17: "bottom core: P1", 18: "bottom core: P2", 19: "bottom core: P3",
          20: "bottom: stage AB", 21: "bottom: leaf", 22: "bottom: publish + barrier",
          23: "bottom: separator (owner) / skip", 24: "bottom: barrier after separator",
-         30: "mc core: S-bar rows, Cholesky + inverse", 31: "mc core: W to operands, Y = W R",
-         32: "mc core: hook (Gram tiles, pushes)", 33: "mc core: X = W'Y", 34: "mc: (re-arm)",
+         30: "mc core: S-bar rows, Cholesky + inverse", 31: "mc core: W to operands, S^-1 = W'W",
+         32: "mc core: X = S^-1 R", 33: "mc core: hook (Schur blocks R'X, pushes)", 34: "mc: (re-arm)",
          35: "bottom_mc: record store", 36: "bottom_mc: last record store + drain",
          25: "bottom: row update + rotate", 26: "bottom: barrier end of level", 27: "bottom: hand-off"}
 
