@@ -286,6 +286,13 @@ def main():
             if (n, m, N, batch, args.flags) == (12, 4, 256, 1024, 0) and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
                 issue = tj.get("issue", {}).get(dom)
+                if issue and "executed_flops_per_wave" in issue and dom == "bottom":
+                    # executed (not algorithmic) fp64 rate of the dominant kernel: flops per wavefront
+                    # from the ISA x wavefronts of this launch / its measured duration
+                    issue = dict(issue)
+                    waves = (N // 4) * batch
+                    issue["executed_tflops"] = issue["executed_flops_per_wave"] * waves / (avg_ms * 1e-3) / 1e12
+                    issue["executed_frac_of_fp64_peak"] = issue["executed_tflops"] / 78.6
         except (OSError, ValueError, KeyError):
             pass
         whole_solve_gbs = (leaf_b + sum(level_b)) * value / world / 1e9
