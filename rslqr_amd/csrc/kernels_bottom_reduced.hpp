@@ -272,15 +272,16 @@ __global__ __launch_bounds__(64, 4) void bottom_reduced(Dims d, const double* __
 // ===================================================================================== matrix-core core
 // Second form of the separator core, used by bottom_reduced_mc / reduced_level_mc: only the
 // Cholesky of S-bar and the inverse W = L^-1 of its factor run on the vector ALU (row / column per
-// lane, v_readlane broadcasts; step j broadcasts row j of L once and uses it for both); the two
-// substitutions become 16x16x4 matrix-core products
-//     Y = W [r_a | b~ | r_bb]        X = W' Y
-// and the Gram blocks Y'Y take Y straight from the accumulator registers: component q of lane
-// (li, lk) of a v_mfma_f64_16x16x4_f64 result is element (4 q + lk, li) -- exactly the element that
-// lane supplies in k-step q when the tile is the B operand (or, transposed, the A operand) of the
-// next product. No panel in LDS, no re-filing; LDS only transposes S-bar (accumulator layout ->
-// one row per lane) and W (one column per lane -> operand layout). Per separator about 160
-// v_readlane + 130 FMAs instead of 420 + 235, the rest on the matrix pipe.
+// lane, v_readlane broadcasts; step j broadcasts row j of L once and uses it for both); the rest is
+// a chain of 16x16x4 matrix-core products through the accumulator registers
+//     S-bar^-1 = W'W        X = S-bar^-1 [r_a | b~ | r_bb]        Schur blocks R'X
+// Component q of lane (li, lk) of a v_mfma_f64_16x16x4_f64 result is element (4 q + lk, li) --
+// exactly the element that lane supplies in k-step q when the tile is the B operand of the next
+// product, and (S-bar^-1 being symmetric) also when it is the A operand; the panel fragments R
+// serve as B operand of S-bar^-1 R and as A operand of R'X unchanged. No panel in LDS, no
+// re-filing; LDS only transposes S-bar (accumulator layout -> one row per lane) and W (one column
+// per lane -> operand layout). Per separator 156 v_readlane + 132 FMAs instead of 420 + 235, and
+// 18 MFMAs (3 + 6 + 9).
 // Everything is written branch-free: loads are unconditional with clamped indices, the tiles are
 // padded to 16 x 16 in LDS (pad rows / columns of W are zero, so padding never reaches a result),
 // conditions only select values.
