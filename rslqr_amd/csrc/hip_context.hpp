@@ -45,7 +45,7 @@ struct NdlqrHipCtx {
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   double* red;  // [batch][N/4][4 n^2 + 2 n] accumulators of the separator-only schedule (size-specialised shapes)
   bool reduced; // upper levels on the reduced system (reduced_level); NDLQR_REDUCED=0 switches back to level_small
-  bool tree;  // whole factorisation in one launch, wavefronts climbing the tree (bottom_reduced_mc<TREE>); NDLQR_TREE=1 (default off: one launch per level is faster)
+  int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
   int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; advance by two per solve
   bool mcore; // separator core with both substitutions on the matrix cores (factor_solve_mc); NDLQR_MCORE=0: factor_solve
   bool bottom_reduced; // levels 0 and 1 on the reduced system too (bottom_reduced); NDLQR_BOTTOM_REDUCED=0: bottom_small<REDUCED>

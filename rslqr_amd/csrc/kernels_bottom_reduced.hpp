@@ -681,9 +681,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void re
 // levels of the next ones. The counters advance by two per solve (tested for parity, never reset).
 // Correct on every placement (write-through pushes, L1-bypassing slot loads, slots padded to whole
 // lines; no fences: an agent-scope fence writes back / invalidates a whole L2 and made this 18 ms),
-// but MEASURED SLOWER than one launch per level (1.07 vs 0.61 ms at (12,4,256)x1024: a climbing
+// Used for small batches (all bottom wavefronts resident at once: (6,3,256)x1 0.053 -> 0.046 ms);
+// for large ones one launch per level is faster (1.07 vs 0.61 ms at (12,4,256)x1024: a climbing
 // wavefront waits for its store acknowledgements, the counter round trip and the slot coming from
-// memory, ~15 us per separator while it holds its SIMD slot) -- kept behind NDLQR_TREE=1.
+// memory, ~15 us per separator while it holds its SIMD slot). launch_small.hpp picks by batch size,
+// NDLQR_TREE=0/1 overrides.
 // Every accumulator element still receives its additions in a fixed order: its contributors are
 // the separators along one spine of the subtree below it, and each of them finishes its pushes
 // before its parent starts.

@@ -48,7 +48,10 @@ static int launch_small(NdlqrHipCtx* c, int J) {
   // 12x12 blocks instead of handing knot rows over
   if constexpr (!STRICT && !KEEP && ndlqr::P1OnMatrixCores<NX, NU>::value) {
     if (lean && c->reduced && JB == 2 && d.K > 2 && c->red) {
-      const bool tree = c->bottom_reduced && c->mcore && c->tree && c->tree_cnt;
+      // tree schedule for small batches (at most half a resident round of bottom wavefronts): three
+      // launches instead of K + 1; measured cross-over at batch x N / 4 ~ 4096 wavefronts
+      const bool tree = c->bottom_reduced && c->mcore && c->tree_cnt &&
+                        (c->tree == 1 || (c->tree < 0 && (size_t)d.batch * (d.N >> 2) <= 2048));
       if (c->bottom_reduced) {
         ScopedSlot t(c, SLOT_BOTTOM);
         if (tree)

@@ -69,7 +69,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
-  c->tree = getenv("NDLQR_TREE") ? atoi(getenv("NDLQR_TREE")) != 0 : false;  // measured slower, see DESIGN.md
+  c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->reduced = getenv("NDLQR_REDUCED") ? atoi(getenv("NDLQR_REDUCED")) != 0 : true;
   c->mcore = getenv("NDLQR_MCORE") ? atoi(getenv("NDLQR_MCORE")) != 0 : true;
   c->bottom_reduced = getenv("NDLQR_BOTTOM_REDUCED") ? atoi(getenv("NDLQR_BOTTOM_REDUCED")) != 0 : true;

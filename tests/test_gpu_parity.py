@@ -296,7 +296,8 @@ def test_env_variants_fast_mode(ndlqr, oracle):
     n, m, N, batch, seed = 12, 4, 128, 3, 91
     probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
     ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
-    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}, {"NDLQR_BOTTOM_REDUCED": "0"}, {"NDLQR_REDUCED": "0"},
+    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_TREE": "0"}, {"NDLQR_MCORE": "0"}, {"NDLQR_BOTTOM_REDUCED": "0"},
+                {"NDLQR_REDUCED": "0"},
                 {"NDLQR_NO_BACKSUB": "1"}, {"NDLQR_NO_BACKSUB": "1", "NDLQR_NO_FINISH": "1"},
                 {"NDLQR_UPPER": "0"}, {"NDLQR_UPPER": "2"}, {"NDLQR_BOTTOM_LEVELS": "1"},
                 {"NDLQR_BOTTOM_LEVELS": "3", "NDLQR_FUSE_LEVEL": "3"}, {"NDLQR_BOTTOM_LEVELS": "0"}):
@@ -309,11 +310,12 @@ def test_env_variants_fast_mode(ndlqr, oracle):
 def test_separator_only_schedules_other_shapes(ndlqr, oracle, n, m, N, batch):
     """The separator-only schedules on the other matrix-core instances (odd row lengths, k-steps
     with padding, shortest horizon with an upper level): default (bottom_reduced_mc +
-    reduced_level_mc), the tree schedule and the vector-ALU core against the oracle."""
+    reduced_level_mc; small batches pick the tree schedule by themselves), one launch per level,
+    the tree schedule and the vector-ALU core against the oracle."""
     seed = 500 + n
     probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
     ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
-    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}):
+    for env in ({}, {"NDLQR_TREE": "0"}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}):
         got = _solve_in_subprocess(n, m, N, batch, seed, env)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         assert err <= REL_TOL, (env, err)
