@@ -344,12 +344,13 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
       sacc = fma(-bc, w[k], sacc);
     }
     const double pivot = readlane_f64(v, j);
-    // 1 / sqrt(pivot): hardware estimate + one third-order correction (what rsqrt() expands to,
-    // without its special-case selects). A non-positive pivot turns into NaN here and stays NaN
+    // 1 / sqrt(pivot): hardware estimate (v_rsq_f64, ~2^-26) + one Newton step -- rsqrt() expands to
+    // a third-order step plus special-case selects; the second-order one is within a few ulp, far
+    // inside the fast-mode tolerance. A non-positive pivot turns into NaN here and stays NaN
     // through every later pivot, so ONE test after the last step flags the separator.
     const double y0 = __builtin_amdgcn_rsq(pivot);
     const double e = fma(-pivot * y0, y0, 1.0);
-    const double rinv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+    const double rinv = fma(y0 * e, 0.5, y0);
     if (j == NX - 1) bad = !((rinv > 0.0) & (rinv < 1.0e300));  // no short-circuit: one basic block
     acc[j] = v * rinv;
     w[j] = sacc * rinv;
