@@ -601,17 +601,23 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
     for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; tq[it] = qr[e < NQ ? e : NQ - 1]; }
 #pragma unroll
     for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; tr[it] = r0[e < NR ? e : NR - 1]; }
+    // The stores are unconditional, on the same clamped index as the loads (surplus lanes rewrite the
+    // last element with its own value): a store under a lane predicate makes the compiler sink the
+    // load behind the predicate too, and the loads then complete one after the other.
 #pragma unroll
-    for (int it = 0; it < IS; ++it) { const int e = lane + 64 * it; if (e < NS) reinterpret_cast<double2*>(slot)[e] = ts[it]; }
-#pragma unroll
-    for (int it = 0; it < IA; ++it) {
-      const int e = lane + 64 * it, row = e / W, c = e - row * W;
-      if (e < NA) abs_[row * WP + c] = ta[it];
+    for (int it = 0; it < IS; ++it) {
+      const int e = lane + 64 * it, ec = e < NS ? e : NS - 1;
+      reinterpret_cast<double2*>(slot)[ec] = ts[it];
     }
 #pragma unroll
-    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; if (e < NQ) rq[e] = 1.0 / tq[it]; }
+    for (int it = 0; it < IA; ++it) {
+      const int e = lane + 64 * it, ec = e < NA ? e : NA - 1, row = ec / W, c = ec - row * W;
+      abs_[row * WP + c] = ta[it];
+    }
 #pragma unroll
-    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; if (e < NR) zs[e] = tr[it]; }
+    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it, ec = e < NQ ? e : NQ - 1; rq[ec] = 1.0 / tq[it]; }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it, ec = e < NR ? e : NR - 1; zs[ec] = tr[it]; }
   }
   wave_lds_sync();
   const double *DL = slot, *DR = slot + NN, *CA = slot + 2 * NN, *CB = slot + 3 * NN;
@@ -734,9 +740,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
         t[it] = reinterpret_cast<const double2*>(abm)[e < NA ? e : NA - 1];
       }
 #pragma unroll
-      for (int it = 0; it < IA; ++it) {
-        const int e = lane + 64 * it, row = e / (W / 2), c2 = e - row * (W / 2);
-        if (e < NA) reinterpret_cast<double2*>(&abs_[row * WP])[c2] = t[it];
+      for (int it = 0; it < IA; ++it) {  // unconditional stores on the clamped index: see reduced_separator_mc
+        const int e = lane + 64 * it, ec = e < NA ? e : NA - 1, row = ec / (W / 2), c2 = ec - row * (W / 2);
+        reinterpret_cast<double2*>(&abs_[row * WP])[c2] = t[it];
       }
     } else {
       constexpr int NA = 4 * NX * W, IA = (NA + 63) / 64;
@@ -744,18 +750,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
 #pragma unroll
       for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; t[it] = abm[e < NA ? e : NA - 1]; }
 #pragma unroll
-      for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; if (e < NA) abs_[e] = t[it]; }
+      for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; abs_[e < NA ? e : NA - 1] = t[it]; }
     }
 #pragma unroll
     for (int it = 0; it < IQ; ++it) {
-      const int e = lane + 64 * it, kn = e / W, c = e - kn * W;
-      if (e < NQ) {
-        rq[e] = 1.0 / qv[it];
-        if (!(qv[it] > 0.0) && !(k0 + kn == N - 1 && c >= NX)) flag_failure(info, d, b);  // terminal R is unused
-      }
+      const int e = lane + 64 * it, ec = e < NQ ? e : NQ - 1, kn = ec / W, c = ec - kn * W;
+      rq[ec] = 1.0 / qv[it];
+      if (e < NQ && !(qv[it] > 0.0) && !(k0 + kn == N - 1 && c >= NX)) flag_failure(info, d, b);  // terminal R is unused
     }
 #pragma unroll
-    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; if (e < NR) rh[e] = rv[it]; }
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; rh[e < NR ? e : NR - 1] = rv[it]; }
   }
   wave_lds_sync();
   SEG(20);
