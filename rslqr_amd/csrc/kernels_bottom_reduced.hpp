@@ -506,24 +506,36 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
   constexpr int W = NX + NU, KS = (W + 3) / 4;
   const int li = lane & 15, lk = lane >> 4;
   const int ri = li < NX ? li : NX - 1;  // rows / columns >= NX of a tile are padding: any finite data
-  acc4_t c;
+  // every LDS operand first (one wait for all of them), then the arithmetic
+  double w1[4], za[4], zb[4], in0[4], av[KS], wk[KS], zraw[KS];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
-    const double w1 = q1[ic], za = z1[ic], zb = z1[NX + ic];
+    w1[g] = q1[ic]; za[g] = z1[ic]; zb[g] = z1[NX + ic];
+    in0[g] = init(g);
+  }
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int kq = 4 * q + lk, k = kq < W ? kq : W - 1;
+    const bool fx = first && k < NX;
+    av[q] = am[ri * WP + k]; wk[q] = q0[k]; zraw[q] = z0[fx ? k : NX + k];
+  }
+  acc4_t c;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = lk + 4 * g;
     // rows / columns beyond the block: finite don't-cares
-    c[g] = (li == NX ? -fma(zb, w1, za) : ((i == li) ? w1 : 0.0)) + init(g);
+    c[g] = (li == NX ? -fma(zb[g], w1[g], za[g]) : ((i == li) ? w1[g] : 0.0)) + in0[g];
   }
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
     const int kq = 4 * q + lk, k = kq < W ? kq : W - 1;
     const bool kin = kq < W, fx = first && k < NX;
-    const double av = am[ri * WP + k], wk = q0[k], zraw = z0[fx ? k : NX + k];
-    const double sv = fx ? 0.0 : av * wk;      // S-bar columns
-    const double zc = fx ? -zraw : zraw * wk;  // rhs column
+    const double sv = fx ? 0.0 : av[q] * wk[q];            // S-bar columns
+    const double zc = fx ? -zraw[q] : zraw[q] * wk[q];     // rhs column
     const double bsel = li == NX ? zc : sv;
-    if constexpr (W % 4 == 0) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bsel, c, 0, 0, 0);
-    else c = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? av : 0.0, bsel, c, 0, 0, 0);
+    if constexpr (W % 4 == 0) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bsel, c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? av[q] : 0.0, bsel, c, 0, 0, 0);
   }
   return c;
 }
@@ -669,7 +681,7 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
 
 //   grid (N >> (l+1), batch), block 64; l >= 2.
 template <int NX, int NU>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void reduced_level_mc(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void reduced_level_mc(
     Dims d, int l, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
     double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l) {
   __shared__ ReducedLds<NX, NU> lds;
