@@ -289,22 +289,66 @@ __device__ __forceinline__ void separator_wave(const Dims& d, const int l, const
     const double* Fas = Fblk(F, d, b, a >= 0 ? a : l, s) + NN;
     const double* E1 = Fblk(F, d, b, l, s + 1) + NN;
     const double* B1 = Fblk(F, d, b, bb >= 0 ? bb : l, s + 1) + NN;
+    // Every load is issued before the first LDS store, and the stores are unconditional on the
+    // same clamped index (surplus lanes rewrite the last element with its own value): a store
+    // under a lane predicate -- or a loop around load + store -- makes the loads complete one after
+    // the other (six round trips per wavefront before this form).
+    const double* zs = z + ((size_t)b * N + s) * ROWS;
+    const double zx = zs[NX + (lane < W ? lane : W - 1)];
+    const double zl = zs[ROWS + (lane < 2 * NX ? lane : 2 * NX - 1)];
     if constexpr (NX % 2 == 0) {  // 16-byte copies (block and row offsets are even)
-      for (int e = lane; e < W * NX / 2; e += 64) {
-        reinterpret_cast<double2*>(in.Exu)[e] = reinterpret_cast<const double2*>(Es)[e];
-        reinterpret_cast<double2*>(in.Axu)[e] = reinterpret_cast<const double2*>(Fas)[e];
+      constexpr int N1 = W * NX / 2, I1 = (N1 + 63) / 64, N2 = NN / 2, I2 = (N2 + 63) / 64;
+      double2 t0[I1], t1[I1], t2[I2], t3[I2];
+#pragma unroll
+      for (int it = 0; it < I1; ++it) {
+        const int e = lane + 64 * it, ec = e < N1 ? e : N1 - 1;
+        t0[it] = reinterpret_cast<const double2*>(Es)[ec];
+        t1[it] = reinterpret_cast<const double2*>(Fas)[ec];
       }
-      for (int e = lane; e < NN / 2; e += 64) {
-        reinterpret_cast<double2*>(in.E1x)[e] = reinterpret_cast<const double2*>(E1)[e];
-        reinterpret_cast<double2*>(in.B1x)[e] = reinterpret_cast<const double2*>(B1)[e];
+#pragma unroll
+      for (int it = 0; it < I2; ++it) {
+        const int e = lane + 64 * it, ec = e < N2 ? e : N2 - 1;
+        t2[it] = reinterpret_cast<const double2*>(E1)[ec];
+        t3[it] = reinterpret_cast<const double2*>(B1)[ec];
+      }
+#pragma unroll
+      for (int it = 0; it < I1; ++it) {
+        const int e = lane + 64 * it, ec = e < N1 ? e : N1 - 1;
+        reinterpret_cast<double2*>(in.Exu)[ec] = t0[it];
+        reinterpret_cast<double2*>(in.Axu)[ec] = t1[it];
+      }
+#pragma unroll
+      for (int it = 0; it < I2; ++it) {
+        const int e = lane + 64 * it, ec = e < N2 ? e : N2 - 1;
+        reinterpret_cast<double2*>(in.E1x)[ec] = t2[it];
+        reinterpret_cast<double2*>(in.B1x)[ec] = t3[it];
       }
     } else {
-      for (int e = lane; e < W * NX; e += 64) { in.Exu[e] = Es[e]; in.Axu[e] = Fas[e]; }
-      for (int e = lane; e < NN; e += 64) { in.E1x[e] = E1[e]; in.B1x[e] = B1[e]; }
+      constexpr int N1 = W * NX, I1 = (N1 + 63) / 64, N2 = NN, I2 = (N2 + 63) / 64;
+      double t0[I1], t1[I1], t2[I2], t3[I2];
+#pragma unroll
+      for (int it = 0; it < I1; ++it) {
+        const int e = lane + 64 * it, ec = e < N1 ? e : N1 - 1;
+        t0[it] = Es[ec]; t1[it] = Fas[ec];
+      }
+#pragma unroll
+      for (int it = 0; it < I2; ++it) {
+        const int e = lane + 64 * it, ec = e < N2 ? e : N2 - 1;
+        t2[it] = E1[ec]; t3[it] = B1[ec];
+      }
+#pragma unroll
+      for (int it = 0; it < I1; ++it) {
+        const int e = lane + 64 * it, ec = e < N1 ? e : N1 - 1;
+        in.Exu[ec] = t0[it]; in.Axu[ec] = t1[it];
+      }
+#pragma unroll
+      for (int it = 0; it < I2; ++it) {
+        const int e = lane + 64 * it, ec = e < N2 ? e : N2 - 1;
+        in.E1x[ec] = t2[it]; in.B1x[ec] = t3[it];
+      }
     }
-    const double* zs = z + ((size_t)b * N + s) * ROWS;
-    if (lane < W) in.zxu[lane] = zs[NX + lane];
-    if (lane < 2 * NX) in.z1[lane] = zs[ROWS + lane];
+    in.zxu[lane < W ? lane : W - 1] = zx;
+    in.z1[lane < 2 * NX ? lane : 2 * NX - 1] = zl;
   }
   wave_lds_sync();
   SEG(0);
