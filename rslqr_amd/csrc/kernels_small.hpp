@@ -1533,17 +1533,33 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
   const double rv = r0[r];
   {
     const double* src = AB + ((size_t)b * N + wgbase + 2 * wave) * NX * W;
+    // all loads before the first LDS store, stores unconditional on the clamped index (a loop
+    // around load + store completes the loads one after the other)
     if constexpr (W % 2 == 0) {
       // two knots = 2 NX rows of W doubles; the pair starts 16-byte aligned
-      for (int e = lane; e < NX * W; e += 64) {
-        const int row = e / (W / 2), c2 = e - row * (W / 2);
+      constexpr int NA = NX * W, IA = (NA + 63) / 64;
+      double2 t[IA];
+#pragma unroll
+      for (int it = 0; it < IA; ++it) {
+        const int e = lane + 64 * it;
+        t[it] = reinterpret_cast<const double2*>(src)[e < NA ? e : NA - 1];
+      }
+#pragma unroll
+      for (int it = 0; it < IA; ++it) {
+        const int e = lane + 64 * it, ec = e < NA ? e : NA - 1;
+        const int row = ec / (W / 2), c2 = ec - row * (W / 2);
         const int knot = row / NX, rr = row - knot * NX;
-        reinterpret_cast<double2*>(&me.ab[knot][rr * WP])[c2] = reinterpret_cast<const double2*>(src)[e];
+        reinterpret_cast<double2*>(&me.ab[knot][rr * WP])[c2] = t[it];
       }
     } else {
-      for (int e = lane; e < 2 * NX * W; e += 64) {
-        const int knot = e / (NX * W);
-        me.ab[knot][e - knot * NX * W] = src[e];
+      constexpr int NA = 2 * NX * W, IA = (NA + 63) / 64;
+      double t[IA];
+#pragma unroll
+      for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; t[it] = src[e < NA ? e : NA - 1]; }
+#pragma unroll
+      for (int it = 0; it < IA; ++it) {
+        const int e = lane + 64 * it, ec = e < NA ? e : NA - 1, knot = ec / (NX * W);
+        me.ab[knot][ec - knot * NX * W] = t[it];
       }
     }
   }
