@@ -945,11 +945,42 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int N = d.N, K = d.K, b = blockIdx.y;
   const int first = blockIdx.x * KPB;
-  for (int l = J; l < K; ++l) {
-    const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
-    const double* src = recs + ((size_t)b * N + qs) * REC;
-    double* dst = lds + (l - J) * REC;
-    for (int e = threadIdx.x; e < REC; e += 256) dst[e] = src[e];
+  {
+    // records of the levels J..K-1 into LDS: every load before the first store (a loop around
+    // load + store completes them one after the other); levels beyond K-1 / elements beyond REC are
+    // clamped, the surplus stores rewrite an element with its own value
+    constexpr int MAXL = 12, IT = (REC + 255) / 256;
+    const int nl = K - J;
+    if (nl <= MAXL) {
+      double t[MAXL][IT];
+#pragma unroll
+      for (int q = 0; q < MAXL; ++q) {
+        const int l = J + (q < nl ? q : nl - 1);
+        const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
+        const double* src = recs + ((size_t)b * N + qs) * REC;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int e = threadIdx.x + 256 * it;
+          t[q][it] = src[e < REC ? e : REC - 1];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < MAXL; ++q) {
+        double* dst = lds + (q < nl ? q : nl - 1) * REC;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int e = threadIdx.x + 256 * it;
+          dst[e < REC ? e : REC - 1] = t[q][it];
+        }
+      }
+    } else {
+      for (int l = J; l < K; ++l) {
+        const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
+        const double* src = recs + ((size_t)b * N + qs) * REC;
+        double* dst = lds + (l - J) * REC;
+        for (int e = threadIdx.x; e < REC; e += 256) dst[e] = src[e];
+      }
+    }
   }
   __syncthreads();
 
