@@ -117,8 +117,21 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       const double* Arow = ab + (size_t)(16 * rt + li) * w + lk;
       const double* Bcol = Bsrc + (size_t)lk * n + 16 * ct + li;
       acc4 acc = {0.0, 0.0, 0.0, 0.0};
-      for (int q = 0; q < ksteps; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Arow[4 * q], Bcol[(size_t)4 * q * n], acc, 0, 0, 0);
+      // operand fragments of ten k-steps at a time, all requested before the first product (one
+      // load pair + wait + product per trip costs a memory round trip per k-step)
+      constexpr int CH = 10;
+      for (int q0 = 0; q0 < ksteps; q0 += CH) {
+        double af[CH], bf[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = q0 + c < ksteps ? q0 + c : ksteps - 1;
+          af[c] = Arow[4 * q];
+          bf[c] = Bcol[(size_t)4 * q * n];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)  // surplus steps of the last chunk multiply by zero
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(q0 + c < ksteps ? af[c] : 0.0, bf[c], acc, 0, 0, 0);
+      }
       if (mat == 0) {
         double* dst = S + (16 * rt + lk) * ns + 16 * ct + li;
         const double* e1 = Es1 + (size_t)(n + 16 * rt + lk) * n + 16 * ct + li;
@@ -130,10 +143,23 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
         for (int g = 0; g < 4; ++g) dst[4 * g * xs] = acc[g];
       }
     }
-    for (int i = wave; i < n; i += nwave) {
-      for (int c = lane; c < n; c += 64) X[i * xs + n + c] = -Fbs1[(size_t)(n + i) * n + c];
-      for (int c = ncols + lane; c < xs; c += 64) X[i * xs + c] = 0.0;  // tile padding
+    for (int i0 = wave; i0 < n; i0 += 4 * nwave) {  // four rows per trip, their loads first
+      for (int c = lane; c < n; c += 64) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * nwave < n ? i0 + u * nwave : i0;
+          t[u] = Fbs1[(size_t)(n + i) * n + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * nwave < n ? i0 + u * nwave : i0;
+          X[i * xs + n + c] = -t[u];
+        }
+      }
     }
+    for (int i = wave; i < n; i += nwave)
+      for (int c = ncols + lane; c < xs; c += 64) X[i * xs + c] = 0.0;  // tile padding
   } else {
     for (int i = wave; i < n; i += nwave) {
       const double* arow = ab + i * w;
@@ -153,9 +179,22 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double* arow = ab + i * w;
     double acc = -zs1[i];  // beta = -1 on the old lambda entry (nested_dissection.c:125)
-    for (int k = 0; k < n; ++k) acc = mad<STRICT>(arow[k], zsl[n + k], acc);
-    for (int k = 0; k < m; ++k) acc = mad<STRICT>(arow[n + k], zsl[2 * n + k], acc);
-    X[i * xs + 2 * n] = acc - zs1[n + i];
+    // same order of operations as the scalar loop (k ascending over [A | B] against z.x | z.u, which
+    // are contiguous), operands fetched sixteen pairs at a time
+    const double zlast = zs1[n + i];
+    for (int k0 = 0; k0 < w; k0 += 16) {
+      double av[16], zv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = k0 + u < w ? k0 + u : w - 1;
+        av[u] = arow[k];
+        zv[u] = zsl[n + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (k0 + u < w) acc = mad<STRICT>(av[u], zv[u], acc);
+    }
+    X[i * xs + 2 * n] = acc - zlast;
   }
   __syncthreads();
 
