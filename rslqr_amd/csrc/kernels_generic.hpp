@@ -135,8 +135,11 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       if (mat == 0) {
         double* dst = S + (16 * rt + lk) * ns + 16 * ct + li;
         const double* e1 = Es1 + (size_t)(n + 16 * rt + lk) * n + 16 * ct + li;
+        double ev[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) dst[4 * g * ns] = acc[g] - e1[4 * g * n];
+        for (int g = 0; g < 4; ++g) ev[g] = e1[4 * g * n];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[4 * g * ns] = acc[g] - ev[g];
       } else {
         double* dst = X + (16 * rt + lk) * xs + 16 * ct + li;
 #pragma unroll
