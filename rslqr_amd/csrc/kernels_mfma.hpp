@@ -46,9 +46,18 @@ __global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, doub
     // stage -f_p (lambda rows of knot s+1 in column p), row-major [k][c], padded rows
     const double* f = Fblk(F, d, b, col, s + 1);
     __syncthreads();
-    for (int e = threadIdx.x; e < NX * NX; e += 256) {
-      const int k = e / NX, c = e - k * NX;
-      fl[k * LDSW + c] = -f[e];
+    {  // all loads of the block before the first LDS store (a loop around load + store completes
+       // them one after the other)
+      constexpr int IT = NX * NX / 256;
+      static_assert(NX * NX % 256 == 0, "whole rounds of the 256 threads");
+      double t[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) t[it] = f[threadIdx.x + 256 * it];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int e = threadIdx.x + 256 * it, k = e / NX, c = e - k * NX;
+        fl[k * LDSW + c] = -t[it];
+      }
     }
     __syncthreads();
     double* g = Fblk(F, d, b, col, i);
@@ -85,7 +94,13 @@ __global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, doub
     double* zp = z + ((size_t)b * N + i) * rows + r;
     const double* Erow = E + (size_t)r * NX;
     double acc = *zp;
-    for (int k = 0; k < NX; ++k) acc = fma(-Erow[k], zsep[k], acc);
+    for (int k0 = 0; k0 < NX; k0 += 16) {  // sixteen operand pairs per load round, same order of summation
+      double ev[16], zv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { ev[u] = Erow[k0 + u]; zv[u] = zsep[k0 + u]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fma(-ev[u], zv[u], acc);
+    }
     *zp = acc;
   }
 }
