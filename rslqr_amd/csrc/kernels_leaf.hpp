@@ -25,6 +25,20 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
   for (int i = threadIdx.x; i < n + (last ? 0 : m); i += blockDim.x)
     if (!(qr[i] > 0.0)) flag_failure(info, d, b);
 
+  // Fast mode: one reciprocal per weight instead of sqrt + two divisions per factor element
+  // (L * L == q up to rounding; strict mode keeps the reference's operations)
+  __shared__ double rqs[256];
+  const bool use_rq = !STRICT && w <= 256;
+  if (use_rq) {
+    for (int i = threadIdx.x; i < w; i += blockDim.x) rqs[i] = 1.0 / qr[i];
+    __syncthreads();
+  }
+  auto scaled = [&](const double x, const int i) -> double {  // x / Q_i (i < n) or x / R_{i-n}
+    if (use_rq) return x * rqs[i];
+    const double sq = qr[i] / sqrt(qr[i]);
+    return (x / sq) / sq;
+  };
+
   if (k == 0) {
     double* F0 = Fblk(F, d, b, 0, 0);
     for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
@@ -34,8 +48,7 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
         v = -ab[c * w + r];  // Fy = -A'
       } else if (r >= 2 * n) {
         const int i = r - 2 * n;
-        const double s = qr[n + i] / sqrt(qr[n + i]);
-        v = (ab[c * w + n + i] / s) / s;  // Fu = R \ B'
+        v = scaled(ab[c * w + n + i], n + i);  // Fu = R \ B'
       }
       F0[e] = v;
     }
@@ -46,8 +59,7 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
       } else if (i < 2 * n) {
         v = -r0[i - n];  // zx = -zy_old
       } else {
-        const double s = qr[i - n] / sqrt(qr[i - n]);
-        v = (r0[i] / s) / s;  // zu = R \ zu
+        v = scaled(r0[i], i - n);  // zu = R \ zu
       }
       zk[i] = v;
     }
@@ -62,12 +74,10 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
       double v = 0.0;
       if (r >= 2 * n) {
         const int i = r - 2 * n;
-        const double s = qr[n + i] / sqrt(qr[n + i]);
-        v = (ab[c * w + n + i] / s) / s;  // Fu = R \ B'
+        v = scaled(ab[c * w + n + i], n + i);  // Fu = R \ B'
       } else if (r >= n) {
         const int i = r - n;
-        const double s = qr[i] / sqrt(qr[i]);
-        v = (ab[c * w + i] / s) / s;  // Fx = Q \ A'
+        v = scaled(ab[c * w + i], i);  // Fx = Q \ A'
       }
       Fk[e] = v;
     }
@@ -76,21 +86,13 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
   for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
     const int r = e / n, c = e - r * n;
     double v = 0.0;
-    if (r >= n && r < 2 * n && r - n == c) {
-      const double s = qr[c] / sqrt(qr[c]);
-      v = (-1.0 / s) / s;  // Q \ (-I)
-    }
+    if (r >= n && r < 2 * n && r - n == c) v = scaled(-1.0, c);  // Q \ (-I)
     Fp[e] = v;
   }
   for (int i = threadIdx.x; i < rows; i += blockDim.x) {
     double v = r0[i];
-    if (i >= n && i < 2 * n) {
-      const double s = qr[i - n] / sqrt(qr[i - n]);
-      v = (v / s) / s;
-    } else if (i >= 2 * n && !last) {
-      const double s = qr[i - n] / sqrt(qr[i - n]);
-      v = (v / s) / s;
-    }
+    if (i >= n && i < 2 * n) v = scaled(v, i - n);
+    else if (i >= 2 * n && !last) v = scaled(v, i - n);
     zk[i] = v;
   }
 }
