@@ -43,40 +43,44 @@ namespace ndlqr {
 // Sblk = &S[j0 * ns + j0] (LDS, row pitch ns), Wblk: 16 x 16, row pitch 17 (LDS).
 __device__ __forceinline__ bool chol16_and_inverse(double* Sblk, const int ns, double* Wblk, const int lane) {
   const int r = lane & 15;
-  double acc[16], rinvs[16], w[16];
+  double acc[16], w[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) acc[c] = Sblk[r * ns + c];
-  bool bad = false;
+  // Left-looking Cholesky, one row per lane, fused with the forward substitution of the unit
+  // vectors (lane c: column c of W = L11^-1): step j broadcasts row j of L once and uses it for
+  // both (see factor_solve_mc in kernels_bottom_reduced.hpp)
+  double rinv_last = 0.0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    double v = acc[j];
+    double v = acc[j], sacc = (j == r) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < j; ++k) v = fma(-acc[k], readlane_f64(acc[k], j), v);
-    acc[j] = v;
-    const double pivot = readlane_f64(acc[j], j);
-    bad |= !(pivot > 0.0);  // no short-circuit: keeps the pivot loop one basic block
-    const double rinv = rsqrt(pivot);
-    acc[j] = acc[j] * rinv;
-    rinvs[j] = rinv;
+    for (int k = 0; k < j; ++k) {
+      const double bc = readlane_f64(acc[k], j);
+      v = fma(-acc[k], bc, v);
+      sacc = fma(-bc, w[k], sacc);
+    }
+    const double pivot = readlane_f64(v, j);
+    // 1 / sqrt(pivot): hardware estimate + one Newton step; a non-positive pivot turns into NaN
+    // and stays NaN through every later pivot: one test after the last step
+    const double y0 = __builtin_amdgcn_rsq(pivot);
+    const double e = fma(-pivot * y0, y0, 1.0);
+    const double rinv = fma(y0 * e, 0.5, y0);
+    acc[j] = v * rinv;
+    w[j] = sacc * rinv;
+    rinv_last = rinv;
     __builtin_amdgcn_sched_barrier(0);
+  }
+  const bool bad = !((rinv_last > 0.0) & (rinv_last < 1.0e300));
+  {  // every lane stores (lanes >= 16, replicas, into the pad column): a store under a lane
+     // predicate makes the compiler sink the W recurrence behind it, away from the broadcasts
+    const int wc = lane < 16 ? lane : 16;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) Wblk[rr * 17 + wc] = w[rr];
   }
   if (lane < 16) {
 #pragma unroll
     for (int c = 0; c < 16; ++c)
       if (c <= r) Sblk[r * ns + c] = acc[c];
-  }
-  // column r of W = L11^-1 by forward substitution on the unit vector e_r
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    double sacc = (rr == r) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < rr; ++k) sacc = fma(-readlane_f64(acc[k], rr), w[k], sacc);
-    w[rr] = sacc * rinvs[rr];
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (lane < 16) {
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) Wblk[rr * 17 + r] = w[rr];
   }
   return bad;
 }
