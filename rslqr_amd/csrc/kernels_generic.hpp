@@ -668,15 +668,40 @@ static __global__ void backsub_multipliers_generic(Dims d, int l, const double* 
   const double* yA = z + ((size_t)b * N + base) * rows;      // y_A lives in the lambda rows of knot A+1 = base
   const double* yB = z + ((size_t)b * N + base + T) * rows;
   double* out = z + ((size_t)b * N + s + 1) * rows;
-  for (int r = 0; r < n; ++r) {
-    double part = 0.0;
+  // eight record rows per load round (a row at a time is a memory round trip per row); per row the
+  // same order of summation as before
+  for (int r0 = 0; r0 < n; r0 += 8) {
+    double part[8], zr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      part[u] = 0.0;
+      zr[u] = rc[2 * n * n + (r0 + u < n ? r0 + u : n - 1)];
+    }
     for (int c = lane; c < n; c += 64) {
-      if (hasA) part = fma(rc[(size_t)r * n + c], yA[c], part);
-      if (hasB) part = fma(rc[(size_t)n * n + (size_t)r * n + c], yB[c], part);
+      double fa[8], fb[8], ya = 0.0, yb = 0.0;
+      if (hasA) {  // uniform
+        ya = yA[c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fa[u] = rc[(size_t)(r0 + u < n ? r0 + u : n - 1) * n + c];
+      }
+      if (hasB) {
+        yb = yB[c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fb[u] = rc[(size_t)n * n + (size_t)(r0 + u < n ? r0 + u : n - 1) * n + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (hasA) part[u] = fma(fa[u], ya, part[u]);
+        if (hasB) part[u] = fma(fb[u], yb, part[u]);
+      }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (lane == 0) out[r] = rc[2 * n * n + r] - part;
+    for (int u = 0; u < 8; ++u) {
+      double p = part[u];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+      if (lane == 0 && r0 + u < n) out[r0 + u] = zr[u] - p;
+    }
   }
 }
 
@@ -694,8 +719,20 @@ static __global__ void backsub_states_generic(Dims d, const double* __restrict__
   const double* yk = zk + rows;  // y_k: lambda rows of knot k+1
   const int col = r < n ? r : r - n;  // column of [A_k | B_k] this row meets
   double dot = 0.0;
-  if (k < N - 1 && !(k == 0 && r >= n && r < 2 * n))
-    for (int c = 0; c < n; ++c) dot = fma(ab[(size_t)c * w + col], yk[c], dot);
+  if (k < N - 1 && !(k == 0 && r >= n && r < 2 * n)) {
+    for (int c0 = 0; c0 < n; c0 += 16) {  // sixteen operand pairs per load round, same order of summation
+      double av[16], yv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int c = c0 + u < n ? c0 + u : n - 1;
+        av[u] = ab[(size_t)c * w + col];
+        yv[u] = yk[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (c0 + u < n) dot = fma(av[u], yv[u], dot);
+    }
+  }
   double out;
   if (r < n) out = fma(-qr[r], r0[r], -r0[n + r]) + dot;                               // knot 0: Q x0 + q + A_0' y_0
   else if (r < 2 * n) out = (k == 0) ? -r0[r - n] : (r0[r] - dot + zk[r - n]) / qr[r - n];  // x_k (zk[.] = y_{k-1})
