@@ -73,12 +73,18 @@ __global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, doub
       const double* Erow = E + (size_t)(16 * t + li) * NX + lk;
 #pragma unroll
       for (int q = 0; q < KS; ++q) afrag[q] = Erow[4 * q];
+      // the accumulators of all column tiles first (one load round), then the products
+      mfma_acc_t accs[NB];
 #pragma unroll
       for (int ct = 0; ct < NB; ++ct) {
-        double* gt = g + (size_t)(16 * t + lk) * NX + 16 * ct + li;  // row lk + 4 * reg
-        mfma_acc_t acc;
-        if (created) { acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0; }
-        else { acc[0] = gt[0]; acc[1] = gt[4 * NX]; acc[2] = gt[8 * NX]; acc[3] = gt[12 * NX]; }
+        const double* gt = g + (size_t)(16 * t + lk) * NX + 16 * ct + li;  // row lk + 4 * reg
+        if (created) { accs[ct][0] = 0.0; accs[ct][1] = 0.0; accs[ct][2] = 0.0; accs[ct][3] = 0.0; }
+        else { accs[ct][0] = gt[0]; accs[ct][1] = gt[4 * NX]; accs[ct][2] = gt[8 * NX]; accs[ct][3] = gt[12 * NX]; }
+      }
+#pragma unroll
+      for (int ct = 0; ct < NB; ++ct) {
+        double* gt = g + (size_t)(16 * t + lk) * NX + 16 * ct + li;
+        mfma_acc_t acc = accs[ct];
         const double* bcol = fl + lk * LDSW + 16 * ct + li;
 #pragma unroll
         for (int q = 0; q < KS; ++q)
