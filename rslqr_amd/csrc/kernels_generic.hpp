@@ -108,6 +108,7 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   const double* Fbs1 = bb >= 0 ? Fblk(F, d, b, bb, s + 1) : Es1;
   const double* zsl = z + ((size_t)b * N + s) * d.rows;
   double* zs1 = z + ((size_t)b * N + s + 1) * d.rows;
+  SEG_INIT();
 
   // ---- P1: inner products. Row i of A_s, B_s against the state / input rows of knot s,
   //      minus the state rows of knot s+1 (its coupling block is [-I; 0]).
@@ -203,7 +204,9 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
     }
     X[i * xs + 2 * n] = acc - zlast;
   }
+  SEG(40);
   __syncthreads();
+  SEG(41);
 
   // ---- P2: lower Cholesky in LDS, right-looking: finish column j, then subtract its outer
   //      product from the remaining lower triangle (wavefront per column c, lane per row i >= c).
@@ -246,6 +249,7 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       }
       if (rem > 0) __syncthreads();
     }
+    SEG(42);
     // substitutions, block rows at a time: X_blk <- W X_blk, rows below -= L[rows, blk] X_blk;
     // then X_blk <- W' X_blk, rows above -= L[blk, rows]' X_blk
     const int ctl = (ncols + 15) / 16;
@@ -301,6 +305,7 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       if (jb > 0) __syncthreads();
     }
     __syncthreads();
+    SEG(43);
   } else {
   for (int j = 0; j < n; ++j) {
     const double pivot = S[j * ns + j];
@@ -433,15 +438,22 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   }  // per-pivot path
 
   // ---- store into the lambda rows of knot s+1 (columns l, a, bb) and of the rhs
-  double* outS = Fblk(F, d, b, l, s + 1);
-  double* outa = a >= 0 ? Fblk(F, d, b, a, s + 1) : nullptr;
-  double* outb = bb >= 0 ? Fblk(F, d, b, bb, s + 1) : nullptr;
-  for (int i = wave; i < n; i += nwave)
-    for (int c = lane; c < n; c += 64) {
-      outS[i * n + c] = S[i * ns + c];
-      if (outa) outa[i * n + c] = X[i * xs + c];
-      if (outb) outb[i * n + c] = X[i * xs + n + c];
-    }
+  // With records (fast mode without KEEP: boundary-first schedule, solution by back-substitution)
+  // the lambda rows of the factor array are dead data: nothing that reaches a state / input row or a
+  // record ever reads them (the boundary Schur pass takes f_a, f_bb from the record), so the
+  // Cholesky factor and the two blocks are not written there -- 96 of 160 KB per separator at
+  // (64, 16), and the workgroup's LDS is only released when its stores have drained.
+  if (!rec) {
+    double* outS = Fblk(F, d, b, l, s + 1);
+    double* outa = a >= 0 ? Fblk(F, d, b, a, s + 1) : nullptr;
+    double* outb = bb >= 0 ? Fblk(F, d, b, bb, s + 1) : nullptr;
+    for (int i = wave; i < n; i += nwave)
+      for (int c = lane; c < n; c += 64) {
+        outS[i * n + c] = S[i * ns + c];
+        if (outa) outa[i * n + c] = X[i * xs + c];
+        if (outb) outb[i * n + c] = X[i * xs + n + c];
+      }
+  }
   for (int i = threadIdx.x; i < n; i += blockDim.x) zs1[i] = X[i * xs + 2 * n];
   if (rec) {
     // record f_a | f_bb | z_sep for the back-substitution (backsub_*_generic): the lambda rows of
@@ -454,6 +466,10 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       }
     for (int i = threadIdx.x; i < n; i += blockDim.x) myrec[2 * n * n + i] = X[i * xs + 2 * n];
   }
+#ifdef NDLQR_SEGTIME
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SEG(44);
 }
 
 // ------------------------------------------------------------------------------------- Schur update
@@ -465,7 +481,7 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
 // separators read; the other knots get their solution from the back-substitution): the grid
 // then covers 2 * (N >> (l+1)) knots.
 template <bool STRICT>
-__global__ void schur_generic(Dims d, int l, double* F, double* z, int boundary) {
+__global__ void schur_generic(Dims d, int l, double* F, double* z, int boundary, const double* recs = nullptr) {
   const int n = d.n, rows = d.rows, N = d.N;
   const int b = blockIdx.y;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,6 +497,9 @@ __global__ void schur_generic(Dims d, int l, double* F, double* z, int boundary)
   outer_columns(base, l, N, a, bb);
   const bool left = i <= s;
   const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;  // nested_dissection.c:173-177
+  // recs (boundary pass of the record-based schedule): f_a, f_bb come from the separator's record
+  // and the lambda rows, dead data there, are left alone
+  if (r < n && recs) return;
   if (r < n && !calc_lambda) {
     // lambda rows are not updated here; a freshly created block gets explicit zeros there,
     // except at knot s+1 whose lambda rows already hold f_a / f_bb from the separator kernel.
@@ -490,16 +509,17 @@ __global__ void schur_generic(Dims d, int l, double* F, double* z, int boundary)
     }
     return;
   }
+  const double* myrec = recs ? recs + ((size_t)b * N + s) * (2 * (size_t)n * n + n) : nullptr;
   const double* Erow = Fblk(F, d, b, l, i) + r * n;
   if (a >= 0) {
-    const double* f = Fblk(F, d, b, a, s + 1);  // lambda rows = f_a (n x n, row-major)
+    const double* f = myrec ? myrec : Fblk(F, d, b, a, s + 1);  // lambda rows = f_a (n x n, row-major)
     double* g = Fblk(F, d, b, a, i) + r * n + c;
     double acc = left ? *g : 0.0;
     for (int k = 0; k < n; ++k) acc = mad<STRICT>(-Erow[k], f[k * n + c], acc);
     *g = acc;
   }
   if (bb >= 0) {
-    const double* f = Fblk(F, d, b, bb, s + 1);
+    const double* f = myrec ? myrec + (size_t)n * n : Fblk(F, d, b, bb, s + 1);
     double* g = Fblk(F, d, b, bb, i) + r * n + c;
     double acc = left ? 0.0 : *g;
     for (int k = 0; k < n; ++k) acc = mad<STRICT>(-Erow[k], f[k * n + c], acc);

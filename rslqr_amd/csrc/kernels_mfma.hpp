@@ -20,7 +20,8 @@ typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 //   NB = nstates / 16. grid (N, batch) -- or (2 * (N >> (l+1)), batch) in boundary mode --, block 256,
 //   dynamic LDS = n * (n + 16) doubles.
 template <int NB>
-__global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, double* z, int boundary) {
+__global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, double* z, int boundary,
+                                                  const double* recs = nullptr) {
   constexpr int NX = 16 * NB, KS = NX / 4;
   // LDS row length with 2 * LDSW = 32 (mod 64) dwords: the two k-rows a 32-lane group reads hit disjoint banks
   constexpr int LDSW = (NX % 32 == 16) ? NX : NX + 16;
@@ -44,7 +45,10 @@ __global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, doub
     if (col < 0) continue;  // uniform
     const bool created = pass == 0 ? !left : left;
     // stage -f_p (lambda rows of knot s+1 in column p), row-major [k][c], padded rows
-    const double* f = Fblk(F, d, b, col, s + 1);
+    // recs (boundary pass of the record-based schedule): f_a / f_bb from the separator's record;
+    // the lambda rows of the factor array are dead data there and are skipped below
+    const double* f = recs ? recs + ((size_t)b * N + s) * (2 * (size_t)NX * NX + NX) + (pass == 0 ? 0 : NX * NX)
+                           : Fblk(F, d, b, col, s + 1);
     __syncthreads();
     {  // all loads of the block before the first LDS store (a loop around load + store completes
        // them one after the other)
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, doub
     double* g = Fblk(F, d, b, col, i);
     for (int t = wave; t < RT; t += 4) {
       const bool lamtile = 16 * t < NX;  // NX % 16 == 0: a tile is entirely lambda rows or not
+      if (lamtile && recs) continue;
       if (lamtile && !calc_lambda) {
         if (created && i != s + 1) {  // explicit zeros, like schur_generic
           for (int e = lane; e < 16 * NX; e += 64) g[(16 * t) * NX + e] = 0.0;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, doub
   // rhs entry per row: z(i)[r] -= E(r,:) . z_sep   (vector ALU; tiny next to the block products)
   const double* zsep = z + ((size_t)b * N + s + 1) * rows;
   for (int r = threadIdx.x; r < rows; r += 256) {
-    if (r < NX && !calc_lambda) continue;
+    if (r < NX && (recs || !calc_lambda)) continue;
     double* zp = z + ((size_t)b * N + i) * rows + r;
     const double* Erow = E + (size_t)r * NX;
     double acc = *zp;

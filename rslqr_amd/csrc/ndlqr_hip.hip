@@ -232,17 +232,21 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
       const bool mfma = !STRICT && d.n % 16 == 0 && d.rows % 16 == 0 && d.n <= 64 && !c->no_mfma;
       const size_t flds = sizeof(double) * (size_t)d.n * (d.n + 16);
       if (mfma && d.n == 64)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<4>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<4>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd,
+                           (const double*)rec);
       else if (mfma && d.n == 48)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<3>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<3>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd,
+                           (const double*)rec);
       else if (mfma && d.n == 32)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<2>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<2>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd,
+                           (const double*)rec);
       else if (mfma && d.n == 16)
-        hipLaunchKernelGGL((ndlqr::schur_mfma<1>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd);
+        hipLaunchKernelGGL((ndlqr::schur_mfma<1>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd,
+                           (const double*)rec);
       else {
         const long work = (long)gx * d.rows * d.n;
         hipLaunchKernelGGL((ndlqr::schur_generic<STRICT>), dim3((unsigned)((work + 255) / 256), d.batch),
-                           dim3(256), 0, c->stream, d, l, c->F, c->z, bnd);
+                           dim3(256), 0, c->stream, d, l, c->F, c->z, bnd, (const double*)rec);
       }
     }
   }

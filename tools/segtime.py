@@ -32,6 +32,9 @@ NAMES = {0: "level: stage operands", 1: "level core: P1", 2: "level core: P2 (Ch
          30: "mc core: S-bar rows, Cholesky + inverse", 31: "mc core: W to operands, S^-1 = W'W",
          32: "mc core: X = S^-1 R", 33: "mc core: hook (Schur blocks R'X, pushes)", 34: "mc: (re-arm)",
          35: "bottom_mc: record store", 36: "bottom_mc: last record store + drain",
+         40: "generic separator: P1 products + rhs (own work)", 41: "generic separator: barrier behind P1",
+         42: "generic separator: blocked Cholesky", 43: "generic separator: blocked substitutions",
+         44: "generic separator: stores + drain",
          25: "bottom: row update + rotate", 26: "bottom: barrier end of level", 27: "bottom: hand-off"}
 
 
@@ -57,6 +60,8 @@ def main():
     import rslqr_amd
     from rslqr_amd import api
     n, m, N, batch = 12, 4, 256, 1024
+    if "--config5" in sys.argv:
+        n, m, N, batch = 64, 16, 512, 64
     bs = rslqr_amd.BatchSolver(n, m, N, batch)
     bs.initialize_synthetic(1)
     L = api.lib()
