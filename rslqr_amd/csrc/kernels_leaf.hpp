@@ -12,7 +12,9 @@ namespace ndlqr {
 template <bool STRICT>
 __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                              const double* __restrict__ rhs, double* __restrict__ F,
-                             double* __restrict__ z, int* __restrict__ info) {
+                             double* __restrict__ z, int* __restrict__ info, const int lean = 0) {
+  // lean (record-based schedule: fast mode without KEEP, runtime-sized path): the lambda rows of the
+  // factor blocks are dead data there (see separator_generic) and are not written -- n of 2n + m rows
   const int k = blockIdx.x, b = blockIdx.y;
   const int n = d.n, m = d.m, w = d.w, rows = d.rows, N = d.N;
   const double* ab = AB + ((size_t)b * N + k) * n * w;
@@ -41,7 +43,7 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
 
   if (k == 0) {
     double* F0 = Fblk(F, d, b, 0, 0);
-    for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
+    for (int e = threadIdx.x + (lean ? n * n : 0); e < rows * n; e += blockDim.x) {
       const int r = e / n, c = e - r * n;
       double v = 0.0;
       if (r < n) {
@@ -69,7 +71,7 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
   const int lvl = trailing_ones(k), plvl = trailing_ones(k - 1);
   if (!last) {
     double* Fk = Fblk(F, d, b, lvl, k);
-    for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
+    for (int e = threadIdx.x + (lean ? n * n : 0); e < rows * n; e += blockDim.x) {
       const int r = e / n, c = e - r * n;
       double v = 0.0;
       if (r >= 2 * n) {
@@ -83,7 +85,7 @@ __global__ void leaf_generic(Dims d, const double* __restrict__ AB, const double
     }
   }
   double* Fp = Fblk(F, d, b, plvl, k);
-  for (int e = threadIdx.x; e < rows * n; e += blockDim.x) {
+  for (int e = threadIdx.x + (lean ? n * n : 0); e < rows * n; e += blockDim.x) {
     const int r = e / n, c = e - r * n;
     double v = 0.0;
     if (r >= n && r < 2 * n && r - n == c) v = scaled(-1.0, c);  // Q \ (-I)

@@ -198,7 +198,7 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
   {
     ScopedSlot t(c, SLOT_LEAF);
     hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
-                       c->AB, c->QR, c->rhs, c->F, c->z, c->info);
+                       c->AB, c->QR, c->rhs, c->F, c->z, c->info, lean ? 1 : 0);
   }
   // S (n x (n+1)) + right-hand-side panel (n x pitch; pitch = 2n+1 padded to whole 16-column tiles + 1)
   // (+ on the matrix-core path the inverses of the 16x16 diagonal blocks of the factor, pitch 17)
