@@ -2,21 +2,30 @@
 """bench.py -- headline benchmark: LQR solves/sec at (nx=12, nu=4, N=256, batch=1024 per GPU).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --nx 64 --nu 16 --horizon 512 --batch 256        # BASELINE config 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one ndlqr_SolveBatch (factor + substitute, the reference's ndlqr_Solve,
 src/solve.c:38-190) over the rank's batch of independent synthetic problems, inputs already
-resident in HBM. The batch axis is the sharding unit: every rank owns `--batch` problems
-(weak scaling), there is no data-path collective; torch.distributed (RCCL) is used only for
-the barriers and the max-over-ranks of the elapsed time.
+resident in HBM. The batch axis is the sharding unit: every rank owns `--batch` problems (weak
+scaling), there is no data-path collective; torch.distributed (RCCL) carries the barriers, the
+max-over-ranks of the elapsed time and -- outside `value` -- the optional gather of the solutions.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     -- dominant kernel (the per-level kernel), algorithmic bytes of SURVEY.md 8(d)
-                  model (B) for the levels it covers / its HIP-event time, vs 8 TB/s.
+Prints ONE JSON line on rank 0 (contract in the task description) with:
+  roofline     -- dominant kernel of the step: algorithmic bytes and useful flops of the IMPLEMENTED
+                  schedule (rslqr_amd/roofline.py) / its HIP-event launch time
+                  measured in this run, against 8 TB/s and 78.6 TFLOP/s fp64; the larger fraction
+                  labels the bound. `kernels` holds the same for every kernel kind, `step` for the whole
+                  step, `traffic` the PMC-measured HBM bytes per launch of the committed profile of
+                  exactly this source tree (null when the tree differs).
   cpu_baseline -- the reference's own ndlqr_Solve (oracle/_ref/libref.so, "reference") or the
                   plain-C oracle ("port") timed on this host on a bounded sample (N=1, rank 0).
+  transfers    -- H2D of the packed inputs and D2H of the solutions, timed separately (never in `value`).
+  modes        -- N=1: strict mode, KEEP_FACT and the rhs-only re-solve on the same workload.
+  gather       -- N>1: throughput including the all_gather of every shard's solutions.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,57 +36,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md), ~6300 achievable
-
-
-def model_b_bytes(n, m, N):
-    """SURVEY.md 8(d) 'level-streaming' algorithmic bytes per solve: (leaves, [per level])."""
-    K = int(np.log2(N))
-    Fb = (2 * n + m) * n
-    leaves = N * (4 * n * n + 3 * m * n + m * m + 5 * n + 3 * m)
-    levels = []
-    for l in range(K):
-        L = 1 << (K - l - 1)
-        P1 = L * (K - l) * (4 * n * n + 2 * m * n) + L * (n * n + n * m)
-        P2 = 2 * L * n * n
-        P3 = L * n * n + 2 * L * (K - l - 1) * n * n
-        P4 = (N * Fb if l < K - 1 else 0) + L * (K - l - 1) * n * n + 2 * N * (K - l - 1) * Fb
-        S = L * (2 * n * n + n * m + 8 * n + 2 * m) + N * (Fb + 5 * n + 2 * m)
-        levels.append(8 * (P1 + P2 + P3 + P4 + S))
-    return 8 * leaves, levels
-
-
-def model_flops(n, m, N):
-    """SURVEY.md 8(d) algorithmic flops per solve (dense reference schedule): leaves + per level
-    P1 4n^2(n+m) per product, P2 n^3/3, P3 2n^3 per solve, P4 2*Fb*n per block update, plus the
-    rhs sweep (w = 1)."""
-    K = int(np.log2(N))
-    Fb = (2 * n + m) * n
-    fl = N * (n ** 3 / 3 + m ** 3 / 3 + 4 * n ** 3 + 2 * m * m * n)
-    for l in range(K):
-        L = 1 << (K - l - 1)
-        fl += L * (K - l) * 4 * n * n * (n + m) + L * n ** 3 / 3 + L * (K - l - 1) * 2 * n ** 3
-        fl += N * (K - l - 1) * 2 * Fb * n
-        fl += L * (4 * n * (n + m) + 2 * n * n) + N * 2 * Fb
-    return fl
-
-
-def live_bytes(n, m, N):
-    """Bytes the kernels of this build actually have to move per solve (DESIGN.md "live
-    columns"): inputs + rhs once, per level read E + read/write one outer column + write the
-    other + rhs read/write, plus the separator blocks."""
-    K = int(np.log2(N))
-    Fb = (2 * n + m) * n
-    zb = 2 * n + m
-    leaves = N * (n * (n + m) + (n + m) + zb) + N * (2 * Fb + zb)
-    total = leaves
-    for l in range(K):
-        L = 1 << (K - l - 1)
-        cols = 0 if l == K - 1 else 2  # outer columns alive (upper bound; ends have one)
-        sep = L * (n * (n + m) + 2 * Fb + 2 * zb + (1 + cols) * n * n + n)
-        schur = N * (Fb + cols * Fb + (cols - 1 if cols else 0) * Fb + 2 * zb)
-        total += sep + schur
-    return 8 * total
+from rslqr_amd import roofline as rf  # noqa: E402
 
 
 def host_cores():
@@ -98,34 +57,76 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+def csrc_sha():
+    """Content hash of the kernel sources: ties a committed PMC summary to the tree it was taken on
+    (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rslqr_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip", ".c", ".def", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(n, m, N, batch, flags):
+    """{slot: HBM bytes per launch} from the newest profiles/*_traffic.json taken on exactly this
+    source tree and workload, else ({}, why)."""
+    pdir = os.path.join(ROOT, "profiles")
+    sha = csrc_sha()
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not name.endswith("_traffic.json"):
+            continue
+        try:
+            tj = json.load(open(os.path.join(pdir, name)))
+        except (OSError, ValueError):
+            continue
+        if tj.get("workload") == [n, m, N, batch, flags]:
+            best = (name, tj)
+    if best is None:
+        return {}, "no committed PMC summary for this workload"
+    name, tj = best
+    if tj.get("csrc_sha") != sha:
+        return {}, "%s was taken on csrc %s, this tree is %s: not printed" % (name, tj.get("csrc_sha"), sha)
+    return {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}, "profiles/" + name
+
+
 def cpu_baseline(n, m, N, probs, gpu_solutions):
     """Times the CPU checker on a bounded sample; returns (dict, parity_rel_err)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support  # the oracle bindings: used here ONLY as checker / baseline
+    import ctypes as C
     cores = host_cores()
     flat = [np.ascontiguousarray(np.stack([p[k] for p in probs])) for k in
             ("A", "B", "Q", "R", "q", "r", "d", "x0")]
     count = len(probs)
-    import ctypes as C
     args = [a.ctypes.data_as(support.dp) for a in flat]
+    big = rf.model_b_flops(n, m, N) > 2e9  # (64,16,512): seconds per reference solve
     # parity of the GPU result against the checker on the same sample
     orc = support.Oracle()
     worst = 0.0
-    for i, p in enumerate(probs):
+    for i, p in enumerate(probs[: 1 if big else count]):
         prob = support.Problem(n, m, N, p["A"], p["B"], p["Q"], p["R"], p["q"], p["r"], p["d"], p["x0"])
-        z, _, _, _ = orc.solve(prob, 1)
+        z, _, _, _ = orc.solve(prob, cores if big else 1)
         ref = z[: prob.nvars]
         worst = max(worst, float(np.linalg.norm(gpu_solutions[i] - ref) / np.linalg.norm(ref)))
     out = {"cores": cores}
     if support.have_reference():
         ref = support.Reference()
-        # (i) reference semantics: one solve at a time, all cores inside the solve
-        ref.L.ref_bench(n, m, N, min(count, 2), 1, *args, cores)  # warm-up
-        ms_i = ref.L.ref_bench(n, m, N, count, 1, *args, cores)
-        rate_i = count / (ms_i * 1e-3)
-        # (ii) throughput: one thread per solve, all cores busy with different problems
         ref.L.ref_bench_throughput.restype = C.c_double
         ref.L.ref_bench_throughput.argtypes = [C.c_int] * 5 + [support.dp] * 8 + [C.c_int]
+        # (i) reference semantics: one solve at a time, all cores inside the solve
+        ref.L.ref_bench(n, m, N, 1 if big else min(count, 2), 1, *args, cores)  # warm-up
+        ms_i = ref.L.ref_bench(n, m, N, count, 1, *args, cores)
+        rate_i = count / (ms_i * 1e-3)
+        if big:
+            out.update(kind="reference", value=rate_i, unit="solves/s",
+                       sample="%d problems of (%d,%d,%d): reference ndlqr_Solve from oracle/_ref, 1 solve at "
+                              "a time x %d threads (the one-thread-per-solve mode would take minutes here)"
+                              % (count, n, m, N, cores))
+            return out, worst
+        # (ii) throughput: one thread per solve, all cores busy with different problems
         ref.L.ref_bench_throughput(n, m, N, min(count, cores), 1, *args, cores)
         reps = 3
         ms_ii = ref.L.ref_bench_throughput(n, m, N, count, reps, *args, cores)
@@ -138,7 +139,7 @@ def cpu_baseline(n, m, N, probs, gpu_solutions):
     else:
         ms = C.c_double(0)
         orc.L.oracle_bench(n, m, N, min(count, cores), 1, *args, cores, 1, C.byref(ms))
-        reps = 4
+        reps = 1 if big else 4
         orc.L.oracle_bench(n, m, N, count, reps, *args, cores, 1, C.byref(ms))
         rate_ii = count * reps / (ms.value * 1e-3)
         orc.L.oracle_bench(n, m, N, count, 1, *args, cores, 0, C.byref(ms))
@@ -151,6 +152,30 @@ def cpu_baseline(n, m, N, probs, gpu_solutions):
     return out, worst
 
 
+def time_mode(rslqr_amd, n, m, N, batch, device, seed0, flags, steps, rhs_only=False):
+    """ms per step of one more mode of the same workload (own solver, same synthetic problems)."""
+    bs = rslqr_amd.BatchSolver(n, m, N, batch, device=device, flags=flags)
+    try:
+        bs.initialize_synthetic(seed0)
+        if bs.solve() != 0:
+            return None
+        t0 = time.perf_counter()
+        if rhs_only:
+            for _ in range(steps):
+                if bs.solve_rhs_only() != 0:
+                    return None
+        else:
+            for _ in range(steps):
+                bs.solve_async()
+            bs.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        res, bn = bs.kkt_residuals()
+        return {"ms_per_step": ms, "solves_per_s": batch / (ms * 1e-3), "schedule": bs.schedule(),
+                "kkt_residual_rel_max": float((res / np.maximum(1.0, bn)).max())}
+    finally:
+        bs.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,8 +185,10 @@ def main():
     ap.add_argument("--nu", type=int, default=4)
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
-    ap.add_argument("--flags", type=int, default=0, help="NDLQR_FLAG_* bits (1 strict, 2 generic)")
+    ap.add_argument("--flags", type=int, default=0, help="NDLQR_FLAG_* bits (1 strict, 2 generic, 8 keep fact)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-modes", action="store_true", help="skip the strict / KEEP / rhs-only legs")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the solution-gather leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU sample (0 = auto)")
     args = ap.parse_args()
 
@@ -186,11 +213,31 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    ranks_seen = dist.get_world_size() if distributed else 1
+    if ranks_seen != args.gpus:
+        log("WARNING: --gpus %d but the process group has %d ranks" % (args.gpus, ranks_seen))
 
     import rslqr_amd
     n, m, N, batch = args.nx, args.nu, args.horizon, args.batch
+    steps = args.steps
+    big = rf.model_b_flops(n, m, N) > 2e9
+    if big and args.steps == 100:
+        steps = 10  # (64,16,512) x 256: ~50 ms per step
     bs = rslqr_amd.BatchSolver(n, m, N, batch, device=local_rank, flags=args.flags)
     seed0 = sharding.shard_seed0(rank, batch)  # global problem g has seed 1 + g
+
+    # ---- H2D of the packed inputs, timed on its own (pageable host memory, whole batch, before the
+    #      real problems go up): SURVEY.md 8(d) asks for the transfers next to, never inside, `value`
+    w, rows = n + m, 2 * n + m
+    in_bytes = 8 * batch * N * (n * w + w + rows)
+    h2d_ms = None
+    if rank == 0 and in_bytes <= (8 << 30):
+        hAB, hQR, hrhs = np.ones((batch, N, n * w)), np.ones((batch, N, w)), np.ones((batch, N, rows))
+        bs.upload_packed(hAB, hQR, hrhs)
+        t0 = time.perf_counter()
+        bs.upload_packed(hAB, hQR, hrhs)
+        h2d_ms = (time.perf_counter() - t0) * 1e3
+        del hAB, hQR, hrhs
     log("rank %d: generating + uploading %d synthetic problems" % (rank, batch))
     bs.initialize_synthetic(seed0)
     log("rank %d: warm-up" % rank)
@@ -201,18 +248,10 @@ def main():
         torch.cuda.synchronize()
 
     # Timed region: the product path as shipped (launch sequence replayed as a hipGraph).
-    for _ in range(args.warmup):
-        bs.solve_async()
-    bs.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bs.solve_async()
-    bs.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    log("rank %d: %d steps in %.3f s" % (rank, args.steps, elapsed))
+    elapsed = sharding.timed_region(bs, steps, args.warmup, barrier)
+    log("rank %d: %d steps in %.3f s" % (rank, steps, elapsed))
     fails = bs.cholesky_failures()
+    schedule = bs.schedule()
 
     # Per-kernel durations for the roofline object: the SAME K steps once more with a HIP-event
     # pair around every launch on the launch stream. (Events force eager launches, so they cannot
@@ -221,7 +260,7 @@ def main():
     bs.solve()
     bs.profile_reset()
     tp0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         bs.solve_async()
     bs.synchronize()
     elapsed_profiled = time.perf_counter() - tp0
@@ -231,7 +270,7 @@ def main():
     # per-solve device times (HIP events around the replayed launch sequence, one solve at a time):
     # median and minimum next to the mean of the timed region
     per_solve = []
-    for _ in range(min(args.steps, 50)):
+    for _ in range(min(steps, 50)):
         bs.solve()
         per_solve.append(bs.solve_ms())
     per_solve.sort()
@@ -240,66 +279,98 @@ def main():
     # every problem of the shard, checked on the device against its raw data (outside the timed
     # region): worst ||K z - b|| / max(1, ||b||) -- SURVEY.md 8(d) "KKT residual of every problem"
     kres, kbn = bs.kkt_residuals()
-    kkt_worst = float((kres / [max(1.0, v) for v in kbn]).max())
+    kkt_worst = float((kres / np.maximum(1.0, kbn)).max())
 
-    elapsed_max, fails_max, kkt_max = sharding.max_over_ranks(
-        [elapsed, float(fails), kkt_worst], device="cuda" if backend == "nccl" else "cpu")
-    fails_max = int(fails_max)
+    # ---- D2H of the solutions, timed on its own
+    t0 = time.perf_counter()
+    local_sol = bs.solutions()
+    d2h_ms = (time.perf_counter() - t0) * 1e3
+
+    # ---- N>1: the same steps with every shard's solutions gathered after each
+    gather = None
+    if distributed and not args.no_gather:
+        gsteps = min(steps, 20)
+        if backend == "nccl":
+            send = torch.empty((batch, bs.nvars), dtype=torch.float64, device="cuda")
+            recv = torch.empty((world * batch, bs.nvars), dtype=torch.float64, device="cuda")
+
+            def do_gather():
+                bs.solutions_to_device(send.data_ptr())  # pack kernel on the solver's stream
+                bs.synchronize()
+                dist.all_gather_into_tensor(recv, send)   # RCCL over xGMI
+                torch.cuda.synchronize()
+                return recv
+        else:
+            def do_gather():
+                return sharding.gather_solutions(bs.solutions())
+        do_gather()
+        g_elapsed, last = sharding.timed_region_with_gather(bs, gsteps, barrier, do_gather)
+        mine = last[rank * batch:(rank + 1) * batch]
+        mine = mine.cpu().numpy() if hasattr(mine, "cpu") else np.asarray(mine)
+        gather_ok = bool(np.array_equal(mine, local_sol))
+        gather = {"steps": gsteps, "elapsed_s": g_elapsed, "own_shard_intact": gather_ok,
+                  "bytes_per_rank_per_step": 8 * batch * bs.nvars}
+
+    red = [elapsed, float(fails), kkt_worst]
+    if gather:
+        red += [gather["elapsed_s"], 0.0 if gather["own_shard_intact"] else 1.0]
+    red = sharding.max_over_ranks(red, device="cuda" if backend == "nccl" else "cpu")
+    elapsed_max, fails_max, kkt_max = red[0], int(red[1]), red[2]
 
     if rank == 0:
-        total_solves = batch * world * args.steps
+        total_solves = batch * world * steps
         value = total_solves / elapsed_max
-        leaf_b, level_b = model_b_bytes(n, m, N)
-        # Dominant kernel = the slot with the largest HIP-event time. Its algorithmic bytes are the
-        # SURVEY 8(d) model-(B) bytes of exactly the phases it covers:
-        #   bottom          leaf phase + levels 0..JB-1            (1 launch per step)
-        #   apply           Schur/solution sweep of levels J..K-1  (1 launch per step)
-        #   separator+schur one level each (generic / level-by-level path)
-        K = len(level_b)
         used = {k: v for k, v in prof.items() if v[1] > 0}
-        dom = max(used, key=lambda k: used[k][0])
-        JB = int(os.environ.get("NDLQR_BOTTOM_LEVELS", "2"))
-        if dom == "bottom":
-            covered = leaf_b + sum(level_b[:JB])
-            dom_ms, dom_launches = used["bottom"]
-        elif dom == "apply":
-            covered = sum(level_b[JB:])
-            dom_ms, dom_launches = used["apply"]
-        elif dom == "upper":
-            # separators + boundary Schur of levels JB..K-1 in one launch; model (B) charges those
-            # levels' P1-P3 bytes to it and the Schur/solution sweep to apply -- reported together
-            covered = sum(level_b[JB:])
-            dom_ms, dom_launches = used["upper"]
-        else:
-            dom_ms = sum(used[k][0] for k in ("separator", "schur") if k in used)
-            dom_launches = used.get("schur", used.get("separator"))[1]
-            covered = sum(level_b) / K
-            dom = "separator+schur"
-        avg_ms = dom_ms / max(dom_launches, 1)
-        bytes_per_launch = covered * batch
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # measured HBM bytes per launch of that kernel: committed PMC summary of the same config
-        # (rocprofv3 cannot run inside this process; profiles/r01_traffic.json says how it was taken)
-        traffic, issue = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if (n, m, N, batch, args.flags) == (12, 4, 256, 1024, 0) and dom in tj["kernels"]:
-                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
-                issue = tj.get("issue", {}).get(dom)
-                if issue and "executed_flops_per_wave" in issue and dom == "bottom":
-                    # executed (not algorithmic) fp64 rate of the dominant kernel: flops per wavefront
-                    # from the ISA x wavefronts of this launch / its measured duration
-                    issue = dict(issue)
-                    waves = (N // 4) * batch
-                    issue["executed_tflops"] = issue["executed_flops_per_wave"] * waves / (avg_ms * 1e-3) / 1e12
-                    issue["executed_frac_of_fp64_peak"] = issue["executed_tflops"] / 78.6
-        except (OSError, ValueError, KeyError):
-            pass
-        whole_solve_gbs = (leaf_b + sum(level_b)) * value / world / 1e9
+        model = rf.model_for(schedule, n, m, N)
+        traffic, traffic_src = committed_traffic(n, m, N, batch, args.flags)
+        kernels = {}
+        for slot, (ms, launches) in used.items():
+            avg_ms = ms / launches
+            entry = {"avg_launch_ms": avg_ms, "launches_per_step": launches / steps,
+                     "ms_per_step": ms / steps}
+            if model and slot in model:
+                entry.update(rf.kernel_roofline(model[slot], batch, avg_ms))
+                assert 0.0 < entry["frac"] <= 1.0, (slot, entry)
+            entry["traffic"] = traffic.get(slot)
+            kernels[slot] = entry
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        step_ms = elapsed_max / steps * 1e3
+        roofline = dict(kernels[dom])
+        roofline["kernel"] = dom
+        roofline["schedule"] = schedule
+        if "frac" not in roofline:
+            # strict / KEEP schedules stream the whole factor array level by level: SURVEY 8(d) model (B)
+            # is what they execute
+            b = rf.model_b_bytes(n, m, N) * batch
+            gbs = b / (sum(k["ms_per_step"] for k in kernels.values()) * 1e-3) / 1e9
+            roofline.update(bound="hbm", achieved=gbs, peak=rf.HBM_PEAK_GBS, unit="GB/s", frac=gbs / rf.HBM_PEAK_GBS,
+                            note="whole step against SURVEY.md 8(d) model (B) level-streaming bytes")
+        roofline["traffic_source"] = traffic_src
+        if model:
+            sb = sum(v["bytes"] for v in model.values()) * batch
+            sf = sum(v["flops"] for v in model.values()) * batch
+            dev_ms = sum(k["ms_per_step"] for k in kernels.values())
+            roofline["step"] = {
+                "algorithmic_bytes": sb, "useful_flops": sf, "kernel_ms": dev_ms,
+                "hbm_frac": sb / (dev_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
+                "fp64_frac": sf / (dev_ms * 1e-3) / 1e12 / rf.FP64_PEAK_TFLOPS,
+                # inputs read once + solution written once (SURVEY 8(d) floor (A)): what a perfectly
+                # fused solver would move -- the step's distance from the HBM roof of the PROBLEM
+                "compulsory_bytes": rf.compulsory_bytes(n, m, N) * batch,
+                "compulsory_hbm_frac": rf.compulsory_bytes(n, m, N) * batch / (dev_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
+                "traffic": sum(kernels[k]["traffic"] * kernels[k]["launches_per_step"] for k in kernels)
+                if all(kernels[k]["traffic"] for k in kernels) else None,
+            }
+        roofline["kernels"] = {k: v for k, v in kernels.items() if k != dom}
+        # the reference's dense schedule priced at this throughput (> peak: the bytes are not moved)
+        roofline["vs_level_streaming_model"] = {
+            "model_b_bytes_per_solve": rf.model_b_bytes(n, m, N),
+            "equivalent_gbs_per_gpu": rf.model_b_bytes(n, m, N) * value / world / 1e9,
+            "model_b_flops_per_solve": rf.model_b_flops(n, m, N)}
         result = {
             "metric": "LQR solves/sec (nx=%d,nu=%d,N=%d,batch=%d per GPU)" % (n, m, N, batch),
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": step_ms,
             "ms_per_solve": 1e3 / value,
             "device_ms_per_step": {"median": dev_median, "min": dev_min, "reps": len(per_solve),
                                    "note": "rank 0, HIP events per solve, one solve in flight"},
@@ -308,36 +379,43 @@ def main():
             "config": {"workload": "nx=%d nu=%d N=%d batch=%d per GPU, fp64, factor+solve per step"
                                    % (n, m, N, batch),
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "flags": args.flags, "cholesky_failures": fails_max,
-                       "kkt_residual_rel_max": kkt_max},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": dom_launches,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "whole_solve_model_b_gbs_per_gpu": whole_solve_gbs,
-                         "live_column_bytes_per_solve": live_bytes(n, m, N),
-                         # the kernels are fp64 VALU-issue bound after the traffic reduction: the
-                         # compute roof next to the (contractual) HBM one. Algorithmic flops of
-                         # the dense reference schedule; structural zeros are skipped at run time.
-                         "fp64": {"algorithmic_flops_per_solve": model_flops(n, m, N),
-                                  "achieved_tflops": model_flops(n, m, N) * value / world / 1e12,
-                                  "peak_tflops": 78.6,
-                                  "frac": model_flops(n, m, N) * value / world / 1e12 / 78.6},
-                         "model_b_bytes_per_solve": leaf_b + sum(level_b),
-                         # what actually bounds the dominant kernel (SQ counters of the committed
-                         # profile, not measured in this run): fp64 vector-ALU + matrix issue time
-                         "issue_bound_profile": issue},
-            "kernel_ms": {k: {"total_ms": v[0], "launches": v[1]} for k, v in prof.items() if v[1]},
+                       "ranks_seen": ranks_seen, "backend": backend if distributed else None,
+                       "flags": args.flags, "schedule": schedule, "cholesky_failures": fails_max,
+                       "kkt_residual_rel_max": kkt_max, "csrc_sha": csrc_sha()},
+            "roofline": roofline,
             "kernel_ms_note": "second pass of the same %d steps with per-launch HIP events (eager "
                               "launches): %.3f ms/step vs %.3f ms/step in the timed, graph-replayed region"
-                              % (args.steps, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3),
+                              % (steps, elapsed_profiled / steps * 1e3, step_ms),
+            "transfers": {"h2d_ms": h2d_ms, "h2d_bytes": in_bytes, "d2h_ms": d2h_ms,
+                          "d2h_bytes": 8 * batch * bs.nvars,
+                          "note": "rank 0, pageable host memory, whole shard; not part of `value`"},
         }
+        if gather:
+            g_el, g_bad = red[3], red[4]
+            result["gather"] = {
+                "steps": gather["steps"], "value_incl_gather": batch * world * gather["steps"] / g_el,
+                "ms_per_step_incl_gather": g_el / gather["steps"] * 1e3,
+                "collective": "all_gather_into_tensor (RCCL)" if backend == "nccl" else "all_gather (gloo, host)",
+                "bytes_per_rank_per_step": gather["bytes_per_rank_per_step"],
+                "every_rank_found_its_shard_intact": g_bad == 0.0,
+                "note": "solve, pack kernel, host sync, all_gather of [batch, nvars] per step; `value` excludes it"}
+        if world == 1 and not args.no_modes and not big and args.flags == 0:
+            log("secondary modes (strict / KEEP_FACT / rhs-only)")
+            msteps = min(steps, 20)
+            result["modes"] = {
+                "strict_fp (flags=1, bit-identical to the reference)":
+                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 1, msteps),
+                "keep_fact (flags=8, complete factor array materialised)":
+                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 8, msteps),
+                "rhs_only (flags=16 records kept, new right-hand side per step)":
+                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 16, msteps, rhs_only=True)}
         if world == 1 and not args.no_cpu:
             cores = host_cores()
             log("cpu_baseline leg on %d cores" % cores)
-            count = args.cpu_sample or max(8, min(batch, 8 * cores))  # ~10 s of CPU work
+            count = args.cpu_sample or (3 if big else max(8, min(batch, 8 * cores)))  # ~10-30 s of CPU work
+            count = min(count, batch)
             probs = [rslqr_amd.generate_synthetic(n, m, N, seed0 + p) for p in range(count)]
-            gpu_sol = [bs.solution(p) for p in range(count)]
+            gpu_sol = [local_sol[p] for p in range(count)]
             base, worst = cpu_baseline(n, m, N, probs, gpu_sol)
             result["cpu_baseline"] = base
             result["parity_rel_err_vs_cpu"] = worst

@@ -218,10 +218,10 @@ int ndlqr_GetSFactorization(NdLqrCholeskyFactors* cholfacts, int leaf, int level
 typedef struct {
   double t_total_ms;
   double t_leaves_ms;
-  double t_products_ms;
-  double t_cholesky_ms;
-  double t_cholsolve_ms;
-  double t_shur_ms;
+  double t_products_ms;  /* device: separator kernels (products + Cholesky + solves fused) */
+  double t_cholesky_ms;  /* device: always 0 (fused into the separator kernels) */
+  double t_cholsolve_ms; /* device: always 0 (fused into the separator kernels) */
+  double t_shur_ms;      /* device: Schur-update kernels + solution sweep */
   int num_threads;
 } NdLqrProfile;
 
@@ -249,6 +249,8 @@ typedef struct {
   int num_threads;   /* accepted and reported; irrelevant on the device */
   /* ---- appended (not in the reference) ---- */
   void* device_ctx;  /* opaque: batch-of-1 device solver */
+  unsigned device_flags;     /* NDLQR_FLAG_* used by ndlqr_Solve (ndlqr_SetDeviceFlags; default 0) */
+  int device_profiling_off;  /* ndlqr_SetDeviceProfiling(solver, 0) */
 } NdLqrSolver;
 
 NdLqrSolver* ndlqr_NewNdLqrSolver(int nstates, int ninputs, int nhorizon);
@@ -273,7 +275,12 @@ int ndlqr_CopySolution(NdLqrSolver* solver, double* soln);
  * hipGraph, which halves the latency of a single small solve; only t_total_ms / solve_time_ms are
  * filled then. */
 int ndlqr_SetDeviceProfiling(NdLqrSolver* solver, int on);
-/* additive: copy the device factorisation into solver->fact->data (reference layout). */
+/* additive: NDLQR_FLAG_* bits ndlqr_Solve runs with (default 0 = fast mode, solution only; the same
+ * launch sequence ndlqr_SolveBatch times). NDLQR_FLAG_STRICT_FP reproduces the reference's default
+ * build bit for bit, NDLQR_FLAG_KEEP_FACT materialises the factor array during every solve. */
+int ndlqr_SetDeviceFlags(NdLqrSolver* solver, unsigned flags);
+/* additive: copy the device factorisation into solver->fact->data (reference layout). Without
+ * NDLQR_FLAG_KEEP_FACT on the solve the (still resident) problem is factored once more for it. */
 int ndlqr_SyncFactorsToHost(NdLqrSolver* solver);
 
 /* ------------------------------------------------------------------ nested_dissection.h:39-147 */
@@ -384,6 +391,9 @@ int ndlqr_BatchNumVars(const NdLqrBatchSolver* bs);
 int ndlqr_BatchSize(const NdLqrBatchSolver* bs);
 int ndlqr_CopyBatchSolution(NdLqrBatchSolver* bs, int p, double* soln);    /* nvars doubles */
 int ndlqr_CopyBatchSolutions(NdLqrBatchSolver* bs, double* soln);          /* batch*nvars */
+/* the same [batch][nvars] array written to DEVICE memory by a kernel on the solver's stream
+ * (asynchronous; e.g. the send buffer of an all_gather of the shards' solutions) */
+int ndlqr_CopyBatchSolutionsDevice(NdLqrBatchSolver* bs, double* dsoln);
 int ndlqr_CopyBatchFactors(NdLqrBatchSolver* bs, int p, double* fact);     /* reference layout */
 int ndlqr_BatchCholeskyFailures(NdLqrBatchSolver* bs);
 /* KKT residual ||K z - b||_2 and ||b||_2 of every problem's resident solution against its raw

@@ -49,7 +49,9 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* ctx, int p0, int count, const double* A
                             const double* QR, const double* rhs);
 /* The same packing done ON the device from flat arrays that already live in HBM (reference
  * layout: A [batch][N][n*n] and B [batch][N][n*m] column-major, Q,q,d [batch][N][n], R,r [batch][N][m],
- * x0 [batch][n]); asynchronous on the context's stream. */
+ * x0 [batch][n]); asynchronous on the context's stream. The caller orders the pack kernel behind
+ * whatever produced the inputs: synchronise the producer stream first, or make it the context's
+ * stream with ndlqr_hip_set_stream. Invalidates a cached factorisation / cached records. */
 int ndlqr_hip_pack_flat_device(NdlqrHipCtx* ctx, const double* A, const double* B, const double* Q,
                                const double* R, const double* q, const double* r, const double* d,
                                const double* x0);
@@ -73,6 +75,10 @@ double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
 int ndlqr_hip_download_solutions(NdlqrHipCtx* ctx, int p0, int count, double* soln);
 int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* ctx, int p, double* z_full); /* N*(2n+m) */
 int ndlqr_hip_download_factors(NdlqrHipCtx* ctx, int p, double* fact); /* needs NDLQR_FLAG_KEEP_FACT */
+int ndlqr_hip_factors_valid(const NdlqrHipCtx* ctx); /* 1: the device holds the factor array of the last solve */
+/* Solutions of the whole batch packed as [batch][nvars] into DEVICE memory `dst` (e.g. the send
+ * buffer of an RCCL all_gather of the shards' solutions), by a kernel on the context's stream. */
+int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* ctx, double* dst);
 /* Residual of the resident solution against the raw problem, per problem, computed on the device:
  * res[b] = ||K z - b||_2, bnorm[b] = ||b||_2 (bnorm may be NULL); the rows are those of the
  * reference's KKT system (src/solver.c:122-194). batch doubles each. */
@@ -84,6 +90,9 @@ int ndlqr_hip_set_fuse_level(NdlqrHipCtx* ctx, int J);
  * (0..3; 0 = separate leaf / separator / Schur kernels). Results do not depend on it. */
 int ndlqr_hip_set_bottom_levels(NdlqrHipCtx* ctx, int JB);
 int ndlqr_hip_cholesky_failures(NdlqrHipCtx* ctx);
+/* Name of the launch sequence the last solve used (for reports): "reduced", "reduced-tree",
+ * "knot-lean", "knot-strict", "knot-keep", "generic-lean", "generic-strict", "generic-keep". */
+const char* ndlqr_hip_schedule(const NdlqrHipCtx* ctx);
 
 /* Per-kernel profile (NDLQR_FLAG_PROFILE): HIP-event durations accumulated since the last
  * reset, one slot per kernel kind. Returns number of slots / fills name, total ms, launches. */

@@ -102,7 +102,8 @@ class NdLqrSolver(C.Structure):
                 ("fact", C.POINTER(NdData)), ("soln", C.POINTER(NdData)),
                 ("cholfacts", C.POINTER(NdLqrCholeskyFactors)), ("solve_time_ms", C.c_double),
                 ("linalg_time_ms", C.c_double), ("profile", NdLqrProfile),
-                ("num_threads", C.c_int), ("device_ctx", C.c_void_p)]
+                ("num_threads", C.c_int), ("device_ctx", C.c_void_p),
+                ("device_flags", C.c_uint), ("device_profiling_off", C.c_int)]
 
 
 _LIB = None
@@ -192,6 +193,7 @@ def lib():
     proto("ndlqr_CopySolution", ci, sp, dp)
     proto("ndlqr_SyncFactorsToHost", ci, sp)
     proto("ndlqr_SetDeviceProfiling", ci, sp, ci)
+    proto("ndlqr_SetDeviceFlags", ci, sp, C.c_uint)
     # stage functions
     proto("ndlqr_SolveLeaf", ci, sp, ci)
     proto("ndlqr_SolveLeaves", ci, sp)
@@ -224,6 +226,7 @@ def lib():
     proto("ndlqr_BatchSize", ci, vp)
     proto("ndlqr_CopyBatchSolution", ci, vp, ci, dp)
     proto("ndlqr_CopyBatchSolutions", ci, vp, dp)
+    proto("ndlqr_CopyBatchSolutionsDevice", ci, vp, vp)
     proto("ndlqr_CopyBatchFactors", ci, vp, ci, dp)
     proto("ndlqr_BatchCholeskyFailures", ci, vp)
     proto("ndlqr_BatchKktResiduals", ci, vp, dp, dp)
@@ -236,6 +239,10 @@ def lib():
     proto("ndlqr_hip_profile_get", ci, vp, ci, C.c_char_p, ci, dp, C.POINTER(ci))
     proto("ndlqr_hip_profile_reset", ci, vp)
     proto("ndlqr_hip_device_pointers", ci, vp, C.POINTER(vp))
+    proto("ndlqr_hip_upload_inputs", ci, vp, ci, ci, dp, dp, dp)
+    proto("ndlqr_hip_factors_valid", ci, vp)
+    proto("ndlqr_hip_schedule", C.c_char_p, vp)
+    proto("ndlqr_hip_pack_solutions_device", ci, vp, vp)
     proto("ndlqr_hip_set_fuse_level", ci, vp, ci)
     proto("ndlqr_hip_set_bottom_levels", ci, vp, ci)
     proto("ndlqr_hip_gemm", ci, ci, ci, ci, ci, ci, cd, dp, ci, dp, ci, cd, dp, ci)
@@ -372,6 +379,18 @@ class BatchSolver:
             raise RuntimeError("ndlqr_CopyBatchSolutions failed: %d" % got)
         return out
 
+    def solutions_to_device(self, device_ptr):
+        """[batch][nvars] packed solutions into device memory (asynchronous on the solver's stream)."""
+        got = self.L.ndlqr_CopyBatchSolutionsDevice(self.h, C.c_void_p(int(device_ptr)))
+        if got != self.nvars:
+            raise RuntimeError("ndlqr_CopyBatchSolutionsDevice failed: %d" % got)
+
+    def upload_packed(self, AB, QR, rhs):
+        """Raw H2D of inputs already in the device layout of include/ndlqr_hip.h (whole batch)."""
+        err = self.L.ndlqr_hip_upload_inputs(self.ctx, 0, self.batch, _ptr(AB), _ptr(QR), _ptr(rhs))
+        if err:
+            raise RuntimeError("ndlqr_hip_upload_inputs failed: %d" % err)
+
     def factors(self, p):
         K = int(np.log2(self.N))
         out = np.zeros(self.N * K * (2 * self.n + self.m) * self.n)
@@ -392,6 +411,10 @@ class BatchSolver:
             self.L.ndlqr_hip_profile_get(self.ctx, slot, name, 64, C.byref(ms), C.byref(cnt))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    def schedule(self):
+        """Name of the launch sequence the last solve used."""
+        return self.L.ndlqr_hip_schedule(self.ctx).decode()
 
     def profile_reset(self):
         self.L.ndlqr_hip_profile_reset(self.ctx)

@@ -274,6 +274,11 @@ int ndlqr_CopyBatchSolutions(NdLqrBatchSolver* bs, double* soln) {
   int err = ndlqr_hip_download_solutions(bs->ctx, 0, bs->batch, soln);
   return err ? err : bs->nvars;
 }
+int ndlqr_CopyBatchSolutionsDevice(NdLqrBatchSolver* bs, double* dsoln) {
+  if (!bs || !dsoln) return NDLQR_ERR_INVALID;
+  int err = ndlqr_hip_pack_solutions_device(bs->ctx, dsoln);
+  return err ? err : bs->nvars;
+}
 int ndlqr_CopyBatchFactors(NdLqrBatchSolver* bs, int p, double* fact) {
   if (!bs || !fact || p < 0 || p >= bs->batch) return NDLQR_ERR_INVALID;
   return ndlqr_hip_download_factors(bs->ctx, p, fact);

@@ -14,8 +14,11 @@
 
 #include "kernels_common.hpp"
 
-// records the message for ndlqr_hip_last_error(), prints it, returns NDLQR_ERR_NO_DEVICE
+// records the message for ndlqr_hip_last_error(), prints it, returns NDLQR_ERR_NO_DEVICE (or
+// NDLQR_ERR_INVALID for a rejected launch configuration / argument)
 int ndlqr_hip_fail(const char* what, hipError_t e);
+struct NdlqrHipCtx;
+int ndlqr_hip_ensure_F(NdlqrHipCtx* c);
 #define HIP_TRY(expr)                                                  \
   do {                                                                 \
     hipError_t e_ = (expr);                                            \
@@ -40,7 +43,7 @@ struct NdlqrHipCtx {
   double* AB;
   double* QR;
   double* rhs;
-  double* F;
+  double* F;    // complete factor array; allocated by the first solve whose schedule touches it (ndlqr_hip_ensure_F)
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   double* red;  // [batch][N/4][4 n^2 + 2 n] accumulators of the separator-only schedule (size-specialised shapes)
@@ -50,6 +53,9 @@ struct NdlqrHipCtx {
   bool mcore; // separator core with both substitutions on the matrix cores (factor_solve_mc); NDLQR_MCORE=0: factor_solve
   bool bottom_reduced; // levels 0 and 1 on the reduced system too (bottom_reduced); NDLQR_BOTTOM_REDUCED=0: bottom_small<REDUCED>
   int* info;
+  const char* schedule;  // name of the launch sequence the last solve used (ndlqr_hip_schedule)
+  int* h_fail;      // pinned host word: the batch-wide failure count, copied behind the last kernel of a solve
+  double* kkt_out;  // [2 batch] scratch of ndlqr_hip_kkt_residual (allocated on first use)
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
   bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)

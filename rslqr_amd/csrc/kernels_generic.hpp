@@ -567,6 +567,16 @@ static __global__ void pack_flat_generic(Dims d, const double* __restrict__ A, c
   }
 }
 
+// Solutions [batch][N][2n+m] (the unused trailing u_N slot included) -> [batch][nvars] packed, the
+// layout of ndlqr_CopyBatchSolutions, in device memory. grid (N, batch).
+static __global__ void pack_solutions_generic(Dims d, const double* __restrict__ z, double* __restrict__ dst) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  const size_t nvars = (size_t)d.rows * d.N - d.m;
+  const int len = k < d.N - 1 ? d.rows : d.rows - d.m;
+  for (int e = threadIdx.x; e < len; e += blockDim.x)
+    dst[(size_t)b * nvars + (size_t)k * d.rows + e] = z[((size_t)b * d.N + k) * d.rows + e];
+}
+
 // ------------------------------------------------------------------------------------- rhs-only sweep
 // Factor / solve split (the reference cannot separate them, docs/rslqr_usage.dox):
 // with the complete factor array kept on the device (NDLQR_FLAG_KEEP_FACT) a new right-hand side

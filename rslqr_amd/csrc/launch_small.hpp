@@ -27,31 +27,70 @@ static void launch_bottom(NdlqrHipCtx* c, bool lean) {
                      ((lean || (KEEP && !STRICT)) ? 1 : 0) | ((c->flags & NDLQR_FLAG_KEEP_RECORDS) ? 2 : 0));
 }
 
+// What launch_small is going to do for this context: decided once, before the launch sequence is
+// enqueued (and possibly captured), so that ndlqr_hip.hip can allocate what the schedule needs.
+struct SmallPlan {
+  int JB;        // tree levels fused with the leaf phase in the bottom kernel
+  bool lean;     // solution by back-substitution from the separator records (fast mode, no KEEP)
+  int store_l;   // keep the separator factors for a record-based re-solve (KEEP_RECORDS)
+  bool reduced;  // separator-only schedule (bottom_reduced_mc + reduced_level_mc)
+  bool tree;     // ... with the whole factorisation in one launch (small batches)
+  bool needs_F;  // the schedule reads or writes the factor array
+};
+
 template <int NX, int NU, bool STRICT, bool KEEP>
-static int launch_small(NdlqrHipCtx* c, int J) {
+static SmallPlan plan_small(const NdlqrHipCtx* c, int J) {
   const ndlqr::Dims& d = c->d;
-  using Sh = ndlqr::SchurShape<NX, NU>;
+  SmallPlan p;
   // leaf + levels 0..JB-1 fused on chip when the horizon is long enough, else the leaf kernel
   int JB = c->bottom_levels;
   if (JB > 3) JB = 3;
   while (JB > 0 && d.K <= JB) --JB;
   if (JB > J) JB = J;
+  p.JB = JB;
   // fast mode without KEEP: solution by back-substitution from the separator records (needs the
   // boundary-first schedule right after the bottom kernel, so that no level reads interior knots)
-  const bool lean = !STRICT && !KEEP && JB >= J && JB >= 1 && JB < d.K && c->upper_mode != 0 &&
-                    (d.K + 4) * NX <= 256 && !c->no_backsub;
-  const int store_l = (c->flags & NDLQR_FLAG_KEEP_RECORDS) ? 1 : 0;  // factors for a record-based re-solve
-  // the record-based re-solve needs every separator's record and factor: KEEP writes them all,
-  // KEEP_RECORDS adds the factors to the lean schedule
-  c->rec_complete = !STRICT && (KEEP || (lean && store_l));
+  p.lean = !STRICT && !KEEP && JB >= J && JB >= 1 && JB < d.K && c->upper_mode != 0 &&
+           (d.K + 4) * NX <= 256 && !c->no_backsub;
+  p.store_l = (c->flags & NDLQR_FLAG_KEEP_RECORDS) ? 1 : 0;  // factors for a record-based re-solve
+  p.reduced = false;
+  p.tree = false;
   // separator-only schedule of the upper levels (see reduced_level): the bottom kernel pushes
   // 12x12 blocks instead of handing knot rows over
   if constexpr (!STRICT && !KEEP && ndlqr::P1OnMatrixCores<NX, NU>::value) {
-    if (lean && c->reduced && JB == 2 && d.K > 2 && c->red) {
+    if (p.lean && c->reduced && JB == 2 && d.K > 2 && c->red) {
+      p.reduced = true;
       // tree schedule for small batches (at most half a resident round of bottom wavefronts): three
       // launches instead of K + 1; measured cross-over at batch x N / 4 ~ 4096 wavefronts
-      const bool tree = c->bottom_reduced && c->mcore && c->tree_cnt &&
-                        (c->tree == 1 || (c->tree < 0 && (size_t)d.batch * (d.N >> 2) <= 2048));
+      p.tree = c->bottom_reduced && c->mcore && c->tree_cnt &&
+               (c->tree == 1 || (c->tree < 0 && (size_t)d.batch * (d.N >> 2) <= 2048));
+    }
+  }
+  // the separator-only schedule touches F only to park the factors of KEEP_RECORDS
+  p.needs_F = !(p.reduced && !p.store_l);
+  return p;
+}
+
+template <int NX, int NU, bool STRICT, bool KEEP>
+static int launch_small(NdlqrHipCtx* c, int J) {
+  const ndlqr::Dims& d = c->d;
+  using Sh = ndlqr::SchurShape<NX, NU>;
+  const SmallPlan plan = plan_small<NX, NU, STRICT, KEEP>(c, J);
+  const int JB = plan.JB;
+  const bool lean = plan.lean;
+  const int store_l = plan.store_l;
+  // the record-based re-solve needs every separator's record and factor: KEEP writes them all,
+  // KEEP_RECORDS adds the factors to the lean schedule
+  c->rec_complete = !STRICT && (KEEP || (lean && store_l));
+  if constexpr (!STRICT && !KEEP && ndlqr::P1OnMatrixCores<NX, NU>::value) {
+    if (plan.reduced) {
+      const bool tree = plan.tree;
+      c->schedule = tree ? "reduced-tree" : "reduced";
+      if (tree) {
+        // arrival counters start from zero in every solve: a launch that did not run to completion
+        // (error mid-graph, aborted stream) cannot leave odd counters behind for the next one
+        HIP_TRY(hipMemsetAsync(c->tree_cnt, 0, sizeof(int) * (size_t)d.batch * (d.N >> 2), c->stream));
+      }
       if (c->bottom_reduced) {
         ScopedSlot t(c, SLOT_BOTTOM);
         if (tree)
@@ -83,6 +122,7 @@ static int launch_small(NdlqrHipCtx* c, int J) {
       return NDLQR_OK;
     }
   }
+  c->schedule = lean ? "knot-lean" : (STRICT ? "knot-strict" : "knot-keep");
   switch (JB) {
     case 3: launch_bottom<NX, NU, STRICT, KEEP, 3>(c, lean); break;
     case 2: launch_bottom<NX, NU, STRICT, KEEP, 2>(c, lean); break;

@@ -22,6 +22,9 @@ const char* ndlqr_hip_last_error(void) { return g_last_error.c_str(); }
 int ndlqr_hip_fail(const char* what, hipError_t e) {
   g_last_error = std::string(what) + ": " + hipGetErrorString(e);
   fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+  // a launch configuration / argument the device rejects is the caller's (or this library's) error,
+  // not a missing device
+  if (e == hipErrorInvalidConfiguration || e == hipErrorInvalidValue) return NDLQR_ERR_INVALID;
   return NDLQR_ERR_NO_DEVICE;
 }
 static int fail(const char* what, hipError_t e) { return ndlqr_hip_fail(what, e); }
@@ -47,6 +50,11 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
     g_last_error = "invalid dimensions";
     return nullptr;
   }
+  if (batch > 65535) {  // the batch index rides on gridDim.y
+    g_last_error = "batch > 65535 problems per solver: split the batch over several solvers";
+    fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+    return nullptr;
+  }
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -69,6 +77,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
+  c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false;
+  c->big_lds_kernel = nullptr;
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->reduced = getenv("NDLQR_REDUCED") ? atoi(getenv("NDLQR_REDUCED")) != 0 : true;
   c->mcore = getenv("NDLQR_MCORE") ? atoi(getenv("NDLQR_MCORE")) != 0 : true;
@@ -89,8 +99,10 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
             hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess &&
             hipMalloc(&c->AB, bytes_AB(d)) == hipSuccess && hipMalloc(&c->QR, bytes_QR(d)) == hipSuccess &&
             hipMalloc(&c->rhs, bytes_z(d)) == hipSuccess && hipMalloc(&c->z, bytes_z(d)) == hipSuccess &&
-            hipMalloc(&c->F, bytes_F(d)) == hipSuccess && hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
-            hipMalloc(&c->info, sizeof(int) * ((size_t)batch + 1)) == hipSuccess;
+            hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
+            hipMalloc(&c->info, sizeof(int) * ((size_t)batch + 1)) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  if (ok) *c->h_fail = 0;
   if (ok && nhorizon >= 8 && has_small_instance(nstates, ninputs)) {
     // slot = DL | DR | CA | CB | gL | gR, padded to whole 128-byte lines (RedSlot<NX>::SIZE)
     const size_t slot_doubles = (4 * (size_t)nstates * nstates + 2 * nstates + 15) / 16 * 16;
@@ -101,10 +113,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
          hipMemsetAsync(c->tree_cnt, 0, cnt_bytes, c->stream) == hipSuccess;
   }
   if (ok) {
-    // Structural zeros of F are never written by the kernels; zero once so that the factor
-    // download matches the reference's calloc'ed array (src/nddata.c:34).
-    ok = hipMemsetAsync(c->F, 0, bytes_F(d), c->stream) == hipSuccess &&
-         hipMemsetAsync(c->z, 0, bytes_z(d), c->stream) == hipSuccess &&
+    // (the factor array F is allocated by the first solve whose schedule touches it: ndlqr_hip_ensure_F)
+    ok = hipMemsetAsync(c->z, 0, bytes_z(d), c->stream) == hipSuccess &&
          hipMemsetAsync(c->info, 0, sizeof(int) * ((size_t)batch + 1), c->stream) == hipSuccess &&
          hipStreamSynchronize(c->stream) == hipSuccess;
   }
@@ -125,10 +135,34 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
+  (void)hipFree(c->kkt_out);
+  if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+// The complete factor array [batch][K][N][2n+m][n] (5.6 GB at (12,4,256) x 1024, 87 GB at
+// (64,16,512) x 256) exists only for the schedules that touch it: strict mode, KEEP_FACT, the
+// knot-based and runtime-sized paths, and the factors kept by KEEP_RECORDS. The default
+// separator-only fast path never allocates it. Must run outside stream capture (hipMalloc).
+int ndlqr_hip_ensure_F(NdlqrHipCtx* c) {
+  if (c->F) return NDLQR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipError_t e = hipMalloc(&c->F, bytes_F(c->d));
+  if (e != hipSuccess) {
+    c->F = nullptr;
+    g_last_error = "factor array does not fit on the device (" + std::to_string(bytes_F(c->d) >> 20) +
+                   " MiB): use the default fast mode without NDLQR_FLAG_KEEP_FACT, or a smaller batch";
+    fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+    (void)hipGetLastError();
+    return NDLQR_ERR_INVALID;
+  }
+  // Structural zeros of F are never written by the kernels; zero once so that the factor
+  // download matches the reference's calloc'ed array (src/nddata.c:34).
+  HIP_TRY(hipMemsetAsync(c->F, 0, bytes_F(c->d), c->stream));
+  return NDLQR_OK;
 }
 
 int ndlqr_hip_set_flags(NdlqrHipCtx* c, unsigned flags) {
@@ -177,12 +211,15 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->d, A, B, Q, R,
                      q, r, d, x0, c->AB, c->QR, c->rhs);
   HIP_TRY(hipGetLastError());
-  c->fact_valid = false;
+  c->fact_valid = false;  // new A, B, Q, R: neither a cached factor array nor cached records match
+  c->rec_complete = false;
   return NDLQR_OK;
 }
 
 int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
   if (!c || !out5) return NDLQR_ERR_INVALID;
+  const int ferr = ndlqr_hip_ensure_F(c);  // the caller asks for the factor array: it has to exist
+  if (ferr) return ferr;
   out5[0] = c->AB; out5[1] = c->QR; out5[2] = c->rhs; out5[3] = c->F; out5[4] = c->z;
   return NDLQR_OK;
 }
@@ -195,6 +232,7 @@ template <bool STRICT>
 static int launch_generic(NdlqrHipCtx* c, bool lean) {
   const ndlqr::Dims& d = c->d;
   double* rec = lean ? c->rec : nullptr;
+  c->schedule = lean ? "generic-lean" : (STRICT ? "generic-strict" : "generic-keep");
   {
     ScopedSlot t(c, SLOT_LEAF);
     hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
@@ -267,6 +305,7 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
 //      small_instances.def
 #define NDLQR_SMALL_INSTANCE(NX_, NU_)                                              \
   int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep, int J); \
+  int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep, int J); \
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c);                               \
   int ndlqr_small_kpb_##NX_##_##NU_(void);
 #include "small_instances.def"
@@ -275,6 +314,7 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
 struct SmallInstance {
   int nx, nu;
   int (*solve)(NdlqrHipCtx*, bool, bool, int);
+  int (*needs_F)(const NdlqrHipCtx*, bool, bool, int);
   void (*rhs)(NdlqrHipCtx*);
   int (*kpb)(void);
 };
@@ -284,6 +324,10 @@ struct SmallInstance {
     if (strict) return keep ? launch_small<NX_, NU_, true, true>(c, J) : launch_small<NX_, NU_, true, false>(c, J); \
     return keep ? launch_small<NX_, NU_, false, true>(c, J) : launch_small<NX_, NU_, false, false>(c, J);           \
   }                                                                                                 \
+  int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep, int J) {      \
+    if (strict) return keep ? plan_small<NX_, NU_, true, true>(c, J).needs_F : plan_small<NX_, NU_, true, false>(c, J).needs_F; \
+    return keep ? plan_small<NX_, NU_, false, true>(c, J).needs_F : plan_small<NX_, NU_, false, false>(c, J).needs_F;           \
+  }                                                                                                 \
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c) { launch_rhs_records<NX_, NU_>(c); }           \
   int ndlqr_small_kpb_##NX_##_##NU_(void) { return ndlqr::SchurShape<NX_, NU_>::KPB; }
 #include "small_instances.def"
@@ -292,7 +336,8 @@ struct SmallInstance {
 
 static const SmallInstance kSmallInstances[] = {
 #define NDLQR_SMALL_INSTANCE(NX_, NU_) \
-  {NX_, NU_, ndlqr_small_solve_##NX_##_##NU_, ndlqr_small_rhs_##NX_##_##NU_, ndlqr_small_kpb_##NX_##_##NU_},
+  {NX_, NU_, ndlqr_small_solve_##NX_##_##NU_, ndlqr_small_needs_F_##NX_##_##NU_, ndlqr_small_rhs_##NX_##_##NU_, \
+   ndlqr_small_kpb_##NX_##_##NU_},
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 };
@@ -309,22 +354,40 @@ static const SmallInstance* find_small(const ndlqr::Dims& d) {
   return nullptr;
 }
 
-// returns true when (n, m, N) has a size-specialised instance and it was launched
-static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
+// the size-specialised instance that serves this context (nullptr: runtime-sized kernels) and the
+// fuse level J it runs with
+static const SmallInstance* pick_small(const NdlqrHipCtx* c, int* J_out) {
   const ndlqr::Dims& d = c->d;
+  if (c->flags & NDLQR_FLAG_GENERIC) return nullptr;
   const SmallInstance* inst = find_small(d);
-  if (!inst) return false;
+  if (!inst) return nullptr;
   const int kpb = inst->kpb();
-  if (d.N < kpb) return false;
-  const bool keep = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0;
+  if (d.N < kpb) return nullptr;
   // apply_small needs all KPB knots of a workgroup inside one level-J subtree: 2^(J+1) >= KPB
   int Jmin = 0;
   while ((2 << Jmin) < kpb) ++Jmin;
   int J = c->fuse_level >= 0 ? c->fuse_level : 2;
   if (J < Jmin) J = Jmin;
   if (J > d.K) J = d.K;
-  *err = inst->solve(c, strict, keep, J);
+  *J_out = J;
+  return inst;
+}
+
+// returns true when (n, m, N) has a size-specialised instance and it was launched
+static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
+  int J = 0;
+  const SmallInstance* inst = pick_small(c, &J);
+  if (!inst) return false;
+  *err = inst->solve(c, strict, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0, J);
   return true;
+}
+
+// does the launch sequence enqueue_solve is about to issue touch the factor array?
+static bool solve_needs_F(const NdlqrHipCtx* c) {
+  int J = 0;
+  const SmallInstance* inst = pick_small(c, &J);
+  if (!inst) return true;  // the runtime-sized kernels work on F
+  return inst->needs_F(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0, J) != 0;
 }
 
 // Enqueue leaf/bottom + per-level + apply launches on the context's stream.
@@ -335,17 +398,24 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   int err = NDLQR_OK;
   bool done = false;
   c->rec_complete = false;
-  if (!(c->flags & NDLQR_FLAG_GENERIC)) done = try_launch_small(c, strict, &err);
+  done = try_launch_small(c, strict, &err);
   if (!done) {
     const bool lean = !strict && !(c->flags & NDLQR_FLAG_KEEP_FACT) && !c->no_backsub;
     err = strict ? launch_generic<true>(c, false) : launch_generic<false>(c, lean);
   }
+  // the batch-wide failure count travels to pinned host memory behind the last kernel: the host
+  // reads it after the stream synchronisation without another blocking copy
+  if (!err) HIP_TRY(hipMemcpyAsync(c->h_fail, c->info + d.batch, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   return err;
 }
 
 int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
+  if (solve_needs_F(c)) {  // before any capture starts: allocation is not a stream operation
+    const int ferr = ndlqr_hip_ensure_F(c);
+    if (ferr) return ferr;
+  }
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   int err = NDLQR_OK;
   if (c->flags & NDLQR_FLAG_PROFILE) {
@@ -459,9 +529,7 @@ int ndlqr_hip_synchronize(NdlqrHipCtx* c) {
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     c->last_ms = ms;
     c->timing_pending = false;
-    int total = 0;  // info[batch] = batch-wide count of non-positive pivots
-    HIP_TRY(hipMemcpy(&total, c->info + c->d.batch, sizeof(int), hipMemcpyDeviceToHost));
-    c->last_failures = total;
+    c->last_failures = *c->h_fail;  // info[batch] = batch-wide count of non-positive pivots of the last solve
   }
   for (auto& p : c->pending) {
     float ms = 0;
@@ -507,12 +575,25 @@ int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln
   return NDLQR_OK;
 }
 
+const char* ndlqr_hip_schedule(const NdlqrHipCtx* c) { return c ? c->schedule : "none"; }
+
+int ndlqr_hip_factors_valid(const NdlqrHipCtx* c) { return c && c->fact_valid ? 1 : 0; }
+
+int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* c, double* dst) {
+  if (!c || !dst) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, c->stream, d, c->z, dst);
+  HIP_TRY(hipGetLastError());
+  return NDLQR_OK;
+}
+
 int ndlqr_hip_kkt_residual(NdlqrHipCtx* c, double* res, double* bnorm) {
   if (!c || !res) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
-  double* out = nullptr;
-  HIP_TRY(hipMalloc(&out, sizeof(double) * 2 * (size_t)d.batch));
+  if (!c->kkt_out) HIP_TRY(hipMalloc(&c->kkt_out, sizeof(double) * 2 * (size_t)d.batch));
+  double* out = c->kkt_out;
   hipLaunchKernelGGL(ndlqr::kkt_residual_generic, dim3(d.batch), dim3(256), 0, c->stream, d, c->AB, c->QR, c->rhs,
                      c->z, out);
   hipError_t e = hipGetLastError();
@@ -520,7 +601,6 @@ int ndlqr_hip_kkt_residual(NdlqrHipCtx* c, double* res, double* bnorm) {
   if (e == hipSuccess && bnorm)
     e = hipMemcpyAsync(bnorm, out + d.batch, sizeof(double) * d.batch, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(out);
   if (e != hipSuccess) return fail("ndlqr_hip_kkt_residual", e);
   return NDLQR_OK;
 }
@@ -616,18 +696,17 @@ int ndlqr_hip_gemm(int tA, int tB, int m, int n, int k, double alpha, const doub
 
 int ndlqr_hip_potrf_lower(int n, double* A, int lda) {
   if (dense_ready()) return NDLQR_ERR_NO_DEVICE;
-  DevBuf dA;
-  int* dinfo = nullptr;
+  DevBuf dA, dI;  // dI: one int, held as a double-sized buffer
   const size_t bA = sizeof(double) * (size_t)lda * n;
   HIP_TRY(hipMalloc(&dA.p, bA));
-  HIP_TRY(hipMalloc(&dinfo, sizeof(int)));
+  HIP_TRY(hipMalloc(&dI.p, sizeof(double)));
+  int* dinfo = reinterpret_cast<int*>(dI.p);
   HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
   HIP_TRY(hipMemcpy(dA.p, A, bA, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(ndlqr::dense_potrf, dim3(1), dim3(256), 0, 0, n, dA.p, lda, dinfo);
+  HIP_TRY(hipGetLastError());
   int info = 0;
-  hipError_t e = hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
-  (void)hipFree(dinfo);
-  if (e != hipSuccess) return fail("potrf", e);
+  HIP_TRY(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(A, dA.p, bA, hipMemcpyDeviceToHost));
   return info ? -1 : 0;
 }

@@ -101,6 +101,8 @@ NdLqrSolver* ndlqr_NewNdLqrSolver(int nstates, int ninputs, int nhorizon) {
   s->profile = ndlqr_NewNdLqrProfile();
   s->num_threads = 1;
   s->device_ctx = NULL;
+  s->device_flags = 0u;
+  s->device_profiling_off = 0;
   if (!slab || !s->diagonals || !s->data || !s->fact || !s->soln || !s->cholfacts ||
       !s->tree.node_list) {
     free(slab);
@@ -239,11 +241,11 @@ int ndlqr_Solve(NdLqrSolver* solver) {
     return NDLQR_ERR_NO_DEVICE;
   }
   NdlqrHipCtx* ctx = (NdlqrHipCtx*)ndlqr_BatchDeviceContext(bs);
-  /* a single solver keeps the whole factorisation on the device, like the reference keeps it in
-   * solver->fact (ndlqr_SyncFactorsToHost copies it out on demand) */
-  unsigned want = ndlqr_hip_get_flags(ctx) | NDLQR_FLAG_KEEP_FACT;
-  if (solver->linalg_time_ms < 0.0) want &= ~NDLQR_FLAG_PROFILE; else want |= NDLQR_FLAG_PROFILE;
-  const int profiling_off = solver->linalg_time_ms < 0.0;
+  /* The same launch sequence as the batch API (default: fast mode, solution only). The
+   * factorisation the reference leaves in solver->fact is produced on demand by
+   * ndlqr_SyncFactorsToHost; ndlqr_SetDeviceFlags selects strict mode / KEEP_FACT up front. */
+  unsigned want = solver->device_flags & ~NDLQR_FLAG_PROFILE;
+  if (!solver->device_profiling_off) want |= NDLQR_FLAG_PROFILE;
   ndlqr_hip_set_flags(ctx, want);
   ndlqr_hip_profile_reset(ctx);
   int err = ndlqr_batch_upload_from_mirrors(bs, solver->data, solver->diagonals, solver->soln->data);
@@ -255,18 +257,22 @@ int ndlqr_Solve(NdLqrSolver* solver) {
   if (derr) return derr;
 
   solver->solve_time_ms = ndlqr_BatchSolveTimeMs(bs);
-  solver->linalg_time_ms = profiling_off ? -1.0 : 0.0;  /* < 0 marks "device profiling off" */
+  solver->linalg_time_ms = 0.0; /* the reference's global LA timer is compiled out by default too */
   ndlqr_ResetProfile(&solver->profile);
-  /* Device kernels fuse the reference's phases differently: the leaf kernel maps to
-   * t_leaves_ms; the per-level kernel (products + Cholesky + solves + Schur + rhs sweep)
-   * is reported under t_shur_ms, its dominant component. */
+  /* The device kernels fuse the reference's phases (src/solve.c:15-25,76-116) differently; the
+   * buckets are filled per kernel kind (see NdLqrProfile in ndlqr.h):
+   *   t_leaves_ms    leaf kernel / bottom kernel (leaf phase fused with tree levels 0-1)
+   *   t_products_ms  separator kernels (inner products + Cholesky + triangular solves in one kernel)
+   *   t_shur_ms      Schur-update kernels and the solution sweep (apply / back-substitution)
+   *   t_cholesky_ms, t_cholsolve_ms   always 0: never separate kernels on the device */
   const int slots = ndlqr_hip_profile_slots(ctx);
   for (int sl = 0; sl < slots; ++sl) {
     char name[64];
     double ms = 0;
     int launches = 0;
     if (ndlqr_hip_profile_get(ctx, sl, name, (int)sizeof(name), &ms, &launches) != 0) continue;
-    if (strncmp(name, "leaf", 4) == 0) solver->profile.t_leaves_ms += ms;
+    if (strncmp(name, "leaf", 4) == 0 || strncmp(name, "bottom", 6) == 0) solver->profile.t_leaves_ms += ms;
+    else if (strncmp(name, "separator", 9) == 0 || strncmp(name, "upper", 5) == 0) solver->profile.t_products_ms += ms;
     else solver->profile.t_shur_ms += ms;
   }
   solver->profile.t_total_ms = wall_ms() - t0;
@@ -287,16 +293,30 @@ int ndlqr_CopySolution(NdLqrSolver* solver, double* soln) {
 
 int ndlqr_SetDeviceProfiling(NdLqrSolver* solver, int on) {
   if (!solver) return -1;
-  /* linalg_time_ms is unused on the device path (the reference's global LA timer is compiled out
-   * by default, src/linalg_utils.h:4-12); its sign carries the switch so that the caller-visible
-   * struct layout stays the reference's. */
-  solver->linalg_time_ms = on ? 0.0 : -1.0;
+  solver->device_profiling_off = on ? 0 : 1;
+  return 0;
+}
+
+int ndlqr_SetDeviceFlags(NdLqrSolver* solver, unsigned flags) {
+  if (!solver) return -1;
+  solver->device_flags = flags;
   return 0;
 }
 
 int ndlqr_SyncFactorsToHost(NdLqrSolver* solver) {
   if (!solver || !solver->device_ctx) return NDLQR_ERR_INVALID;
-  return ndlqr_CopyBatchFactors((NdLqrBatchSolver*)solver->device_ctx, 0, solver->fact->data);
+  NdLqrBatchSolver* bs = (NdLqrBatchSolver*)solver->device_ctx;
+  NdlqrHipCtx* ctx = (NdlqrHipCtx*)ndlqr_BatchDeviceContext(bs);
+  if (!ndlqr_hip_factors_valid(ctx)) {
+    /* the last ndlqr_Solve ran without NDLQR_FLAG_KEEP_FACT: its inputs are still resident on the
+     * device, so factor once more with the factor array materialised */
+    const unsigned flags = ndlqr_hip_get_flags(ctx);
+    ndlqr_hip_set_flags(ctx, (flags | NDLQR_FLAG_KEEP_FACT) & ~NDLQR_FLAG_PROFILE);
+    int err = ndlqr_SolveBatch(bs);
+    ndlqr_hip_set_flags(ctx, flags);
+    if (err && err != NDLQR_ERR_NOT_SPD) return err;
+  }
+  return ndlqr_CopyBatchFactors(bs, 0, solver->fact->data);
 }
 
 const char* ndlqr_Version(void) { return "rslqr_amd 0.1 (gfx950)"; }

@@ -46,3 +46,35 @@ def gather_solutions(local, device=None):
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, t)
     return torch.cat(parts, dim=0).cpu().numpy()
+
+
+def timed_region(solver, steps, warmup, barrier):
+    """bench.py's timed region, shared with the CPU rehearsal (tests/test_sharding_gloo.py):
+    `warmup` untimed steps, then exactly `steps` steps bracketed by barrier() on both sides.
+    `solver` needs solve_async() and synchronize(). Returns the rank's elapsed seconds."""
+    import time
+    for _ in range(warmup):
+        solver.solve_async()
+    solver.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.solve_async()
+    solver.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def timed_region_with_gather(solver, steps, barrier, gather):
+    """The same steps, each followed by the collection of every shard's solutions (SURVEY.md 8(e):
+    throughput including the gather). gather() -> gathered array or None. Returns (seconds, last)."""
+    import time
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        solver.solve_async()
+        solver.synchronize()
+        last = gather()
+    barrier()
+    return time.perf_counter() - t0, last

@@ -306,6 +306,53 @@ def test_env_variants_fast_mode(ndlqr, oracle):
         assert err <= REL_TOL, (env, err)
 
 
+def test_tree_schedule_fills_the_chip(ndlqr, oracle):
+    """The one-launch tree schedule at a size where its bottom wavefronts (32 x 256 / 4 = 2048) spread
+    over all eight XCDs with several wavefronts per SIMD -- the regime its hand-off protocol
+    (write-through pushes, s_waitcnt vmcnt(0), relaxed agent-scope arrival counter, L1-bypassing slot
+    loads) has to be right in. Two solves per process (the second starts from the counters the first
+    left and reset), every member against the level-per-launch schedule, some against the oracle."""
+    n, m, N, batch, seed = 12, 4, 256, 32, 2100
+    tree = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "1"})
+    flat = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0"})
+    err = np.linalg.norm(tree - flat, axis=1) / np.linalg.norm(flat, axis=1)
+    assert err.max() <= REL_TOL, err.max()
+    for b in (0, 13, batch - 1):
+        prob = synth(ndlqr, n, m, N, seed + b)
+        ref = oracle.solve(prob, 8)[0][: prob.nvars]
+        assert np.linalg.norm(tree[b] - ref) / np.linalg.norm(ref) <= REL_TOL
+
+
+def test_dropin_solve_flags(ndlqr, oracle):
+    """ndlqr_Solve runs the batch API's default fast path; ndlqr_SetDeviceFlags selects strict mode
+    (bit-identical to the reference's default build) or KEEP_FACT up front; ndlqr_SyncFactorsToHost
+    works either way (it re-factors the resident problem when the factor array was not kept)."""
+    L = ndlqr.lib()
+    pyprob, soln = load_json_problem(os.path.join(GOLDEN, "lqr_prob_256.json"))
+    z, fact, _, _ = oracle.solve(pyprob, 1, want_fact=True)
+    nvars = soln.size
+    for flags in (0, ndlqr.FLAG_STRICT_FP, ndlqr.FLAG_KEEP_FACT, ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT):
+        prob = L.ndlqr_ReadLQRProblemJSONFile(os.path.join(GOLDEN, "lqr_prob_256.json").encode())
+        solver = L.ndlqr_NewNdLqrSolver(pyprob.n, pyprob.m, pyprob.N)
+        assert L.ndlqr_SetDeviceFlags(solver, flags) == 0
+        assert L.ndlqr_InitializeWithLQRProblem(prob, solver) == 0
+        assert L.ndlqr_Solve(solver) == 0
+        x = np.zeros(nvars)
+        L.ndlqr_CopySolution(solver, x.ctypes.data_as(C.POINTER(C.c_double)))
+        if flags & ndlqr.FLAG_STRICT_FP:
+            assert np.array_equal(x, z[:nvars])
+        else:
+            assert np.linalg.norm(x - z[:nvars]) / np.linalg.norm(z[:nvars]) <= REL_TOL
+        assert L.ndlqr_SyncFactorsToHost(solver) == 0
+        got = solver.contents.fact.contents.numpy()
+        if flags & ndlqr.FLAG_STRICT_FP:
+            assert np.array_equal(got, fact)
+        else:
+            assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
+        L.ndlqr_FreeLQRProblem(prob)
+        L.ndlqr_FreeNdLqrSolver(solver)
+
+
 @pytest.mark.parametrize("n,m,N,batch", [(6, 3, 64, 5), (13, 4, 32, 3), (9, 3, 8, 4), (8, 4, 256, 2), (10, 4, 16, 1)])
 def test_separator_only_schedules_other_shapes(ndlqr, oracle, n, m, N, batch):
     """The separator-only schedules on the other matrix-core instances (odd row lengths, k-steps
@@ -380,8 +427,8 @@ def test_factor_solve_split(ndlqr, oracle, n, m, N, strict):
 # size-independent properties -- the KKT residual of the raw problem (SURVEY.md 8c secondary
 # witness), linearity of the solution in the right-hand side, determinism -- plus a full oracle
 # comparison of a few sampled members.
-@pytest.mark.parametrize("n,m,N,batch,sample", [(12, 4, 256, 1024, 12), (12, 4, 1024, 96, 4), (6, 3, 256, 1, 1),
-                                                (64, 16, 512, 4, 1)])
+@pytest.mark.parametrize("n,m,N,batch,sample", [(12, 4, 256, 1024, 12), (12, 4, 1024, 512, 4), (6, 3, 256, 1, 1),
+                                                (64, 16, 512, 4, 1), (64, 16, 512, 256, 1)])
 def test_full_size_properties(ndlqr, oracle, n, m, N, batch, sample):
     bs = ndlqr.BatchSolver(n, m, N, batch)
     bs.initialize_synthetic(1)
@@ -396,8 +443,9 @@ def test_full_size_properties(ndlqr, oracle, n, m, N, batch, sample):
         prob = synth(ndlqr, n, m, N, 1 + p)  # problem p of ndlqr_InitializeBatchSynthetic(seed0 = 1)
         ok, info = _kkt_ok(oracle, prob, sol[p])
         assert ok, (p, info)
-    # full oracle comparison on two members (threads only speed the oracle up)
-    for p in picks[:2]:
+    # full oracle comparison on two members (one at the (64,16,512) sizes: 340 MB of factor array
+    # per oracle solve); threads only speed the oracle up
+    for p in picks[:1 if n >= 64 else 2]:
         prob = synth(ndlqr, n, m, N, 1 + p)
         z, _, _, _ = oracle.solve(prob, 8)
         ref = z[: prob.nvars]
@@ -505,6 +553,26 @@ assert dev.solve() == 0
 assert np.array_equal(dev.solutions(), host.solutions())
 res, bn = dev.kkt_residuals()
 assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+# new matrices packed ON the device invalidate cached records / factors, like the host upload does
+# (mirror of test_factor_solve_split's host-side check): the rhs-only re-solve must be refused
+for fl in (R.FLAG_KEEP_RECORDS, R.FLAG_KEEP_FACT):
+    keep = R.BatchSolver(n, m, N, batch, device=0, flags=fl)
+    keep.initialize_flat_device(*[t.data_ptr() for t in tens])
+    assert keep.solve() == 0
+    assert keep.solve_rhs_only() == 0
+    gen2 = [R.generate_synthetic(n, m, N, 160 + p) for p in range(batch)]
+    tens2 = [torch.from_numpy(np.ascontiguousarray(np.stack([g[k] for g in gen2]))).to("cuda:0")
+             for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
+    torch.cuda.synchronize()
+    keep.initialize_flat_device(*[t.data_ptr() for t in tens2])
+    assert keep.solve_rhs_only() == -1, "stale records accepted after a device-side re-pack"
+    assert keep.solve() == 0 and keep.solve_rhs_only() == 0
+    keep.close()
+# packed solutions written to device memory (the send buffer of the multi-GPU gather)
+out = torch.empty((batch, dev.nvars), dtype=torch.float64, device="cuda:0")
+dev.solutions_to_device(out.data_ptr())
+dev.synchronize()
+assert np.array_equal(out.cpu().numpy(), dev.solutions())
 print("DEVICE_PACKING_OK")
 """ % root
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)

@@ -1,7 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo. The batch is sharded by rank with global seeds, each rank
-solves its shard (with the CPU oracle here -- no GPU in this container; on a GPU box the same
-sharding feeds BatchSolver), results are gathered and must equal the single-process answer in
-global problem order; max_over_ranks reduces timings like bench.py does."""
+"""N>1 path on CPU: world_size-2 gloo. The batch is sharded by rank with global seeds and driven
+through the SAME control flow bench.py runs on the GPUs (rslqr_amd.sharding.timed_region,
+timed_region_with_gather, gather_solutions, max_over_ranks); only the solver object differs: the CPU
+oracle stands in for BatchSolver here -- no GPU in this container. The gathered result must equal the
+single-process answer in global problem order."""
 import os
 import socket
 import sys
@@ -48,9 +49,28 @@ def _worker(rank, world, port, per_rank, n, m, N, outdir):
     assert sharding.env_rank() == (rank, rank, world)
     lo, hi = sharding.shard_range(rank, world, per_rank)
     assert (lo, hi) == (rank * per_rank, (rank + 1) * per_rank)
-    local = _solve_shard(rank, world, per_rank, n, m, N)
-    dist.barrier()
-    allsol = sharding.gather_solutions(local)
+
+    class OracleShard:  # the surface of rslqr_amd.BatchSolver that the timed regions use
+        calls = 0
+        sol = None
+
+        def solve_async(self):
+            self.calls += 1
+            self.sol = _solve_shard(rank, world, per_rank, n, m, N)
+
+        def synchronize(self):
+            return 0
+
+        def solutions(self):
+            return self.sol
+
+    shard = OracleShard()
+    elapsed = sharding.timed_region(shard, 2, 1, dist.barrier)
+    assert shard.calls == 3 and elapsed > 0.0
+    g_elapsed, allsol = sharding.timed_region_with_gather(
+        shard, 1, dist.barrier, lambda: sharding.gather_solutions(shard.solutions()))
+    assert shard.calls == 4 and g_elapsed > 0.0
+    assert np.array_equal(allsol[rank * per_rank:(rank + 1) * per_rank], shard.solutions())
     mx = sharding.max_over_ranks([1.0 + rank, 5.0 - rank])
     if rank == 0:
         np.save(os.path.join(outdir, "all.npy"), allsol)
