@@ -1,23 +1,41 @@
 #!/bin/bash
-# Developer tool, run on the GPU box:  bash tools/profile_round.sh TAG
+# Developer tool, run on the GPU box:  bash tools/profile_round.sh TAG [bench.py workload args]
+#   e.g. bash tools/profile_round.sh r02c        (headline workload)
+#        bash tools/profile_round.sh r02_config5 --nx 64 --nu 16 --horizon 512 --batch 256
 # 1. bench.py (with the cpu_baseline leg)          -> gpurun_out/TAG_bench.json
 # 2. rocprofv3 --kernel-trace --stats of bench.py   -> gpurun_out/TAG_stats/
 # 3. rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, no trace domains)
 #                                                   -> gpurun_out/TAG_pmc_{fetch,write}/
-# Copy what should be judged into profiles/ afterwards (tools/pmc_summary.py for the PMC pair).
+# 4. summaries: gpurun_out/TAG_kernel_stats.csv, TAG_pmc.txt, TAG_traffic.json
+# Copy what should be judged into profiles/ afterwards.
 set -e
 tag=${1:-rXX}
+shift || true
 root=$(pwd)
 export TMPDIR=/tmp
-python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+python3 bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "[profile_round] bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o run -- python3 bench.py --no-cpu \
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o run -- python3 bench.py --no-cpu --no-modes "$@" \
     > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_stats.err
 echo "[profile_round] kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_fetch -o run -- python3 bench.py --no-cpu --steps 2 --warmup 1 \
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_fetch -o run -- python3 bench.py --no-cpu --no-modes --steps 2 --warmup 1 "$@" \
     > /dev/null 2> gpurun_out/${tag}_pmc_fetch.err
 echo "[profile_round] FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_write -o run -- python3 bench.py --no-cpu --steps 2 --warmup 1 \
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_write -o run -- python3 bench.py --no-cpu --no-modes --steps 2 --warmup 1 "$@" \
     > /dev/null 2> gpurun_out/${tag}_pmc_write.err
 echo "[profile_round] WRITE_SIZE pass done"
-find gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write -name "*.csv" | head -20
+cp $(find gpurun_out/${tag}_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
+f=$(find gpurun_out/${tag}_pmc_fetch -name "*counter_collection.csv" | head -1)
+w=$(find gpurun_out/${tag}_pmc_write -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_summary.py $f $w > gpurun_out/${tag}_pmc.txt
+# workload of the run, from the bench line itself
+read nx nu N batch flags < <(python3 - <<PY
+import json, re
+d = json.load(open("gpurun_out/${tag}_bench.json"))
+m = re.search(r"nx=(\d+) nu=(\d+) N=(\d+) batch=(\d+)", d["config"]["workload"])
+print(*m.groups(), d["config"]["flags"])
+PY
+)
+python3 tools/make_traffic.py $tag $f $w $nx $nu $N $batch $flags > gpurun_out/${tag}_traffic.json
+cat gpurun_out/${tag}_pmc.txt
+head -8 gpurun_out/${tag}_kernel_stats.csv | cut -c1-200
