@@ -83,15 +83,10 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* ctx, double* dst);
  * res[b] = ||K z - b||_2, bnorm[b] = ||b||_2 (bnorm may be NULL); the rows are those of the
  * reference's KKT system (src/solver.c:122-194). batch doubles each. */
 int ndlqr_hip_kkt_residual(NdlqrHipCtx* ctx, double* res, double* bnorm);
-/* Tuning knob: tree level J from which the upper levels run boundary-first + one apply pass
- * (-1 = default, K = pure level-by-level streaming). Results do not depend on it. */
-int ndlqr_hip_set_fuse_level(NdlqrHipCtx* ctx, int J);
-/* Tuning knob: number of tree levels fused with the leaf phase in the on-chip bottom kernel
- * (0..3; 0 = separate leaf / separator / Schur kernels). Results do not depend on it. */
-int ndlqr_hip_set_bottom_levels(NdlqrHipCtx* ctx, int JB);
 int ndlqr_hip_cholesky_failures(NdlqrHipCtx* ctx);
 /* Name of the launch sequence the last solve used (for reports): "reduced", "reduced-tree",
- * "knot-lean", "knot-strict", "knot-keep", "generic-lean", "generic-strict", "generic-keep". */
+ * "reduced-records", "knot-lean", "knot-strict", "knot-keep", "generic-lean", "generic-strict",
+ * "generic-keep" (DESIGN.md section 2). */
 const char* ndlqr_hip_schedule(const NdlqrHipCtx* ctx);
 
 /* Per-kernel profile (NDLQR_FLAG_PROFILE): HIP-event durations accumulated since the last

@@ -243,8 +243,6 @@ def lib():
     proto("ndlqr_hip_factors_valid", ci, vp)
     proto("ndlqr_hip_schedule", C.c_char_p, vp)
     proto("ndlqr_hip_pack_solutions_device", ci, vp, vp)
-    proto("ndlqr_hip_set_fuse_level", ci, vp, ci)
-    proto("ndlqr_hip_set_bottom_levels", ci, vp, ci)
     proto("ndlqr_hip_gemm", ci, ci, ci, ci, ci, ci, cd, dp, ci, dp, ci, cd, dp, ci)
     proto("ndlqr_hip_potrf_lower", ci, ci, dp, ci)
     proto("ndlqr_hip_potrs_lower", ci, ci, ci, dp, ci, dp, ci)
@@ -299,14 +297,6 @@ class BatchSolver:
     @property
     def ctx(self):
         return self.L.ndlqr_BatchDeviceContext(self.h)
-
-    def set_fuse_level(self, J):
-        """Tree level from which the upper levels run boundary-first + one apply pass."""
-        self.L.ndlqr_hip_set_fuse_level(self.ctx, J)
-
-    def set_bottom_levels(self, JB):
-        """Tree levels fused with the leaf phase in the on-chip bottom kernel (0..3)."""
-        self.L.ndlqr_hip_set_bottom_levels(self.ctx, JB)
 
     def initialize_flat(self, A, B, Q, R, q, r, d, x0):
         n, m, N, bt = self.n, self.m, self.N, self.batch

@@ -46,12 +46,11 @@ struct NdlqrHipCtx {
   double* F;    // complete factor array; allocated by the first solve whose schedule touches it (ndlqr_hip_ensure_F)
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
+  double* ytop; // [batch][N/8][n] multipliers of the separators of level >= 3 (rb_backsub_top -> rb_backsub)
   double* red;  // [batch][N/4][4 n^2 + 2 n] accumulators of the separator-only schedule (size-specialised shapes)
-  bool reduced; // upper levels on the reduced system (reduced_level); NDLQR_REDUCED=0 switches back to level_small
+  bool rowbcast; // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom); NDLQR_ROWBCAST=0: bottom_reduced_mc
   int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
   int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; advance by two per solve
-  bool mcore; // separator core with both substitutions on the matrix cores (factor_solve_mc); NDLQR_MCORE=0: factor_solve
-  bool bottom_reduced; // levels 0 and 1 on the reduced system too (bottom_reduced); NDLQR_BOTTOM_REDUCED=0: bottom_small<REDUCED>
   int* info;
   const char* schedule;  // name of the launch sequence the last solve used (ndlqr_hip_schedule)
   int* h_fail;      // pinned host word: the batch-wide failure count, copied behind the last kernel of a solve
@@ -59,15 +58,7 @@ struct NdlqrHipCtx {
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
   bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)
-  const void* big_lds_kernel;  // last kernel whose dynamic-LDS limit was raised on this device
-  int upper_mode;     // NDLQR_UPPER=0: separator_one + schur_small<BOUNDARY> per level; 1 (default): one
-                      // launch per level (level_small); 2: all upper levels in one launch (upper_small)
-  bool no_backsub;    // NDLQR_NO_BACKSUB=1: fast mode keeps hand-off + finish_small (A/B timing)
-  bool no_finish;     // NDLQR_NO_FINISH=1: fast mode keeps apply_small instead of finish_small (A/B timing)
   int sep_threads;    // NDLQR_SEP_THREADS: workgroup size of the matrix-core separator (0 = by block size)
-  int bottom_lds_pad; // NDLQR_BOTTOM_LDS_PAD: extra dynamic LDS bytes for bottom_small (lowers its occupancy; A/B timing)
-  int bottom_levels;  // JB: leaf + levels 0..JB-1 fused in bottom_small (0 = separate kernels)
-  int fuse_level;  // J: levels >= J run boundary-first + apply (0 = level by level)
   hipEvent_t ev_start, ev_stop;
   bool timing_pending;
   double last_ms;
@@ -75,7 +66,6 @@ struct NdlqrHipCtx {
   // the launch sequence captured as a hipGraph (replayed when nothing that shapes it changed)
   hipGraphExec_t graph_exec;
   unsigned graph_flags;
-  int graph_J, graph_JB;
   hipStream_t graph_stream;
   bool fact_valid;   // the device holds a complete factorisation (last solve ran with KEEP_FACT)
   // profile

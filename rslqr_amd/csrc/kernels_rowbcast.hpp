@@ -1,0 +1,723 @@
+// kernels_rowbcast.hpp -- fast mode without KEEP, separator-only (block cyclic reduction) schedule,
+// third form of the separator core: ONE SEPARATOR PER 16-LANE DPP ROW, four per wavefront.
+//
+// Same mathematics as kernels_bottom_reduced.hpp (see its header and DESIGN.md section 2; reference:
+// ndlqr_SolveLeaf src/nested_dissection.c:10-105, ndlqr_FactorInnerProduct :114-134, the separator
+// Cholesky of src/solve.c:87-98, ndlqr_SolveCholeskyFactor :136-152, ndlqr_UpdateShurFactor :154-171).
+// What changes is where the numbers live. Lane i of a row holds ROW i of every matrix of "its"
+// separator (a matrix with C columns = C registers), and every product is of the form
+//     out(i, c) += A(i, k) * B(k, c)   =   v_fmac_f64_dpp out[c], B[c], A[k]  row_newbcast:k
+// -- the broadcast of row k of B from lane k is part of the FMA (DPP source modifier), so there is
+// no v_readlane, no LDS panel, no matrix-core tile padding and no idle replication: measured on
+// gfx950 (tools/ubench/issue_rates.hip, profiles/r02_issue_rates.txt) a v_fmac_f64_dpp costs exactly
+// one plain v_fma_f64 issue slot, a 2 x v_readlane + v_fma_f64 broadcast 3.3 slots, and the fp64
+// matrix cores have no rate advantage (16x16x4: 14.6 slots for 2048 flops; 4x4x4: 3.7 for 512) while
+// 12-wide blocks fill only 42-58 % of a 16x16 tile. Per separator the row form needs ~1 300
+// instructions for FOUR separators; the matrix-core form needed 1 715 vector + 66 x 14.6 matrix slots
+// for THREE.
+//
+//   rb_bottom       leaf phase + tree levels 0, 1: a wavefront owns 16 knots = four groups of four, one
+//                   group per DPP row; three passes (s0 = k0, s2 = k0 + 2, t = k0 + 1 of every group)
+//   rb_backsub_top  multipliers of the separators of level >= 3, one workgroup per problem
+//   rb_backsub      back-substitution of eight knots per workgroup; level-0 separators keep only
+//                   S-bar^-1 (packed lower triangle, n (n + 1) / 2 doubles instead of 2 n^2 + n): their
+//                   f_a, f_bb, z_sep follow from the problem data the kernel reads anyway
+// The upper levels stay on reduced_level_mc (kernels_bottom_reduced.hpp): a four-separators-per-
+// wavefront level kernel in this form was measured slower at every level (127 vs 108 us at level 2,
+// 13 vs 6.5 us at the root: 32 KB of staged slots per wavefront leave five wavefronts per CU).
+//
+// Transposed operands (r_a', r_bb') never need a transposition: at level 0 they are other views of
+// the staged [A | B] (r_bb(s)' = r_a(s + 1) by symmetry of the reduced system), at level 1 both
+// orientations of the coupling blocks are computed (G10 and G01 = G10'), above that the slot could be
+// read by rows or by columns.
+#pragma once
+#include <utility>
+
+#include "kernels_small.hpp"
+
+namespace ndlqr {
+
+// ------------------------------------------------------------------------------------- primitives
+// The DPP instructions read other lanes' registers, so every lane of the wavefront has to execute
+// them: they are `asm volatile`, which keeps the compiler from sinking them into the lane-predicated
+// regions that only store their results (a pure asm whose sole use sits under `if (i < NX)` would
+// otherwise be moved there and read inactive lanes).
+// acc += (x of lane J of this 16-lane row) * y
+template <int J>
+__device__ __forceinline__ void fmac_bc(double& acc, const double x, const double y) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+}
+// acc -= (x of lane J of this row) * y
+template <int J>
+__device__ __forceinline__ void fnmac_bc(double& acc, const double x, const double y) {
+  asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+}
+// x of lane J of this row
+template <int J>
+__device__ __forceinline__ double row_bc(const double x) {
+  double r;
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(J));
+  return r;
+}
+
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Hardware rule (gfx9 family, "VALU writes VGPR -> DPP reads that VGPR": 2 wait states, not
+// interlocked): a register that a DPP instruction is about to read from OTHER lanes must not have been
+// written by one of the two preceding instructions. The compiler inserts those wait states for its own
+// DPP instructions but cannot see into the asm statements here, and it is free to schedule the
+// v_mul that produces an operand right in front of the asm that broadcasts it -- which reads stale
+// lanes. dpp_fence(x): every element of x is produced before this point (empty asm statements that
+// "modify" them: no instruction, only an ordering edge), then two wait states, then the consumers
+// (volatile asm statements keep their order).
+__device__ __forceinline__ void dpp_fence(double& x) {
+  asm volatile("" : "+v"(x));
+  asm volatile("s_nop 1");
+}
+template <int N>
+__device__ __forceinline__ void dpp_fence(double (&x)[N]) {
+#pragma unroll
+  for (int c = 0; c < N; ++c) asm volatile("" : "+v"(x[c]));
+  asm volatile("s_nop 1");
+}
+
+// out[c] (+)= (-) sum_{k < KD} A[k] * B(k, c), c < NC: A = this lane's row of the left factor, B[c] = this
+// lane's row of the right factor (row k is taken from lane k). INIT: out starts from zero; NEG: the
+// product is subtracted. Four columns per asm statement: fewer statements for the compiler's hazard
+// recognizer to pad.
+template <int K, bool NEG>
+__device__ __forceinline__ void fmac_bc4(double& a0, double& a1, double& a2, double& a3, const double x0, const double x1,
+                                         const double x2, const double x3, const double y) {
+  if constexpr (NEG)
+    asm volatile("v_fmac_f64_dpp %0, -%4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, -%5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, -%6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, -%7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y), "n"(K));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y), "n"(K));
+}
+
+template <int KD, int NC, bool INIT, bool NEG = false, int NA, int NB>
+__device__ __forceinline__ void rb_mul(const double (&A)[NA], double (&B)[NB], double (&out)[NC]) {
+  static_assert(KD <= NA && NC <= NB && KD <= 16, "operand shapes");
+  if constexpr (INIT) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) out[c] = 0.0;
+  }
+  dpp_fence(B);
+  sfor<KD>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+#pragma unroll
+    for (int c = 0; c + 4 <= NC; c += 4) fmac_bc4<k, NEG>(out[c], out[c + 1], out[c + 2], out[c + 3], B[c], B[c + 1], B[c + 2], B[c + 3], A[k]);
+#pragma unroll
+    for (int c = NC / 4 * 4; c < NC; ++c) {
+      if constexpr (NEG) fnmac_bc<k>(out[c], B[c], A[k]); else fmac_bc<k>(out[c], B[c], A[k]);
+    }
+  });
+}
+// the same for one column
+template <int KD, int NA>
+__device__ __forceinline__ double rb_mulv(const double (&A)[NA], double b, double out = 0.0) {
+  dpp_fence(b);
+  sfor<KD>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    fmac_bc<k>(out, b, A[k]);
+  });
+  return out;
+}
+// out - sum_k A[k] * b(k)
+template <int KD, int NA>
+__device__ __forceinline__ double rb_mulv_sub(const double (&A)[NA], double b, double out) {
+  dpp_fence(b);
+  sfor<KD>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    fnmac_bc<k>(out, b, A[k]);
+  });
+  return out;
+}
+
+// ------------------------------------------------------------------------------------- separator core
+// Lane i: row i of S-bar in acc. On return acc = row i of the Cholesky factor L (entries above the
+// diagonal: leftovers), w = COLUMN i of W = L^-1 (w[k] = W(k, i), zero for k < i). Left-looking, fused
+// with the forward substitution of the unit vectors; step j takes row j of L from lane j inside the
+// FMAs. Returns true when a pivot was not positive (NaNs propagate to the last pivot).
+template <int NX>
+__device__ __forceinline__ bool rb_chol_inv(const int i, double (&acc)[NX], double (&w)[NX]) {
+  bool bad = false;
+  sfor<NX>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    double v = acc[j], sacc = (j == i) ? 1.0 : 0.0;
+    sfor<j>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      fnmac_bc<j>(v, acc[k], acc[k]);   // v    -= L(j, k) L(i, k)
+      fnmac_bc<j>(sacc, acc[k], w[k]);  // sacc -= L(j, k) W(k, i)
+    });
+    dpp_fence(v);  // v was written by the instruction before last
+    const double pivot = row_bc<j>(v);
+    // 1 / sqrt(pivot): hardware estimate + one Newton step (a few ulp; see factor_solve_mc)
+    const double y0 = __builtin_amdgcn_rsq(pivot);
+    const double e = fma(-pivot * y0, y0, 1.0);
+    const double rinv = fma(y0 * e, 0.5, y0);
+    if constexpr (j == NX - 1) bad = !((rinv > 0.0) & (rinv < 1.0e300));
+    acc[j] = v * rinv;
+    w[j] = sacc * rinv;
+    asm volatile("" : "+v"(w[j]));
+    dpp_fence(acc[j]);  // both are broadcast from this lane by the steps that follow
+  });
+  return bad;
+}
+
+// Row i of S-bar^-1 = W'W from the columns of W: Si(i, c) = sum_{k >= c} W(k, i) W(k, c)
+// (terms with k < i vanish by themselves: w[k] = 0 there).
+template <int NX>
+__device__ __forceinline__ void rb_sinv(const double (&w)[NX], double (&Si)[NX]) {
+  sfor<NX>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    double s = 0.0;
+    sfor<NX - c>([&](auto kc) {
+      constexpr int k = c + decltype(kc)::value;
+      fmac_bc<c>(s, w[k], w[k]);
+    });
+    Si[c] = s;
+  });
+}
+
+// [S-bar | b~] of a separator from the staged problem data (lane i: row i; see leaf_tile_mc):
+//   abrow  row i of [A_s | B_s]                 T[c] = [A_s | B_s](c, i) / [Q_s | R_s](i)  (lane i < W)
+//   tz     z-hat(i): rhs column operand         q1 = 1 / Q_{s+1}(i),  z1l, z1x: rhs(s+1).lambda / .x (i)
+template <int NX, int W>
+__device__ __forceinline__ void rb_leaf(const int i, const double (&abrow)[W], double (&T)[NX], const double tz,
+                                        const double q1, const double z1l, const double z1x, double (&S)[NX],
+                                        double& bz) {
+  rb_mul<W, NX, true>(abrow, T, S);
+  bz = rb_mulv<W>(abrow, tz) - fma(z1x, q1, z1l);
+#pragma unroll
+  for (int c = 0; c < NX; ++c) S[c] += (c == i) ? q1 : 0.0;
+}
+
+// LDS image of one staged knot: [A | B] with a row pitch that keeps 16-byte row reads of 12..16
+// consecutive rows on distinct banks, reciprocal weights, raw right-hand side.
+template <int NX, int NU>
+struct RbKnot {
+  static constexpr int W = NX + NU, ROWS = 2 * NX + NU, WP = (W % 2 == 0) ? W + 2 : W + 1;
+};
+
+// [A | B] of knots 4 g + 2 ph, 4 g + 2 ph + 1 (g = 0..3) of the wavefront's sixteen, coalesced 16-byte
+// loads -> LDS slots [2 g + j]; every load is issued before the first store.
+template <int NX, int NU>
+__device__ __forceinline__ void rb_stage_ab(const int lane, const int ph, const double* __restrict__ abm,
+                                            double (&ab)[8][NX * RbKnot<NX, NU>::WP]) {
+  constexpr int W = NX + NU, WP = RbKnot<NX, NU>::WP;
+  if constexpr (W % 2 == 0) {
+    constexpr int PK = NX * W / 2, NA = 8 * PK, IA = (NA + 63) / 64;  // double2 words per knot / in all
+    double2 t[IA];
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+      const int e = lane + 64 * it, ec = e < NA ? e : NA - 1;
+      const int slot = ec / PK, within = ec - slot * PK;
+      const int knot = 4 * (slot >> 1) + 2 * ph + (slot & 1);
+      t[it] = reinterpret_cast<const double2*>(abm)[knot * PK + within];
+    }
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {  // unconditional stores on the clamped index (see reduced_separator_mc)
+      const int e = lane + 64 * it, ec = e < NA ? e : NA - 1;
+      const int slot = ec / PK, within = ec - slot * PK, row = within / (W / 2), c2 = within - row * (W / 2);
+      reinterpret_cast<double2*>(&ab[slot][row * WP])[c2] = t[it];
+    }
+  } else {
+    constexpr int PK = NX * W, NA = 8 * PK, IA = (NA + 63) / 64;
+    double t[IA];
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+      const int e = lane + 64 * it, ec = e < NA ? e : NA - 1;
+      const int slot = ec / PK, within = ec - slot * PK;
+      const int knot = 4 * (slot >> 1) + 2 * ph + (slot & 1);
+      t[it] = abm[knot * PK + within];
+    }
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+      const int e = lane + 64 * it, ec = e < NA ? e : NA - 1;
+      const int slot = ec / PK, within = ec - slot * PK, row = within / W, c = within - row * W;
+      ab[slot][row * WP + c] = t[it];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- bottom levels
+//   grid (N / 16, batch), block 64; N >= 16; NX <= 16, NX + NU <= 16.
+// Row g of the wavefront owns knots k0 .. k0 + 3, k0 = 16 blockIdx.x + 4 g. Pass 1: s0 = k0 of every
+// group from knots k0, k0 + 1 (and the leaf tile of t = k0 + 1, whose [A | B] is staged then);
+// pass 2: s2 = k0 + 2 from knots k0 + 2, k0 + 3 (re-staged over the first two); pass 3: t. What the
+// level-0 separators contribute to t stays in registers; what the group contributes to the
+// separators k0 - 1 and k0 + 3 goes to their slots: the level-0 share as plain stores (which
+// initialise the accumulators of this solve), t's share as atomic adds behind them.
+template <int NX, int NU>
+struct alignas(16) RbBottomLds {
+  static constexpr int W = NX + NU, ROWS = 2 * NX + NU, WP = RbKnot<NX, NU>::WP;
+  double ab[8][NX * WP];   // two knots of each of the four groups: [2 g + j]
+  double rq[16][W];        // 1 / [Q | R] of all sixteen knots
+  double rh[16][ROWS];     // raw right-hand sides of all sixteen knots
+};
+
+template <int NX, int NU>
+__global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+                                                   const double* __restrict__ rhs, double* red,
+                                                   double* __restrict__ rec, int* __restrict__ info) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, WP = RbKnot<NX, NU>::WP;
+  static_assert(NX <= 16 && W <= 16, "one DPP row holds the rows of S-bar and of [A | B]'");
+  __shared__ RbBottomLds<NX, NU> lds;
+  const int lane = threadIdx.x, b = blockIdx.y, N = d.N;
+  const int g = lane >> 4, i = lane & 15;
+  const int ic = i < NX ? i : NX - 1;  // rows >= NX of a DPP row are padding: they repeat row NX - 1
+  const int kc = i < W ? i : W - 1;
+  const int kw = blockIdx.x * 16;      // first knot of the wavefront
+  const int k0 = kw + 4 * g;           // first knot of this row's group
+  const bool hasA = k0 > 0, hasB = k0 + 4 < N, first = k0 == 0;
+  const bool rowlane = i < NX;
+
+  // ---- staging: weights and right-hand sides of all 16 knots, [A | B] of knots k0 + 2 ph, k0 + 2 ph + 1
+  const double* const abm = AB + ((size_t)b * N + kw) * NX * W;
+  {
+    const double* q0 = QR + ((size_t)b * N + kw) * W;
+    const double* r0 = rhs + ((size_t)b * N + kw) * ROWS;
+    constexpr int NQ = 16 * W, IQ = (NQ + 63) / 64, NR = 16 * ROWS, IR = (NR + 63) / 64;
+    double qv[IQ], rv[IR];
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; qv[it] = q0[e < NQ ? e : NQ - 1]; }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; rv[it] = r0[e < NR ? e : NR - 1]; }
+    rb_stage_ab<NX, NU>(lane, 0, abm, lds.ab);
+#pragma unroll
+    for (int it = 0; it < IQ; ++it) {
+      const int e = lane + 64 * it, ec = e < NQ ? e : NQ - 1, kn = ec / W, c = ec - kn * W;
+      (&lds.rq[0][0])[ec] = 1.0 / qv[it];
+      if (e < NQ && !(qv[it] > 0.0) && !(kw + kn == N - 1 && c >= NX)) flag_failure(info, d, b);  // terminal R is unused
+    }
+#pragma unroll
+    for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; (&lds.rh[0][0])[e < NR ? e : NR - 1] = rv[it]; }
+  }
+  wave_lds_sync();
+
+  // operands of the separator between staged knots `sa` (knot index kn within the 16) and `sb`:
+  //   abrow, T, tz for the leaf tile; Ra / RaT rows of r_a, r_a'; Rb / RbT rows of r_bb, r_bb'
+  auto leaf_ops = [&](const int slot, const int kn, const bool fst, double (&abrow)[W], double (&T)[NX], double& tz) {
+    const double* am = lds.ab[slot];
+    if constexpr (WP % 2 == 0 && W % 2 == 0) {
+#pragma unroll
+      for (int k = 0; k < W; k += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(&am[ic * WP + k]);
+        abrow[k] = t.x; abrow[k + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) abrow[k] = am[ic * WP + k];
+    }
+    const bool fx = fst && kc < NX;  // knot 0: the state is fixed, its columns leave S-bar and carry x0 in the rhs
+    const double wk = fx ? 0.0 : lds.rq[kn][kc];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) T[c] = am[c * WP + kc] * wk;
+    tz = fx ? -lds.rh[kn][kc] : lds.rh[kn][NX + kc] * wk;
+  };
+
+  // Rows of the coupling blocks, re-read from the staged [A | B] right where they are needed (the live
+  // ranges decide whether the kernel fits two wavefronts per SIMD): knot s in slot `sl` (knot index kn
+  // of the sixteen), knot s + 1 in slot sl + 1.
+  //   r_a(i, c)  = -A_s(i, c) / Q_s(c)            r_a(c, i)  = -A_s(c, i) / Q_s(i)
+  //   r_bb(i, c) = -A_{s+1}(c, i) / Q_{s+1}(i)    r_bb(c, i) = -A_{s+1}(i, c) / Q_{s+1}(c)
+  auto load_Ra = [&](const int sl, const int kn, const bool has, double (&R)[NX]) {
+    const double* am = lds.ab[sl];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) R[c] = has ? -am[ic * WP + c] * lds.rq[kn][c] : 0.0;
+  };
+  auto load_RaT = [&](const int sl, const int kn, const bool has, double (&R)[NX]) {
+    const double* am = lds.ab[sl];
+    const double wi = lds.rq[kn][ic];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) R[c] = has ? -am[c * WP + ic] * wi : 0.0;
+  };
+  auto load_Rb = [&](const int sl, const int kn, const bool has, double (&R)[NX]) {
+    const double* a1 = lds.ab[sl + 1];
+    const double wi = lds.rq[kn + 1][ic];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) R[c] = has ? -a1[c * WP + ic] * wi : 0.0;
+  };
+  auto load_RbT = [&](const int sl, const int kn, const bool has, double (&R)[NX]) {
+    const double* a1 = lds.ab[sl + 1];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) R[c] = has ? -a1[ic * WP + c] * lds.rq[kn + 1][c] : 0.0;
+  };
+
+  double St[NX], bzt;                             // [S-bar | b~] of t, accumulated over passes 1 and 2
+  double Rat[NX], RaTt[NX], Rbt[NX], RbTt[NX];    // rows of r_a, r_a', r_bb, r_bb' of t
+  double* const myrec = rec + ((size_t)b * N + k0) * REC;
+  const RedSlot<NX> sA = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
+  const RedSlot<NX> sB = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
+
+  // Elimination of one level-0 separator (knot s in slot sl): S-bar^-1 goes to its record (row i, lower
+  // triangle packed: entry (i, c), c <= i, at i (i + 1) / 2 + c); returns X = S-bar^-1 [r_a | b~ | r_bb].
+  auto eliminate0 = [&](const int sl, const int kn, const bool fst, const bool ha, const bool hb, double* const r,
+                        double (&Xa)[NX], double& xz, double (&Xb)[NX]) {
+    double Si[NX], bz;
+    {
+      double S[NX], w[NX];
+      {
+        double abrow[W], T[NX], tz;
+        leaf_ops(sl, kn, fst, abrow, T, tz);
+        rb_leaf<NX, W>(i, abrow, T, tz, lds.rq[kn + 1][ic], lds.rh[kn + 1][ic], lds.rh[kn + 1][NX + ic], S, bz);
+      }
+      if (rb_chol_inv<NX>(i, S, w) && i == 0) flag_failure(info, d, b);
+      rb_sinv<NX>(w, Si);
+    }
+    if (rowlane) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c)
+        if (c <= i) r[i * (i + 1) / 2 + c] = Si[c];
+    }
+    double R[NX];
+    load_Ra(sl, kn, ha, R);
+    rb_mul<NX, NX, true>(Si, R, Xa);
+    xz = rb_mulv<NX>(Si, bz);
+    load_Rb(sl, kn, hb, R);
+    rb_mul<NX, NX, true>(Si, R, Xb);
+  };
+
+  // ================================================================ pass 1: s0 = k0 (knots k0, k0 + 1)
+  {
+    // leaf tile of t first, while its [A | B] (knot k0 + 1) is staged
+    double abrow[W], T[NX], tz;
+    leaf_ops(2 * g + 1, 4 * g + 1, false, abrow, T, tz);
+    rb_leaf<NX, W>(i, abrow, T, tz, lds.rq[4 * g + 2][ic], lds.rh[4 * g + 2][ic], lds.rh[4 * g + 2][NX + ic], St, bzt);
+  }
+  {
+    double Xa[NX], Xb[NX], xz;
+    eliminate0(2 * g, 4 * g, first, hasA, true, myrec, Xa, xz, Xb);
+    double Rt[NX], G[NX];
+    load_RaT(2 * g, 4 * g, hasA, Rt);
+    // to separator k0 - 1 (DR, gR: plain stores, they start this solve's accumulators) ...
+    rb_mul<NX, NX, true>(Rt, Xa, G);                       // r_a' S^-1 r_a
+    const double gv = rb_mulv<NX>(Rt, xz);                 // r_a' S^-1 b~
+    if (hasA && rowlane) {
+      store_row<NX>(sA.DR() + i * NX, G);
+      sA.gR()[i] = gv;
+    }
+    rb_mul<NX, NX, true, true>(Rt, Xb, RaTt);              // -(r_a' S^-1 r_bb)(i, c) = r_a(t)(c, i)
+    // ... and to t: DL[t] = r_bb' S^-1 r_bb, gL[t] = r_bb' S^-1 b~, r_a(t) = -r_bb' S^-1 r_a
+    load_RbT(2 * g, 4 * g, true, Rt);
+    rb_mul<NX, NX, false, true>(Rt, Xb, St);
+    bzt = rb_mulv_sub<NX>(Rt, xz, bzt);
+    rb_mul<NX, NX, true, true>(Rt, Xa, Rat);
+  }
+
+  // ================================================================ pass 2: s2 = k0 + 2 (knots k0 + 2, k0 + 3)
+  wave_lds_sync();  // last read of the first two knots
+  rb_stage_ab<NX, NU>(lane, 1, abm, lds.ab);
+  wave_lds_sync();
+  {
+    double Xa[NX], Xb[NX], xz;
+    eliminate0(2 * g, 4 * g + 2, false, true, hasB, myrec + 2 * REC, Xa, xz, Xb);
+    double Rt[NX], G[NX];
+    load_RbT(2 * g, 4 * g + 2, hasB, Rt);
+    rb_mul<NX, NX, true>(Rt, Xb, G);                       // r_bb' S^-1 r_bb -> DL of separator k0 + 3
+    const double gv = rb_mulv<NX>(Rt, xz);
+    if (hasB && rowlane) {
+      store_row<NX>(sB.DL() + i * NX, G);
+      sB.gL()[i] = gv;
+    }
+    rb_mul<NX, NX, true, true>(Rt, Xa, RbTt);              // -(r_bb' S^-1 r_a)(i, c) = r_bb(t)(c, i)
+    load_RaT(2 * g, 4 * g + 2, true, Rt);
+    rb_mul<NX, NX, false, true>(Rt, Xa, St);               // DR[t], gR[t]
+    bzt = rb_mulv_sub<NX>(Rt, xz, bzt);
+    rb_mul<NX, NX, true, true>(Rt, Xb, Rbt);               // r_bb(t) = -r_a' S^-1 r_bb
+  }
+
+  // ================================================================ pass 3: t = k0 + 1
+  {
+    double Xa[NX], Xb[NX], xz;
+    {
+      double Si[NX];
+      {
+        double w[NX];
+        if (rb_chol_inv<NX>(i, St, w) && i == 0) flag_failure(info, d, b);
+        rb_sinv<NX>(w, Si);
+      }
+      rb_mul<NX, NX, true>(Si, Rat, Xa);
+      xz = rb_mulv<NX>(Si, bzt);
+      rb_mul<NX, NX, true>(Si, Rbt, Xb);
+    }
+    if (rowlane) {  // record f_a | f_bb | z_sep
+      double* r = myrec + REC;
+      if (hasA) store_row<NX>(r + i * NX, Xa);
+      if (hasB) store_row<NX>(r + NN + i * NX, Xb);
+      r[2 * NN + i] = xz;
+    }
+    const bool leftchild = (k0 & 4) == 0;
+    // DR / DL are symmetric (up to rounding): the atomic adds write element (i, c) into [c * NX + i], so
+    // that the twelve lanes of a row hit one 96-byte run instead of twelve different 64-byte
+    // segments (the memory-side atomic units take one request per segment: the row-major form
+    // made this kernel 3.6x slower than its instruction count)
+    double G[NX];
+    rb_mul<NX, NX, true>(RaTt, Xa, G);
+    double gv = rb_mulv<NX>(RaTt, xz);
+    if (hasA && rowlane) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) atomicAdd(sA.DR() + c * NX + i, G[c]);
+      atomicAdd(sA.gR() + i, gv);
+    }
+    rb_mul<NX, NX, true>(RaTt, Xb, G);  // coupling of the parent to its other neighbour: CA[B] = (r_a' S^-1 r_bb)' or CB[A] = r_a' S^-1 r_bb
+    if (hasA && hasB && rowlane) {
+      if (leftchild) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) sB.CA()[c * NX + i] = G[c];
+      } else {
+        store_row<NX>(sA.CB() + i * NX, G);
+      }
+    }
+    rb_mul<NX, NX, true>(RbTt, Xb, G);
+    gv = rb_mulv<NX>(RbTt, xz);
+    if (hasB && rowlane) {
+#pragma unroll
+      for (int c = 0; c < NX; ++c) atomicAdd(sB.DL() + c * NX + i, G[c]);
+      atomicAdd(sB.gL() + i, gv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- back-substitution
+// Two launches. rb_backsub_top: multipliers of the separators of level >= 3, top-down over the tree,
+//     y_s = z_sep(s) - f_a(s) y_A - f_bb(s) y_B      (A / B: the separators left / right of s's subtree),
+// one workgroup per problem (N / 8 - 1 separators, K - 3 dependent steps), result in ytop[b][s >> 3].
+// rb_backsub: one workgroup per eight knots = one level-2 subtree. It needs only the two multipliers
+// next to it from ytop (backsub_small fetched the K - 3 records on its path to the root instead and
+// resolved them again in every workgroup), resolves its level-2 and level-1 separators from their
+// records and its four level-0 separators from the problem data and the compact record S-bar^-1 of
+// rb_bottom (their neighbours s - 1, s + 1 are known by then):
+//   v = [A_s | B_s] z-hat(s) - r_a y_{s-1} - r_bb y_{s+1} - z(s+1).lambda - z(s+1).x / Q_{s+1},   y_s = S-bar^-1 v
+//   r_a y = -A_s (y / Q_s),   r_bb y = -(A_{s+1}' y) / Q_{s+1}
+// (A_{s+1}' y_{s+1} is the dot product the state rows of knot s + 1 need anyway); then states and
+// inputs from the stationarity rows (src/solve.c:137-182 produces the same quantities level by level):
+//   lambda_k = y_{k-1}; knot 0: lambda = Q x0 + q + A_0' y_0;
+//   x_k = Q^-1 (-q_k - A_k' y_k + y_{k-1}),  u_k = R^-1 (-r_k - B_k' y_k).
+//   rb_backsub_top: grid (batch), block 256, dynamic LDS (N / 8) * NX doubles; N >= 16.
+template <int NX>
+__global__ __launch_bounds__(256) void rb_backsub_top(Dims d, const double* __restrict__ recs, double* __restrict__ ytop) {
+  constexpr int NN = NX * NX, REC = 2 * NN + NX;
+  extern __shared__ double ytop_lds[];  // [N / 8][NX]: y of separator 8 j + 7
+  const int N = d.N, K = d.K, b = blockIdx.x, t = threadIdx.x;
+  for (int L = K - 1; L >= 3; --L) {
+    const int T = 2 << L, nsep = N >> (L + 1);
+    for (int it = t; it < nsep * NX; it += 256) {
+      const int q = it / NX, r = it - q * NX;
+      const int base = q * T, s = base + (T >> 1) - 1;
+      const double* rc = recs + ((size_t)b * N + s) * REC;
+      double acc = rc[2 * NN + r];
+      if (base > 0) {
+        double f[NX];
+        load_row<NX>(rc + r * NX, f);
+        const double* y = ytop_lds + ((base - 1) >> 3) * NX;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc = fma(-f[c], y[c], acc);
+      }
+      if (base + T < N) {
+        double f[NX];
+        load_row<NX>(rc + NN + r * NX, f);
+        const double* y = ytop_lds + ((base + T - 1) >> 3) * NX;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc = fma(-f[c], y[c], acc);
+      }
+      ytop_lds[(s >> 3) * NX + r] = acc;
+    }
+    __syncthreads();
+  }
+  double* out = ytop + (size_t)b * (N >> 3) * NX;
+  for (int e = t; e < ((N >> 3) - 1) * NX; e += 256) out[e] = ytop_lds[e];
+}
+
+//   rb_backsub: grid (N / 8, batch), block 256; N >= 8.
+// Everything the workgroup needs ([A | B] of its eight knots, its seven records, weights, right-hand
+// sides: ~27 KB) arrives in ONE round of coalesced 16-byte loads and is staged in LDS; rows and columns
+// are read from there. (Row- and column-wise global loads per thread made the address units the
+// bottleneck of the first version: ~6 line requests per line actually fetched.)
+template <int NX, int NU>
+struct alignas(16) RbBacksubLds {
+  static constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, R0 = NX * (NX + 1) / 2;
+  static constexpr int R0P = (R0 + 1) / 2 * 2;      // compact record, padded to whole 16-byte words
+  static constexpr int WP = RbKnot<NX, NU>::WP;
+  double ab[8][NX * WP];
+  double rec0[4][R0P];    // level-0 separators first + 0, 2, 4, 6: S-bar^-1, packed lower triangle
+  double rec1[3][REC + (REC & 1)];  // separators first + 1, first + 3, first + 5: f_a | f_bb | z_sep
+  double ys[9][NX];       // [0..6]: separators first .. first + 6; [7]: first - 1; [8]: first + 7
+  double qs[8][W];        // 1 / [Q | R]
+  double rs[8][ROWS];     // raw right-hand sides
+  double dots[8][NX];     // A_i' y_i of the odd knots (state rows)
+  double vs[4][NX];       // v of the four level-0 separators
+};
+
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+                                                  const double* __restrict__ rhs, const double* __restrict__ recs,
+                                                  const double* __restrict__ ytop, double* __restrict__ z) {
+  using Lds = RbBacksubLds<NX, NU>;
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP;
+  constexpr int R0 = Lds::R0;
+  static_assert(9 * NX <= 256 && KPB * ROWS <= 256, "thread roles fit the workgroup");
+  __shared__ Lds lds;
+  const int N = d.N, b = blockIdx.y, first = blockIdx.x * KPB;
+  auto sep_slot = [&](int s) -> int { return s < first ? 7 : (s >= first + 7 ? 8 : s - first); };
+  const int t = threadIdx.x;
+
+  // ---- one round of loads
+  {
+    const double* abm = AB + ((size_t)b * N + first) * NX * W;
+    const double* rc0 = recs + ((size_t)b * N + first) * REC;
+    constexpr int NA = KPB * NX * W, IA = (NA + 255) / 256;                  // [A | B]: scalar words (W may be odd)
+    constexpr int N0 = 4 * R0, I0 = (N0 + 255) / 256, N1 = 3 * REC, I1 = (N1 + 255) / 256;
+    constexpr int NQ = KPB * W, NR = KPB * ROWS;
+    static_assert(NQ <= 256 && NR <= 256, "one load per thread for the vectors");
+    double ta[IA], t0[I0], t1[I1];
+#pragma unroll
+    for (int it = 0; it < IA; ++it) { const int e = t + 256 * it; ta[it] = abm[e < NA ? e : NA - 1]; }
+#pragma unroll
+    for (int it = 0; it < I0; ++it) {
+      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / R0, w_ = ec - j * R0;
+      t0[it] = rc0[(size_t)(2 * j) * REC + w_];
+    }
+#pragma unroll
+    for (int it = 0; it < I1; ++it) {
+      const int e = t + 256 * it, ec = e < N1 ? e : N1 - 1, j = ec / REC, w_ = ec - j * REC;
+      t1[it] = rc0[(size_t)(2 * j + 1) * REC + w_];
+    }
+    const double tq = QR[((size_t)b * N + first) * W + (t < NQ ? t : NQ - 1)];
+    const double tr = rhs[((size_t)b * N + first) * ROWS + (t < NR ? t : NR - 1)];
+    double ty = 0.0;
+    if (t < 2 * NX) {  // the two multipliers next to the workgroup's subtree
+      const int sx = t < NX ? first - 1 : first + 7;
+      if (sx >= 0 && sx < N - 1) ty = ytop[((size_t)b * (N >> 3) + (sx >> 3)) * NX + (t < NX ? t : t - NX)];
+    }
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+      const int e = t + 256 * it, ec = e < NA ? e : NA - 1, kn = ec / (NX * W), w_ = ec - kn * NX * W;
+      const int row = w_ / W, c = w_ - row * W;
+      lds.ab[kn][row * WP + c] = ta[it];
+    }
+#pragma unroll
+    for (int it = 0; it < I0; ++it) {
+      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / R0, w_ = ec - j * R0;
+      lds.rec0[j][w_] = t0[it];
+    }
+#pragma unroll
+    for (int it = 0; it < I1; ++it) {
+      const int e = t + 256 * it, ec = e < N1 ? e : N1 - 1, j = ec / REC, w_ = ec - j * REC;
+      lds.rec1[j][w_] = t1[it];
+    }
+    (&lds.qs[0][0])[t < NQ ? t : NQ - 1] = 1.0 / tq;
+    (&lds.rs[0][0])[t < NR ? t : NR - 1] = tr;
+    if (t < 2 * NX) lds.ys[t < NX ? 7 : 8][t < NX ? t : t - NX] = ty;
+  }
+  __syncthreads();
+
+  const int q = t / NX, r = t - q * NX;
+  const bool sep_thread = q < 7;
+  const int s = first + (sep_thread ? q : 0), l = trailing_ones(s);  // l <= 2 for the local separators
+  const int sbase = s - ((1 << l) - 1);
+  const bool hasA = sbase > 0, hasB = sbase + (2 << l) < N;
+  const int slotA = hasA ? sep_slot(sbase - 1) : 0, slotB = hasB ? sep_slot(sbase + (2 << l) - 1) : 0;
+  const int kn = t / ROWS, rr = t - kn * ROWS;  // output role: knot kn of the workgroup, row rr
+  const bool out_thread = kn < KPB;
+  const int kc = out_thread ? kn : 0;
+  const int i = first + kc;
+  const bool lam = rr < NX;
+  const int col = lam ? rr : rr - NX;  // column of [A_i | B_i] this row dots with y_i
+  const bool needs_ab = out_thread && i < N - 1 && (lam ? i == 0 : !(i == 0 && rr < 2 * NX));
+  auto ab_dot = [&](const double* y) {  // column `col` of [A_i | B_i] times y
+    const double* am = lds.ab[kc] + col;
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) a = fma(am[c * WP], y[c], a);
+    return a;
+  };
+
+  // ---- multipliers of the local separators of level 2 and 1
+  for (int Lv = 2; Lv >= 1; --Lv) {
+    if (sep_thread && l == Lv) {
+      const double* rc = lds.rec1[q >> 1];
+      double a = rc[2 * NN + r];
+      if (hasA) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) a = fma(-rc[r * NX + c], lds.ys[slotA][c], a);
+      }
+      if (hasB) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) a = fma(-rc[NN + r * NX + c], lds.ys[slotB][c], a);
+      }
+      lds.ys[q][r] = a;
+    }
+    __syncthreads();
+  }
+  // ---- A_i' y_i of the odd knots (their separators are of level >= 1): part of v and of x_i
+  const bool odd_state = out_thread && (kn & 1) && rr >= NX && rr < 2 * NX;
+  double dot = 0.0;
+  if (odd_state) {
+    if (needs_ab) dot = ab_dot(lds.ys[sep_slot(i)]);
+    lds.dots[kn][rr - NX] = dot;
+  }
+  __syncthreads();
+  // ---- level-0 separators: v, then y = S-bar^-1 v
+  if (sep_thread && l == 0) {
+    const int k = s - first;  // even knot of the workgroup
+    const bool fst = s == 0;
+    const double* arow = lds.ab[k] + r * WP;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const double wq = lds.qs[k][c];
+      double zh;  // z-hat(c) + what r_a y_{s-1} contributes through column c
+      if (c < NX) zh = fst ? -lds.rs[k][c] : (lds.rs[k][NX + c] + (hasA ? lds.ys[slotA][c] : 0.0)) * wq;
+      else zh = lds.rs[k][NX + c] * wq;
+      v = fma(arow[c], zh, v);
+    }
+    const double q1 = lds.qs[k + 1][r];
+    v -= lds.rs[k + 1][r] + (lds.rs[k + 1][NX + r] - lds.dots[k + 1][r]) * q1;
+    lds.vs[k >> 1][r] = v;
+  }
+  __syncthreads();
+  if (sep_thread && l == 0) {
+    const double* v = lds.vs[(s - first) >> 1];
+    const double* si = lds.rec0[(s - first) >> 1];  // symmetric: row r from the packed lower triangle
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) a = fma(c <= r ? si[r * (r + 1) / 2 + c] : si[c * (c + 1) / 2 + r], v[c], a);
+    lds.ys[q][r] = a;
+  }
+  __syncthreads();
+
+  // ---- solution rows
+  if (!out_thread) return;
+  const double rv = lds.rs[kn][rr];
+  double out;
+  const double* yi = lds.ys[sep_slot(i < N - 1 ? i : i - 1)];        // y_i   (unused for the last knot)
+  const double* yp = lds.ys[sep_slot(i > 0 ? i - 1 : 0)];            // y_{i-1} (unused for knot 0)
+  if (needs_ab && !odd_state) dot = ab_dot(yi);
+  if (lam) {
+    out = (i == 0) ? fma(-QR[(size_t)b * N * W + rr], rv, -lds.rs[0][NX + rr]) + dot : yp[rr];
+  } else if (rr < 2 * NX) {
+    out = (i == 0) ? -lds.rs[0][rr - NX] : (rv - dot + yp[rr - NX]) * lds.qs[kn][rr - NX];
+  } else {
+    out = (i == N - 1) ? rv : (rv - dot) * lds.qs[kn][rr - NX];
+  }
+  z[((size_t)b * N + i) * ROWS + rr] = out;
+}
+
+}  // namespace ndlqr

@@ -7,8 +7,6 @@
 //   bottom_small       leaf phase + tree levels 0..JB-1 fused on chip (registers + LDS exchange)
 //   separator_core     S-bar, f_a, f_bb, z_sep of one separator by one wavefront (device function;
 //                      products on the matrix cores in fast mode)
-//   reduced_level      fast mode without KEEP: one upper level on the reduced (separator-only)
-//                      system -- assemble from pushed 12x12 blocks, factor, solve, push (gram_mfma)
 //   level_small        one upper level: separator (separator_wave) + Schur update of the first and
 //                      last knot of every subtree (schur_rows), one wavefront per subtree
 //   backsub_small      fast mode without KEEP: solution by back-substitution over the separator
@@ -16,8 +14,6 @@
 //   apply_small        strict / KEEP: every knot through all upper levels in registers, one pass
 //   rhs_forward_small, rhs_forward_upper
 //                      new right-hand side against cached records + factors (then backsub_small)
-//   separator_one, schur_small, upper_small, finish_small
-//                      alternative schedules kept for A/B timing and for J > JB
 //
 // Variants that were measured and dropped (numbers in DESIGN.md, "Tried and dropped"): two separators per
 // wavefront with L broadcast from LDS, an LDS-resident Cholesky/substitution with rolled pivot
@@ -380,16 +376,6 @@ __device__ __forceinline__ void separator_wave(const Dims& d, const int l, const
   SEG(4);
 }
 
-//   grid (N >> (l+1), batch), block 64.
-template <int NX, int NU, bool STRICT, bool KEEP>
-__global__ __launch_bounds__(64) void separator_one(Dims d, int l, const double* __restrict__ AB,
-                                                    double* F, double* z, double* __restrict__ rec,
-                                                    int* __restrict__ info) {
-  __shared__ SepIn<NX, NU> in;
-  __shared__ SepOut<NX> out;
-  separator_wave<NX, NU, STRICT, KEEP, true>(d, l, blockIdx.x, blockIdx.y, threadIdx.x, AB, F, z, rec, info, in, out);
-}
-
 // leaf-phase rhs entry rr of knot i from the raw right-hand side (the rhs part of ndlqr_SolveLeaf)
 template <int NX, int NU>
 __device__ __forceinline__ double leaf_rhs_entry(const Dims& d, const int b, const int i, const int rr,
@@ -438,182 +424,6 @@ struct RedSlot {
 template <int NX>
 __device__ __forceinline__ RedSlot<NX> red_slot(double* red, const Dims& d, const int b, const int t) {
   return RedSlot<NX>{red + ((size_t)b * (d.N >> 2) + (t >> 2)) * RedSlot<NX>::SIZE};
-}
-
-// Gram blocks of the forward-substituted panel Y on the matrix cores. The lanes first re-file
-// their columns in the panel as [a (NX) | z | pad] [bb (NX) | pad] -- two 16-column tiles --, so
-// that the products fall apart cleanly:
-//   tile 00: Y_a' Y_a and Y_a' y_z    (aa(r, c, v), c = NX is the rhs column)
-//   tile 11: Y_bb' Y_bb               (bb(r, c, v))
-//   tile 01: Y_a' Y_bb and y_z' Y_bb  (ab(r, c, v), r = NX is the rhs row)
-// each fragment read from LDS once and used as A and as B operand; tiles that are not needed
-// (need_* false) cost nothing.
-template <int NX, bool need_aa, bool need_bb, bool need_ab, class EmitAA, class EmitBB, class EmitAB>
-__device__ __forceinline__ void gram_mfma(const int lane, double (&x)[NX], SepOut<NX>& out, EmitAA aa, EmitBB bb,
-                                          EmitAB ab) {
-  constexpr int LD = SepOut<NX>::LD, NC = SepOut<NX>::NC, KS = (NX + 3) / 4;
-  static_assert(NC == 32 && NX + 1 <= 16, "two column tiles of 16: [a | z], [bb]");
-  typedef double acc4 __attribute__((ext_vector_type(4)));
-  if (lane <= 2 * NX) {  // panel column `lane`: a, bb or z
-    const int dst = lane < NX ? lane : (lane < 2 * NX ? 16 + (lane - NX) : NX);
-#pragma unroll
-    for (int k = 0; k < NX; ++k) out.X[k * LD + dst] = x[k];
-  }  // the padding columns of both tiles keep whatever they hold: they only reach products that
-     // nobody reads (every output element depends on its own pair of columns alone)
-  wave_lds_sync();
-  const int li = lane & 15, lk = lane >> 4;
-  acc4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = {0.0, 0.0, 0.0, 0.0}, g11 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    const int kk = 4 * q + lk, k = kk < NX ? kk : NX - 1;
-    const double f0 = kk < NX ? out.X[k * LD + li] : 0.0;
-    const double f1 = kk < NX ? out.X[k * LD + 16 + li] : 0.0;
-    if constexpr (need_aa) g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, g00, 0, 0, 0);
-    if constexpr (need_ab) g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, g01, 0, 0, 0);
-    if constexpr (need_bb) g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, g11, 0, 0, 0);
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int r = lk + 4 * g;
-    if constexpr (need_aa) { if (r < NX && li <= NX) aa(r, li, g00[g]); }
-    if constexpr (need_bb) { if (r < NX && li < NX) bb(r, li, g11[g]); }
-    if constexpr (need_ab) { if (r <= NX && li < NX) ab(r, li, g01[g]); }
-  }
-  wave_lds_sync();
-}
-
-// One level of the separator-only schedule, one wavefront per separator.
-//   grid (N >> (l+1), batch), block 64; l >= 2; instances with matrix-core products only.
-template <int NX, int NU>
-__global__ __launch_bounds__(64) void reduced_level(Dims d, int l, const double* __restrict__ AB,
-                                                    const double* __restrict__ QR,
-                                                    const double* __restrict__ rhs, double* red,
-                                                    double* __restrict__ rec, double* F, int* __restrict__ info,
-                                                    const int store_l) {
-  constexpr int W = NX + NU, NN = NX * NX, LD = SepOut<NX>::LD, KS = (W + 3) / 4, SP = NX + 2;
-  typedef double acc4 __attribute__((ext_vector_type(4)));
-  __shared__ SepOut<NX> out;
-  __shared__ double scr[NX * SP];
-  const int lane = threadIdx.x, b = blockIdx.y, N = d.N;
-  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
-  const bool hasA = base > 0, hasB = base + T < N;
-  const RedSlot<NX> my = red_slot<NX>(red, d, b, s);
-  const int li = lane & 15, lk = lane >> 4;
-  const int ri = li < NX ? li : NX - 1;
-  SEG_INIT();
-  const double* abm = AB + ((size_t)b * N + s) * NX * W;
-  const double* qr = QR + ((size_t)b * N + s) * W;
-  const double* qr1 = QR + ((size_t)b * N + s + 1) * W;
-
-  // [S-bar | b~] = [A | B] diag(1/Q, 1/R) [A | B]' + Q_{s+1}^-1 - DL - DR  |  [A | B] z(s).xu - z(s+1)
-  // - gL - gR as ONE 16x16 tile: column NX of the B operand carries the leaf-phase rhs of knot s.
-  // (Knots s and s+1 of a level >= 2 are never the first or the last knot: no special cases.)
-  // Every global operand is requested first, in straight-line code with clamped indices, so that
-  // the wavefront pays one memory round trip before it starts computing.
-  const double* r0 = rhs + ((size_t)b * N + s) * (2 * NX + NU);
-  const double* r1 = r0 + (2 * NX + NU);
-  constexpr int QP = (NN + 63) / 64;
-  double pca[QP], pcb[QP];
-#pragma unroll
-  for (int q = 0; q < QP; ++q) {
-    const int e = lane + 64 * q, ec = e < NN ? e : NN - 1;
-    pca[q] = my.CA()[ec];
-    pcb[q] = my.CB()[ec];
-  }
-  double dlr[4], extra[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
-    dlr[g] = my.DL()[ic * NX + ri] + my.DR()[ic * NX + ri];
-    // diagonal term of S-bar (lanes li < NX) / rhs terms (lane li == NX)
-    extra[g] = li == NX ? r1[ic] + r1[NX + ic] / qr1[ic] + my.gL()[ic] + my.gR()[ic] : 1.0 / qr1[ic];
-  }
-  double afr[KS], bfr[KS];
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    const int kk = 4 * q + lk, k = kk < W ? kk : W - 1;
-    const bool kin = kk < W;
-    const double wk = 1.0 / qr[k];
-    const double av = abm[ri * W + k], zv = r0[NX + k];
-    afr[q] = kin ? av : 0.0;
-    bfr[q] = !kin ? 0.0 : (li < NX ? av * wk : (li == NX ? zv * wk : 0.0));
-  }
-  acc4 c0;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int i = lk + 4 * g;
-    double v = 0.0;
-    if (i < NX) {
-      if (li < NX) v = (i == li ? extra[g] : 0.0) - dlr[g];
-      else if (li == NX) v = -extra[g];
-    }
-    c0[g] = v;
-  }
-#pragma unroll
-  for (int q = 0; q < KS; ++q) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[q], bfr[q], c0, 0, 0, 0);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int i = lk + 4 * g;
-    if (i < NX) {
-      if (li < NX) scr[i * SP + li] = c0[g];
-      else if (li == NX) out.X[i * LD + 2 * NX] = c0[g];
-    }
-  }
-  // panel columns [r_a | r_bb]
-#pragma unroll
-  for (int q = 0; q < QP; ++q) {
-    const int e = lane + 64 * q;
-    if (e < NN) {
-      const int i = e / NX, j = e - i * NX;
-      out.X[i * LD + j] = hasA ? -pca[q] : 0.0;
-      out.X[i * LD + NX + j] = hasB ? -pcb[q] : 0.0;
-    }
-  }
-  wave_lds_sync();
-  const int grp = lane / NX, gi = lane - grp * NX;
-  double acc[NX], Lrow[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) acc[j] = scr[gi * SP + j];
-
-  // pushes to the two neighbours
-  const bool leftchild = (base & T) == 0;
-  const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
-  const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
-  auto hook = [&](double (&x)[NX]) {
-    gram_mfma<NX, true, true, true>(
-        lane, x, out,
-        [&](int r, int c, double v) {  // Y_a' [Y_a | y_z]
-          if (!hasA) return;
-          if (c < NX) atomicAdd(sa.DR() + r * NX + c, v); else atomicAdd(sa.gR() + r, v);
-        },
-        [&](int r, int c, double v) { if (hasB) atomicAdd(sb.DL() + r * NX + c, v); },  // Y_bb' Y_bb
-        [&](int r, int c, double v) {  // [Y_a | y_z]' Y_bb
-          if (!hasB) return;
-          if (r == NX) atomicAdd(sb.gL() + c, v);
-          else if (hasA) { if (leftchild) sb.CA()[c * NX + r] = v; else sa.CB()[r * NX + c] = v; }
-        });
-  };
-  SEG(9);
-  const bool bad = factor_solve<NX, false, false, 8>(lane, acc, out, Lrow,
-                                                     store_l ? Fblk(F, d, b, l, s + 1) : nullptr, hook);
-  if (bad && lane == 0) flag_failure(info, d, b);
-  SEG(13);  // re-arms the clock after factor_solve's own marks
-
-  double* myrec = rec + ((size_t)b * N + s) * (2 * NN + NX);
-  if (grp < 2) {
-    if (grp == 0 ? hasA : hasB) {
-      double row[NX];
-#pragma unroll
-      for (int c = 0; c < NX; ++c) row[c] = out.X[gi * LD + grp * NX + c];
-      store_row<NX>(myrec + grp * NN + gi * NX, row);
-    }
-  } else if (grp == 2) {
-    myrec[2 * NN + gi] = out.X[gi * LD + 2 * NX];
-  }
-#ifdef NDLQR_SEGTIME
-  __builtin_amdgcn_s_waitcnt(0);
-#endif
-  SEG(12);
 }
 
 // ------------------------------------------------------------------------------------- row update helpers
@@ -817,94 +627,10 @@ __device__ __forceinline__ void schur_rows(const Dims& d, const int l, const int
   schur_rows_apply<NX, NU, STRICT, LDF, ZS>(d, l, i, r, b, F, z, fa, fb, zsep, row);
 }
 
-// BOUNDARY = false: every knot (grid.x = N / KPB workgroups of KPB consecutive knots).
-// BOUNDARY = true : only the first and the last knot of every level-l subtree, the two that
-//                   later separators read (one wavefront per subtree, KPW must be 2..; grid.x =
-//                   ceil(N / 2^(l+1) / WAVES)); used for the upper levels before apply_small.
-template <int NX, int NU, bool STRICT, bool BOUNDARY>
-__global__ __launch_bounds__(256) void schur_small(Dims d, int l, double* F, double* z,
-                                                   const double* __restrict__ recs) {
-  using Sh = SchurShape<NX, NU>;
-  constexpr int ROWS = Sh::ROWS, KPW = Sh::KPW, KPB = Sh::KPB, REC = Sh::REC, WAVES = Sh::WAVES;
-  static_assert(KPW >= 2 && (KPB & (KPB - 1)) == 0, "knots per workgroup must be a power of two");
-  const int N = d.N, b = blockIdx.y;
-  const int half = 1 << l, T = 2 << l;
-  const int nsub = N >> (l + 1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int kn = lane / ROWS, r = lane - kn * ROWS;
-  int i;
-  const bool idle_lane = kn >= 2;  // lanes beyond two knots only help staging the record
-  if (BOUNDARY) {
-    const int sub = blockIdx.x * WAVES + wave;
-    if (sub >= nsub) return;
-    i = sub * T + (kn == 0 ? 0 : T - 1);
-  } else {
-    if (kn >= KPW) return;
-    i = blockIdx.x * KPB + wave * KPW + kn;
-  }
-  const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
-  // All knots of a wavefront sit in the same level-l subtree (KPW consecutive, aligned knots),
-  // so the separator record address is wave-uniform.
-  //   full-level mode: scalar loads, SGPR operands in the FMAs (many wavefronts hide the latency);
-  //   boundary mode  : few wavefronts, latency-bound -> each wavefront stages its record in LDS
-  //                    with one round of vector loads and reads it back as broadcasts.
-  const int qs = __builtin_amdgcn_readfirstlane(s);
-  const double* rcd = recs + ((size_t)b * N + qs) * REC;
-  __shared__ __attribute__((aligned(16))) double recl[BOUNDARY ? WAVES : 1][BOUNDARY ? REC : 2];
-  if constexpr (BOUNDARY) {
-    double* dst = recl[wave];
-    if constexpr (REC % 2 == 0) {
-      for (int e = lane; e < REC / 2; e += 64)
-        reinterpret_cast<double2*>(dst)[e] = reinterpret_cast<const double2*>(rcd)[e];
-    } else {
-      for (int e = lane; e < REC; e += 64) dst[e] = rcd[e];
-    }
-    wave_lds_sync();
-    rcd = dst;
-    if (idle_lane) return;
-  }
-  const double* fa = rcd;
-  const double* fb = rcd + NX * NX;
-  const double* zsep = rcd + 2 * NX * NX;
-  schur_rows<NX, NU, STRICT, NX, 1>(d, l, i, r, b, F, z, fa, fb, zsep);
-}
-
 // ------------------------------------------------------------------------------------- upper levels
-// Levels l0..K-1 of ONE problem in one launch: per level every wavefront takes subtrees in turn --
-// separator (separator_wave) and, below the top level, the Schur update of the subtree's first
-// and last knot straight from the solved panel in LDS -- and the workgroup barrier between levels
-// replaces the launch boundary (all hand-overs between levels go through global memory, which a
-// workgroup sees coherently across its barrier). Same arithmetic per element as separator_one +
-// schur_small<BOUNDARY> level by level; what it removes is 2 (K - l0) - 1 short, latency-bound
-// launches whose tails each drain the whole chip.
-//   grid (batch), block 64 * nw, dynamic LDS = nw * (sizeof(SepIn) + sizeof(SepOut)).
-template <int NX, int NU, bool STRICT, bool KEEP>
-__global__ __launch_bounds__(512) void upper_small(Dims d, int l0, const double* __restrict__ AB, double* F,
-                                                   double* z, double* __restrict__ rec,
-                                                   int* __restrict__ info, const int store_l) {
-  constexpr int ROWS = 2 * NX + NU, LD = SepOut<NX>::LD;
-  extern __shared__ __attribute__((aligned(16))) unsigned char upper_lds[];
-  const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  SepIn<NX, NU>& in = reinterpret_cast<SepIn<NX, NU>*>(upper_lds)[wave];
-  SepOut<NX>& out = reinterpret_cast<SepOut<NX>*>(upper_lds + (size_t)nw * sizeof(SepIn<NX, NU>))[wave];
-  const int b = blockIdx.x, K = d.K;
-  const int kn = lane / ROWS, r = lane - kn * ROWS;
-  for (int l = l0; l < K; ++l) {
-    const int nsub = d.N >> (l + 1), T = 2 << l;
-    for (int sub = wave; sub < nsub; sub += nw) {
-      separator_wave<NX, NU, STRICT, KEEP, KEEP>(d, l, sub, b, lane, AB, F, z, rec, info, in, out, store_l != 0);
-      if (l < K - 1 && kn < 2) {
-        const int i = sub * T + (kn == 0 ? 0 : T - 1);
-        schur_rows<NX, NU, STRICT, LD, LD>(d, l, i, r, b, F, z, out.X, out.X + NX, out.X + 2 * NX);
-      }
-      wave_lds_sync();  // the panel is rewritten by this wavefront's next subtree
-    }
-    __syncthreads();
-  }
-}
-
-// One level, one wavefront per subtree: separator + boundary Schur update in the same launch
-// (the loop body of upper_small with chip-wide parallelism).  grid (N >> (l+1), batch), block 64.
+// One level of the knot-based schedule, one wavefront per subtree: the separator (separator_wave)
+// and, below the top level, the Schur update of the subtree's first and last knot -- the two rows
+// later separators read -- straight from the solved panel in LDS.  grid (N >> (l+1), batch), block 64.
 template <int NX, int NU, bool STRICT, bool KEEP>
 __global__ __launch_bounds__(64) void level_small(Dims d, int l, const double* __restrict__ AB, double* F,
                                                   double* z, double* __restrict__ rec, int* __restrict__ info,
@@ -929,11 +655,11 @@ __global__ __launch_bounds__(64) void level_small(Dims d, int l, const double* _
 
 // ------------------------------------------------------------------------------------- apply
 // All upper levels J..K-1 for every knot in ONE pass (DESIGN.md "boundary-first"): once the
-// separator records of those levels exist (separator_one on the boundary knots, which
-// schur_small<BOUNDARY> keeps up to date), a knot's updates at successive levels only involve its
+// separator records of those levels exist (level_small: separator + the boundary knots of every
+// subtree), a knot's updates at successive levels only involve its
 // own rows: E (column l), the two live outer columns and its rhs entry stay in registers and
 // rotate from level to level; only the rhs (and, with KEEP, the finished columns) go back to HBM.
-// Same operations in the same order per element as running schur_small level by level.
+// Same operations in the same order per element as a full Schur pass per level.
 //   grid (N / KPB, batch), block 256, dynamic LDS = (K - J) * REC doubles.
 // Knots that the boundary pass already advanced (first / last knot of a 2^J block) join at the
 // level where that pass left them (lstart).
@@ -1041,132 +767,6 @@ __global__ __launch_bounds__(256) void apply_small(Dims d, int J, double* F, dou
     rotate_roles<NX>(E, Ca, Cb, __builtin_amdgcn_readfirstlane((int)((base & T) == 0)) != 0);
   }
   *zp = zz;
-}
-
-// ------------------------------------------------------------------------------------- finish
-// Fast-mode replacement for apply_small when neither the finished factor columns (KEEP) nor the
-// reference's operation order (STRICT) is asked for. Above level J a knot row only contributes
-// to its own solution entry, and the map (E, C) -> (E', C') of one level (row_update followed by
-// rotate_roles) is linear and the same for every knot of a half-subtree:
-//     left half,  left child :  E' = -E f_bb      C' = C - E f_a
-//     left half,  right child:  E' = C - E f_a    C' = -E f_bb
-//     right half, left child :  E' = C - E f_bb   C' = -E f_a
-//     right half, right child:  E' = -E f_a       C' = C - E f_bb
-// so z_final = z - sum_l E_l z_sep(l) = z - [E_J C_J] w_J with the 2 NX-vector w_l of the knot's
-// half-subtree from the top-down recurrence (w_K = 0)
-//     w_l.E = z_sep(l) - P w_{l+1}.E - Q w_{l+1}.C,   (P, Q) = left child ? (f_bb, f_a) : (f_a, f_bb)
-//     w_l.C = (left half == left child) ? w_{l+1}.C : w_{l+1}.E
-// Two NX-term dot products per knot row instead of 2 NX^2 + NX multiply-adds per level; same
-// result up to rounding (tests: fast-mode tolerance against the oracle and the KKT residual).
-// Boundary knots join at the level where the boundary pass left them (lstart, see apply_small);
-// the lambda rows of knot s+1 start from the separator's own results one level higher.
-//   grid (N / KPB, batch), block 256, dynamic LDS = (K - J) * (REC + 2 * 2 NX) doubles; J >= 2.
-template <int NX, int NU>
-__global__ __launch_bounds__(256) void finish_small(Dims d, int J, const double* __restrict__ F, double* z,
-                                                    const double* __restrict__ recs) {
-  using Sh = SchurShape<NX, NU>;
-  constexpr int ROWS = Sh::ROWS, KPW = Sh::KPW, KPB = Sh::KPB, REC = Sh::REC, NN = NX * NX;
-  constexpr int HB = 2, WV = 2 * NX;  // half-subtrees of a level that one workgroup can touch (l >= 2)
-  static_assert(KPB == 8, "half-subtree bookkeeping assumes eight knots per workgroup");
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int N = d.N, K = d.K, b = blockIdx.y;
-  const int first = blockIdx.x * KPB;
-  double* wv = lds + (K - J) * REC;  // w of (level l, half-subtree hb) at wv[((l - J) * HB + hb) * WV]
-  for (int l = J; l < K; ++l) {
-    const int qs = ((first >> (l + 1)) << (l + 1)) + (1 << l) - 1;
-    const double* src = recs + ((size_t)b * N + qs) * REC;
-    double* dst = lds + (l - J) * REC;
-    for (int e = threadIdx.x; e < REC; e += 256) dst[e] = src[e];
-  }
-  __syncthreads();
-
-  for (int l = K - 1; l >= J; --l) {
-    const int nh = (KPB >> l) > 1 ? (KPB >> l) : 1;
-    if ((int)threadIdx.x < nh * WV) {
-      const int hb = threadIdx.x / WV, e = threadIdx.x - hb * WV;
-      const int h = (first >> l) + hb, sub = h >> 1;
-      const bool left = (h & 1) == 0, leftchild = (sub & 1) == 0;
-      int a, bb;
-      outer_columns(sub << (l + 1), l, N, a, bb);
-      const double* rc = lds + (l - J) * REC;
-      const bool top = (l == K - 1);
-      const double* wn = wv + ((top ? 0 : l + 1 - J) * HB) * WV;  // one half-subtree at l + 1 >= 3
-      double out = 0.0;
-      if (e < NX) {
-        out = rc[2 * NN + e];
-        if (!top) {
-          const double* P = leftchild ? rc + NN : rc;
-          const double* Q = leftchild ? rc : rc + NN;
-          const bool hasP = leftchild ? bb >= 0 : a >= 0, hasQ = leftchild ? a >= 0 : bb >= 0;
-          if (hasP) {
-#pragma unroll
-            for (int c = 0; c < NX; ++c) out = fma(-P[e * NX + c], wn[c], out);
-          }
-          if (hasQ) {
-#pragma unroll
-            for (int c = 0; c < NX; ++c) out = fma(-Q[e * NX + c], wn[NX + c], out);
-          }
-        }
-      } else if (!top) {
-        out = (left == leftchild) ? wn[e] : wn[e - NX];
-      }
-      wv[((l - J) * HB + hb) * WV + e] = out;
-    }
-    __syncthreads();
-  }
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int kn = lane / ROWS, r = lane - kn * ROWS;
-  if (kn >= KPW) return;
-  const int i = first + wave * KPW + kn;
-  const bool lam = r < NX;
-  int l = J;
-  {
-    const int mask = (1 << J) - 1;
-    if ((i & mask) == 0) l = (i == 0) ? K : __builtin_ctz(i);
-    else if ((i & mask) == mask) l = trailing_ones(i);
-    if (l > K - 1) l = K - 1;
-  }
-  const int half = 1 << l, T = 2 << l;
-  const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
-  int a, bb;
-  outer_columns(base, l, N, a, bb);
-  const bool left = i <= s;
-  const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
-  double* zp = z + ((size_t)b * N + i) * ROWS + r;
-  if (!lam || calc_lambda) {
-    const double* w = wv + ((l - J) * HB + ((i >> l) - (first >> l))) * WV;
-    double E[NX];
-    load_row<NX>(Fblk(F, d, b, l, i) + r * NX, E);
-    double acc = *zp;
-#pragma unroll
-    for (int c = 0; c < NX; ++c) acc = fma(-E[c], w[c], acc);
-    const int cc = left ? a : bb;
-    if (cc >= 0) {
-      load_row<NX>(Fblk(F, d, b, cc, i) + r * NX, E);
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc = fma(-E[c], w[NX + c], acc);
-    }
-    *zp = acc;
-  } else if (i == s + 1 && l + 1 < K) {
-    // lambda rows of knot s+1: z holds z_sep(l), the row's columns are f_a / f_bb of this level
-    const bool leftchild = (base & T) == 0;
-    const double* rc = lds + (l - J) * REC;
-    const double* w = wv + ((l + 1 - J) * HB) * WV;
-    const double* Ep = leftchild ? rc + NN + r * NX : rc + r * NX;
-    const double* Cp = leftchild ? rc + r * NX : rc + NN + r * NX;
-    const bool hasE = leftchild ? bb >= 0 : a >= 0, hasC = leftchild ? a >= 0 : bb >= 0;
-    double acc = *zp;
-    if (hasE) {
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc = fma(-Ep[c], w[c], acc);
-    }
-    if (hasC) {
-#pragma unroll
-      for (int c = 0; c < NX; ++c) acc = fma(-Cp[c], w[NX + c], acc);
-    }
-    *zp = acc;
-  }
 }
 
 // ------------------------------------------------------------------------------------- back-substitution
@@ -1511,22 +1111,17 @@ __global__ __launch_bounds__(512) void rhs_forward_upper(Dims d, const double* _
 // wavefront computes the separator of its own subtree (redundantly for l > 0 -- no result
 // broadcast, no idle waves), updates its two knots and rotates the column roles (see
 // apply_small). Written back: column JB and the live outer column of every knot plus its rhs
-// block -- what separator_*(JB) / schur / apply expect -- and, with KEEP, the finished columns
-// 0..JB-1. Arithmetic and order per element are those of leaf_generic + separator_one +
-// schur_small run level by level.
+// block -- what level_small(JB) / apply_small expect -- and, with KEEP, the finished columns
+// 0..JB-1. Arithmetic and order per element are those of leaf_generic + separator_generic +
+// schur_generic run level by level.
 //   grid (N >> JB, batch), block 32 << JB threads. Requires N > 2^JB.
-// REDUCED (fast mode without KEEP, JB = 2): the workgroup feeds the separator-only schedule of the
-// upper levels (reduced_level) -- its three separators push their Gram blocks to the two
-// separators next to the workgroup, and neither the last level's Schur update nor any hand-off
-// of knot rows is needed.
-template <int NX, int NU, bool STRICT, bool KEEP, int JB, bool REDUCED = false>
+template <int NX, int NU, bool STRICT, bool KEEP, int JB>
 __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double* __restrict__ AB,
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
                                                          double* z, int* __restrict__ info,
                                                          double* __restrict__ rec, const int lean,
-                                                         const int recout, double* red = nullptr) {
-  static_assert(!REDUCED || (JB == 2 && !STRICT && !KEEP), "separator-only feed: fast mode, two fused levels");
+                                                         const int recout) {
   // lean (fast mode without KEEP only): the solution comes from backsub_small, which needs the
   // records of the on-chip separators but nothing of the interior knots -- hand off only the
   // first and the last knot of the workgroup (what the upper levels read).
@@ -1698,55 +1293,9 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
         }
       }
       bool bad;
-      if constexpr (REDUCED) {
-        // Gram pushes: level 0 parks the outward blocks of its two separators in the [A|B]
-        // staging areas they have finished with (knot 0 / knot 2); level 1 adds its own and
-        // writes the workgroup's contribution to the separators left (A) and right (B) of it
-        double* park_a = &pv[0].ab[0][0];  // Y_a'Y_a (NX x NX) | Y_a'y_z of separator wgbase
-        double* park_b = &pv[1].ab[0][0];  // Y_bb'Y_bb | Y_bb'y_z of separator wgbase + 2
-        static_assert(NX * WP >= NX * NX + NX, "parking area too small");
-        const bool hasA = wgbase > 0, hasB = wgbase + NK < N;
-        const bool leftchild = (wgbase & NK) == 0;
-        const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? wgbase - 1 : 3);
-        const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? wgbase + NK - 1 : 3);
-        auto hook = [&](double (&x)[NX]) {
-          if (l == 0) {
-            // separator wgbase (sub 0): its a-side faces the left neighbour; separator
-            // wgbase + 2 (sub 1): its bb-side faces the right neighbour
-            auto none = [](int, int, double) {};
-            if (sub == 0)
-              gram_mfma<NX, true, false, false>(
-                  lane, x, sout,
-                  [&](int r, int c, double v) { if (c < NX) park_a[r * NX + c] = v; else park_a[NX * NX + r] = v; },
-                  none, none);
-            else
-              gram_mfma<NX, false, true, true>(
-                  lane, x, sout, none, [&](int r, int c, double v) { park_b[r * NX + c] = v; },
-                  [&](int r, int c, double v) { if (r == NX) park_b[NX * NX + c] = v; });
-          } else {
-            gram_mfma<NX, true, true, true>(
-                lane, x, sout,
-                [&](int r, int c, double v) {
-                  if (!hasA) return;
-                  if (c < NX) sa.DR()[r * NX + c] = v + park_a[r * NX + c];
-                  else sa.gR()[r] = v + park_a[NX * NX + r];
-                },
-                [&](int r, int c, double v) { if (hasB) sb.DL()[r * NX + c] = v + park_b[r * NX + c]; },
-                [&](int r, int c, double v) {
-                  if (!hasB) return;
-                  if (r == NX) sb.gL()[c] = v + park_b[NX * NX + c];
-                  else if (hasA) { if (leftchild) sb.CA()[c * NX + r] = v; else sa.CB()[r * NX + c] = v; }
-                });
-          }
-        };
-        bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
-                                                       pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP,
-                                                       (recout & 2) ? Fblk(F, d, b, l, s + 1) : nullptr, hook);
-      } else {
-        bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
-                                                       pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP,
-                                                       (!KEEP && (recout & 2)) ? Fblk(F, d, b, l, s + 1) : nullptr);
-      }
+      bad = separator_core<NX, NU, STRICT, KEEP, 16>(lane, ab, xc, sout, Lrow,
+                                                     pv[(s - wgbase) >> 1].ab[(s - wgbase) & 1], WP,
+                                                     (!KEEP && (recout & 2)) ? Fblk(F, d, b, l, s + 1) : nullptr);
       if (bad && lane == 0) flag_failure(info, d, b);
       if (KEEP && lane < NX) store_row<NX>(Fblk(F, d, b, l, s + 1) + gi * NX, Lrow);
       if constexpr (!STRICT) {
@@ -1767,7 +1316,6 @@ __global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double
       }
     }
     SEG(23);
-    if constexpr (REDUCED) { if (l == JB - 1) return; }  // no Schur update, no hand-off: the upper levels work on the pushed blocks
     __syncthreads();
     SEG(24);
 

@@ -77,22 +77,14 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
-  c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false;
-  c->big_lds_kernel = nullptr;
+  c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false;
+
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
-  c->reduced = getenv("NDLQR_REDUCED") ? atoi(getenv("NDLQR_REDUCED")) != 0 : true;
-  c->mcore = getenv("NDLQR_MCORE") ? atoi(getenv("NDLQR_MCORE")) != 0 : true;
-  c->bottom_reduced = getenv("NDLQR_BOTTOM_REDUCED") ? atoi(getenv("NDLQR_BOTTOM_REDUCED")) != 0 : true;
-  c->fuse_level = getenv("NDLQR_FUSE_LEVEL") ? atoi(getenv("NDLQR_FUSE_LEVEL")) : -1;
+  c->rowbcast = getenv("NDLQR_ROWBCAST") ? atoi(getenv("NDLQR_ROWBCAST")) != 0 : true;
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
-  c->no_finish = getenv("NDLQR_NO_FINISH") != nullptr;
-  c->no_backsub = getenv("NDLQR_NO_BACKSUB") != nullptr;
-  c->bottom_lds_pad = getenv("NDLQR_BOTTOM_LDS_PAD") ? atoi(getenv("NDLQR_BOTTOM_LDS_PAD")) : 0;
   c->sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS")) : 0;
-  c->upper_mode = getenv("NDLQR_UPPER") ? atoi(getenv("NDLQR_UPPER")) : 1;
-  c->bottom_levels = getenv("NDLQR_BOTTOM_LEVELS") ? atoi(getenv("NDLQR_BOTTOM_LEVELS")) : 2;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
-  c->graph_exec = nullptr; c->graph_flags = 0; c->graph_J = c->graph_JB = -2; c->graph_stream = nullptr;
+  c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -108,6 +100,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
     const size_t slot_doubles = (4 * (size_t)nstates * nstates + 2 * nstates + 15) / 16 * 16;
     const size_t red_bytes = sizeof(double) * (size_t)batch * (nhorizon / 4) * slot_doubles;
     ok = hipMalloc(&c->red, red_bytes) == hipSuccess && hipMemsetAsync(c->red, 0, red_bytes, c->stream) == hipSuccess;
+    ok = ok && hipMalloc(&c->ytop, sizeof(double) * (size_t)batch * (nhorizon / 8) * nstates) == hipSuccess;
     const size_t cnt_bytes = sizeof(int) * (size_t)batch * (nhorizon / 4);
     ok = ok && hipMalloc(&c->tree_cnt, cnt_bytes) == hipSuccess &&
          hipMemsetAsync(c->tree_cnt, 0, cnt_bytes, c->stream) == hipSuccess;
@@ -135,7 +128,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
-  (void)hipFree(c->kkt_out);
+  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -304,8 +297,8 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
 // ---- size-specialised instances: one translation unit each (small_instance.hip), listed in
 //      small_instances.def
 #define NDLQR_SMALL_INSTANCE(NX_, NU_)                                              \
-  int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep, int J); \
-  int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep, int J); \
+  int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep);       \
+  int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep); \
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c);                               \
   int ndlqr_small_kpb_##NX_##_##NU_(void);
 #include "small_instances.def"
@@ -313,20 +306,20 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
 
 struct SmallInstance {
   int nx, nu;
-  int (*solve)(NdlqrHipCtx*, bool, bool, int);
-  int (*needs_F)(const NdlqrHipCtx*, bool, bool, int);
+  int (*solve)(NdlqrHipCtx*, bool, bool);
+  int (*needs_F)(const NdlqrHipCtx*, bool, bool);
   void (*rhs)(NdlqrHipCtx*);
   int (*kpb)(void);
 };
 #ifdef NDLQR_SINGLE_TU
 #define NDLQR_SMALL_INSTANCE(NX_, NU_)                                                              \
-  int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep, int J) {              \
-    if (strict) return keep ? launch_small<NX_, NU_, true, true>(c, J) : launch_small<NX_, NU_, true, false>(c, J); \
-    return keep ? launch_small<NX_, NU_, false, true>(c, J) : launch_small<NX_, NU_, false, false>(c, J);           \
+  int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep) {                     \
+    if (strict) return keep ? launch_small<NX_, NU_, true, true>(c) : launch_small<NX_, NU_, true, false>(c); \
+    return keep ? launch_small<NX_, NU_, false, true>(c) : launch_small<NX_, NU_, false, false>(c);           \
   }                                                                                                 \
-  int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep, int J) {      \
-    if (strict) return keep ? plan_small<NX_, NU_, true, true>(c, J).needs_F : plan_small<NX_, NU_, true, false>(c, J).needs_F; \
-    return keep ? plan_small<NX_, NU_, false, true>(c, J).needs_F : plan_small<NX_, NU_, false, false>(c, J).needs_F;           \
+  int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep) {             \
+    if (strict) return keep ? plan_small<NX_, NU_, true, true>(c).needs_F : plan_small<NX_, NU_, true, false>(c).needs_F; \
+    return keep ? plan_small<NX_, NU_, false, true>(c).needs_F : plan_small<NX_, NU_, false, false>(c).needs_F;           \
   }                                                                                                 \
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c) { launch_rhs_records<NX_, NU_>(c); }           \
   int ndlqr_small_kpb_##NX_##_##NU_(void) { return ndlqr::SchurShape<NX_, NU_>::KPB; }
@@ -354,40 +347,30 @@ static const SmallInstance* find_small(const ndlqr::Dims& d) {
   return nullptr;
 }
 
-// the size-specialised instance that serves this context (nullptr: runtime-sized kernels) and the
-// fuse level J it runs with
-static const SmallInstance* pick_small(const NdlqrHipCtx* c, int* J_out) {
+// the size-specialised instance that serves this context (nullptr: runtime-sized kernels)
+static const SmallInstance* pick_small(const NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   if (c->flags & NDLQR_FLAG_GENERIC) return nullptr;
   const SmallInstance* inst = find_small(d);
-  if (!inst) return nullptr;
-  const int kpb = inst->kpb();
-  if (d.N < kpb) return nullptr;
-  // apply_small needs all KPB knots of a workgroup inside one level-J subtree: 2^(J+1) >= KPB
-  int Jmin = 0;
-  while ((2 << Jmin) < kpb) ++Jmin;
-  int J = c->fuse_level >= 0 ? c->fuse_level : 2;
-  if (J < Jmin) J = Jmin;
-  if (J > d.K) J = d.K;
-  *J_out = J;
+  // the fused kernels own eight knots per workgroup and two tree levels: shorter horizons run the
+  // runtime-sized kernels
+  if (!inst || d.N < inst->kpb() || d.K < 3) return nullptr;
   return inst;
 }
 
 // returns true when (n, m, N) has a size-specialised instance and it was launched
 static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
-  int J = 0;
-  const SmallInstance* inst = pick_small(c, &J);
+  const SmallInstance* inst = pick_small(c);
   if (!inst) return false;
-  *err = inst->solve(c, strict, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0, J);
+  *err = inst->solve(c, strict, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0);
   return true;
 }
 
 // does the launch sequence enqueue_solve is about to issue touch the factor array?
 static bool solve_needs_F(const NdlqrHipCtx* c) {
-  int J = 0;
-  const SmallInstance* inst = pick_small(c, &J);
+  const SmallInstance* inst = pick_small(c);
   if (!inst) return true;  // the runtime-sized kernels work on F
-  return inst->needs_F(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0, J) != 0;
+  return inst->needs_F(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0) != 0;
 }
 
 // Enqueue leaf/bottom + per-level + apply launches on the context's stream.
@@ -400,7 +383,7 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   c->rec_complete = false;
   done = try_launch_small(c, strict, &err);
   if (!done) {
-    const bool lean = !strict && !(c->flags & NDLQR_FLAG_KEEP_FACT) && !c->no_backsub;
+    const bool lean = !strict && !(c->flags & NDLQR_FLAG_KEEP_FACT);
     err = strict ? launch_generic<true>(c, false) : launch_generic<false>(c, lean);
   }
   // the batch-wide failure count travels to pinned host memory behind the last kernel: the host
@@ -423,8 +406,7 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   } else {
     // The sequence is a fixed chain of up to 1 + 2K short launches: capture it once as a hipGraph
     // and replay it (launch-bound single solves -- batch 1 -- gain the most).
-    const bool stale = !c->graph_exec || c->graph_flags != c->flags || c->graph_J != c->fuse_level ||
-                       c->graph_JB != c->bottom_levels || c->graph_stream != c->stream;
+    const bool stale = !c->graph_exec || c->graph_flags != c->flags || c->graph_stream != c->stream;
     if (stale) {
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       hipGraph_t graph = nullptr;
@@ -436,7 +418,7 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
       e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (e != hipSuccess) { c->graph_exec = nullptr; return fail("hipGraphInstantiate", e); }
-      c->graph_flags = c->flags; c->graph_J = c->fuse_level; c->graph_JB = c->bottom_levels;
+      c->graph_flags = c->flags;
       c->graph_stream = c->stream;
       c->graph_rec_complete = c->rec_complete;  // what the captured sequence leaves behind
     }
@@ -488,7 +470,7 @@ static void launch_rhs_sweep(NdlqrHipCtx* c) {
 
 static bool try_launch_rhs_records(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
-  if (!c->rec_complete || (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_GENERIC)) || c->no_backsub) return false;
+  if (!c->rec_complete || (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_GENERIC))) return false;
   if (d.N < 8 || (size_t)(d.N / 8) * d.n * sizeof(double) > 60 * 1024) return false;
   const SmallInstance* inst = find_small(d);
   if (!inst || (d.K + 4) * inst->nx > 256) return false;
@@ -615,18 +597,6 @@ int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
   return NDLQR_OK;
 }
 
-int ndlqr_hip_set_fuse_level(NdlqrHipCtx* c, int J) {
-  if (!c) return NDLQR_ERR_INVALID;
-  c->fuse_level = J;
-  return NDLQR_OK;
-}
-
-int ndlqr_hip_set_bottom_levels(NdlqrHipCtx* c, int JB) {
-  if (!c || JB < 0) return NDLQR_ERR_INVALID;
-  c->bottom_levels = JB;
-  return NDLQR_OK;
-}
-
 int ndlqr_hip_download_factors(NdlqrHipCtx* c, int p, double* fact) {
   if (!c || !fact || p < 0 || p >= c->d.batch) return NDLQR_ERR_INVALID;
   if (!c->fact_valid) {
@@ -722,6 +692,21 @@ int ndlqr_hip_potrs_lower(int n, int nrhs, const double* L, int ldl, double* B, 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(B, dB.p, bB, hipMemcpyDeviceToHost));
   return NDLQR_OK;
+}
+
+// developer hook (tools/debug_compare.py; not part of include/*.h): raw copy of an internal array,
+// which = 0: separator records [batch][N][2 n^2 + n], 1: accumulator slots of the separator-only schedule
+extern "C" long ndlqr_hip_debug_download(NdlqrHipCtx* c, int which, double* host, long count) {
+  if (!c || !host) return -1;
+  const ndlqr::Dims& d = c->d;
+  const double* src = which == 0 ? c->rec : c->red;
+  const size_t slot_doubles = (4 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
+  const size_t have = which == 0 ? (size_t)d.batch * d.N * (2 * d.n * d.n + d.n) : (size_t)d.batch * (d.N / 4) * slot_doubles;
+  if (!src) return -1;
+  const size_t n = (size_t)count < have ? (size_t)count : have;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  if (hipMemcpy(host, src, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long)n;
 }
 
 #ifdef NDLQR_SEGTIME

@@ -1,8 +1,8 @@
 // small_instance.hip -- one size-specialised instance of the kernels in kernels_small.hpp.
 // Compiled once per line of small_instances.def with -DNDLQR_INST_NX=<nstates>
 // -DNDLQR_INST_NU=<ninputs>; exports the two entry points ndlqr_hip.hip dispatches to:
-//   ndlqr_small_solve_<nx>_<nu>(ctx, strict, keep, J)   factor + solve launch sequence
-//   ndlqr_small_needs_F_<nx>_<nu>(ctx, strict, keep, J)  does that sequence touch the factor array?
+//   ndlqr_small_solve_<nx>_<nu>(ctx, strict, keep)   factor + solve launch sequence
+//   ndlqr_small_needs_F_<nx>_<nu>(ctx, strict, keep)  does that sequence touch the factor array?
 //   ndlqr_small_rhs_<nx>_<nu>(ctx)                      record-based right-hand-side re-solve
 //   ndlqr_small_kpb_<nx>_<nu>()                         knots per workgroup of its Schur kernels
 #include "launch_small.hpp"
@@ -19,14 +19,14 @@ namespace {
 constexpr int NX = NDLQR_INST_NX, NU = NDLQR_INST_NU;
 }
 
-int NDLQR_INST_NAME(ndlqr_small_solve_)(NdlqrHipCtx* c, bool strict, bool keep, int J) {
-  if (strict) return keep ? launch_small<NX, NU, true, true>(c, J) : launch_small<NX, NU, true, false>(c, J);
-  return keep ? launch_small<NX, NU, false, true>(c, J) : launch_small<NX, NU, false, false>(c, J);
+int NDLQR_INST_NAME(ndlqr_small_solve_)(NdlqrHipCtx* c, bool strict, bool keep) {
+  if (strict) return keep ? launch_small<NX, NU, true, true>(c) : launch_small<NX, NU, true, false>(c);
+  return keep ? launch_small<NX, NU, false, true>(c) : launch_small<NX, NU, false, false>(c);
 }
 
-int NDLQR_INST_NAME(ndlqr_small_needs_F_)(const NdlqrHipCtx* c, bool strict, bool keep, int J) {
-  if (strict) return keep ? plan_small<NX, NU, true, true>(c, J).needs_F : plan_small<NX, NU, true, false>(c, J).needs_F;
-  return keep ? plan_small<NX, NU, false, true>(c, J).needs_F : plan_small<NX, NU, false, false>(c, J).needs_F;
+int NDLQR_INST_NAME(ndlqr_small_needs_F_)(const NdlqrHipCtx* c, bool strict, bool keep) {
+  if (strict) return keep ? plan_small<NX, NU, true, true>(c).needs_F : plan_small<NX, NU, true, false>(c).needs_F;
+  return keep ? plan_small<NX, NU, false, true>(c).needs_F : plan_small<NX, NU, false, false>(c).needs_F;
 }
 
 void NDLQR_INST_NAME(ndlqr_small_rhs_)(NdlqrHipCtx* c) { launch_rhs_records<NX, NU>(c); }

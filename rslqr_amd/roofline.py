@@ -66,7 +66,9 @@ def reduced_model(n, m, N, compact_level0=False):
     bottom_b = inputs_doubles(n, m, N) + (N // 2) * rec0 + (N // 4) * rec + (N // 4) * push
     upper_b = nsep_upper * (slot + n * w + w + n + rows + 2 * n + rec + push)
     recs_read = (N // 2) * rec0 + (N // 4) * rec + nsep_upper * rec
-    apply_b = recs_read + inputs_doubles(n, m, N) + N * rows
+    # back-substitution: every record once, the inputs again, the solution; the compact form adds the
+    # multipliers of the top of the tree (written by rb_backsub_top, two read per eight knots)
+    apply_b = recs_read + inputs_doubles(n, m, N) + N * rows + ((N // 8) * n + (N // 8) * 2 * n if compact_level0 else 0)
     out = {
         "bottom": {"bytes": 8 * bottom_b, "flops": (3 * N // 4) * fs, "launches": 1},
         "apply": {"bytes": 8 * apply_b, "flops": backsub_flops(n, m, N), "launches": 1},
@@ -130,10 +132,10 @@ def generic_lean_model(n, m, N):
 def model_for(schedule, n, m, N):
     """Per-slot model of the named launch sequence (ndlqr_hip_schedule), or None when this file has no
     model for it (strict / KEEP schedules stream the whole factor array: model (B) is their roofline)."""
-    if schedule in ("reduced", "reduced-tree"):
-        return reduced_model(n, m, N)
-    if schedule in ("rowbcast", "rowbcast-tree"):
+    if schedule == "reduced":  # compact level-0 records, two-launch back-substitution
         return reduced_model(n, m, N, compact_level0=True)
+    if schedule in ("reduced-tree", "reduced-records"):
+        return reduced_model(n, m, N)
     if schedule == "knot-lean":
         return knot_lean_model(n, m, N)
     if schedule == "generic-lean":

@@ -39,23 +39,14 @@ SHAPES = [(6, 3, 8), (6, 3, 16), (6, 3, 64), (12, 4, 8), (12, 4, 16), (12, 4, 64
 
 
 @pytest.mark.parametrize("n,m,N", SHAPES + [(12, 4, 256), (6, 3, 128)])
-@pytest.mark.parametrize("flags", ["generic", "default", "J2", "J4", "J5", "stream", "B0J3", "B1J2", "B2J2", "B3J3",
-                                   "B3J9"])
+@pytest.mark.parametrize("flags", ["generic", "default"])
 def test_batch_strict_is_bit_exact(ndlqr, oracle, n, m, N, flags):
-    """Strict FP: solution AND complete factor array identical to the oracle, for the generic
-    kernels, the default specialised path and several fuse levels J of the boundary-first path
-    (J = 99: pure level-by-level streaming)."""
+    """Strict FP: solution AND complete factor array identical to the oracle, for the runtime-sized
+    kernels and for the size-specialised knot-based schedule."""
     batch = 3 if N >= 128 else 5
     probs = [synth(ndlqr, n, m, N, 100 + p) for p in range(batch)]
     fl = ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT | (ndlqr.FLAG_GENERIC if flags == "generic" else 0)
     bs = ndlqr.BatchSolver(n, m, N, batch, flags=fl)
-    if flags[0] == "J":
-        bs.set_fuse_level(int(flags[1:]))
-    elif flags[0] == "B":  # bottom levels / fuse level
-        bs.set_bottom_levels(int(flags[1]))
-        bs.set_fuse_level(int(flags[3:]))
-    elif flags == "stream":
-        bs.set_fuse_level(99)
     bs.initialize_flat(*stack(probs))
     assert bs.solve() == 0
     sol = bs.solutions()
@@ -189,26 +180,6 @@ def test_non_spd_block_is_reported(ndlqr):
         bs.close()
 
 
-def test_env_variants_agree(ndlqr, oracle):
-    """The NDLQR_BOTTOM_LEVELS environment knob (A/B timing) does not change strict-mode bits."""
-    import subprocess, sys, json
-    code = (
-        "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import rslqr_amd as R\n"
-        "bs = R.BatchSolver(12, 4, 64, 3, flags=R.FLAG_STRICT_FP); bs.initialize_synthetic(77)\n"
-        "assert bs.solve() == 0; print(json.dumps(bs.solutions().tolist()))\n"
-        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
-    outs = []
-    for env in ({}, {"NDLQR_BOTTOM_LEVELS": "0"}, {"NDLQR_BOTTOM_LEVELS": "1"}, {"NDLQR_BOTTOM_LEVELS": "3"},
-                {"NDLQR_UPPER": "0"}, {"NDLQR_UPPER": "2"}, {"NDLQR_UPPER": "2", "NDLQR_BOTTOM_LEVELS": "1"}):
-        e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
-    for o in outs[1:]:
-        assert np.array_equal(o, outs[0])
-
-
 @pytest.mark.parametrize("n,m,N", [(12, 4, 64), (12, 4, 256), (6, 3, 32), (13, 4, 16), (4, 1, 8), (10, 4, 128)])
 def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
     """NDLQR_FLAG_KEEP_RECORDS: the lean fast-mode solve keeps just the separator records and
@@ -288,19 +259,14 @@ def _solve_in_subprocess(n, m, N, batch, seed, env):
 
 
 def test_env_variants_fast_mode(ndlqr, oracle):
-    """Fast mode has three solution sweeps (back-substitution from the records, finish kernel on the
-    hand-off columns, apply pass), knot-based and separator-only schedules of the bottom and of the
-    upper levels, two separator cores and the tree schedule: each stays within the fast-mode
-    tolerance of the oracle (relative l2 <= 1e-9, here ~1e-15). Two solves per process: the second
-    one runs on what the first left in the accumulators and arrival counters."""
+    """The separator-only schedule has two bottom kernels (row-broadcast core, matrix-core core) and
+    the one-launch tree form for small batches: each stays within the fast-mode tolerance of the
+    oracle (relative l2 <= 1e-9, here ~1e-15). Two solves per process: the second one runs on what
+    the first left in the accumulators."""
     n, m, N, batch, seed = 12, 4, 128, 3, 91
     probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
     ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
-    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_TREE": "0"}, {"NDLQR_MCORE": "0"}, {"NDLQR_BOTTOM_REDUCED": "0"},
-                {"NDLQR_REDUCED": "0"},
-                {"NDLQR_NO_BACKSUB": "1"}, {"NDLQR_NO_BACKSUB": "1", "NDLQR_NO_FINISH": "1"},
-                {"NDLQR_UPPER": "0"}, {"NDLQR_UPPER": "2"}, {"NDLQR_BOTTOM_LEVELS": "1"},
-                {"NDLQR_BOTTOM_LEVELS": "3", "NDLQR_FUSE_LEVEL": "3"}, {"NDLQR_BOTTOM_LEVELS": "0"}):
+    for env in ({}, {"NDLQR_TREE": "1"}, {"NDLQR_TREE": "0"}, {"NDLQR_ROWBCAST": "0", "NDLQR_TREE": "0"}):
         got = _solve_in_subprocess(n, m, N, batch, seed, env)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         assert err <= REL_TOL, (env, err)
@@ -314,7 +280,10 @@ def test_tree_schedule_fills_the_chip(ndlqr, oracle):
     left and reset), every member against the level-per-launch schedule, some against the oracle."""
     n, m, N, batch, seed = 12, 4, 256, 32, 2100
     tree = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "1"})
-    flat = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0"})
+    flat = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0", "NDLQR_ROWBCAST": "0"})
+    rowb = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0"})  # row-broadcast core, same size
+    err = np.linalg.norm(rowb - flat, axis=1) / np.linalg.norm(flat, axis=1)
+    assert err.max() <= REL_TOL, err.max()
     err = np.linalg.norm(tree - flat, axis=1) / np.linalg.norm(flat, axis=1)
     assert err.max() <= REL_TOL, err.max()
     for b in (0, 13, batch - 1):
@@ -353,16 +322,17 @@ def test_dropin_solve_flags(ndlqr, oracle):
         L.ndlqr_FreeNdLqrSolver(solver)
 
 
-@pytest.mark.parametrize("n,m,N,batch", [(6, 3, 64, 5), (13, 4, 32, 3), (9, 3, 8, 4), (8, 4, 256, 2), (10, 4, 16, 1)])
+@pytest.mark.parametrize("n,m,N,batch", [(6, 3, 64, 5), (13, 4, 32, 3), (9, 3, 8, 4), (8, 4, 256, 2), (10, 4, 16, 1),
+                                         (12, 4, 16, 7), (6, 3, 1024, 2), (13, 4, 512, 2)])
 def test_separator_only_schedules_other_shapes(ndlqr, oracle, n, m, N, batch):
-    """The separator-only schedules on the other matrix-core instances (odd row lengths, k-steps
-    with padding, shortest horizon with an upper level): default (bottom_reduced_mc +
-    reduced_level_mc; small batches pick the tree schedule by themselves), one launch per level,
-    the tree schedule and the vector-ALU core against the oracle."""
+    """The separator-only schedules on the other instances (odd row lengths, k-steps with padding,
+    shortest horizon with an upper level): default (small batches pick the tree schedule by
+    themselves), one launch per level with either bottom kernel, and the tree schedule, against the
+    oracle."""
     seed = 500 + n
     probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
     ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
-    for env in ({}, {"NDLQR_TREE": "0"}, {"NDLQR_TREE": "1"}, {"NDLQR_MCORE": "0"}):
+    for env in ({}, {"NDLQR_TREE": "0"}, {"NDLQR_TREE": "1"}, {"NDLQR_ROWBCAST": "0", "NDLQR_TREE": "0"}):
         got = _solve_in_subprocess(n, m, N, batch, seed, env)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         assert err <= REL_TOL, (env, err)

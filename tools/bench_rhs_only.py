@@ -5,10 +5,8 @@ import numpy as np
 import rslqr_amd
 
 n, m, N, batch = 12, 4, 256, 1024
-for name, env, keep in (("records only", {}, rslqr_amd.FLAG_KEEP_RECORDS), ("records", {}, rslqr_amd.FLAG_KEEP_FACT),
-                        ("level sweep", {"NDLQR_NO_BACKSUB": "1"}, rslqr_amd.FLAG_KEEP_FACT)):
-    os.environ.pop("NDLQR_NO_BACKSUB", None)
-    os.environ.update(env)
+for name, keep in (("records only", rslqr_amd.FLAG_KEEP_RECORDS), ("records + factor array", rslqr_amd.FLAG_KEEP_FACT),
+                   ("strict level sweep", rslqr_amd.FLAG_KEEP_FACT | rslqr_amd.FLAG_STRICT_FP)):
     bs = rslqr_amd.BatchSolver(n, m, N, batch, flags=keep)
     bs.initialize_synthetic(1)
     bs.solve()
