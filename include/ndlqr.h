@@ -298,43 +298,6 @@ int ndlqr_UpdateShurFactor(NdData* fact, NdData* soln, int index, int i, int lev
 int ndlqr_ComputeShurCompliment(NdLqrSolver* solver, int index, int level, int upper_level);
 
 /* ================================================================== additive: batch API */
-/* ---------------------------------------------------------------------------------------------
- * Riccati baseline (src/riccati_solver.h:44-178, src/riccati_solve.h:25-49): the reference's
- * serial comparison solver for the same problem, same solution ordering as ndlqr_GetSolution.
- * Here it is composed from the device-backed Matrix helpers below (rslqr_amd/csrc/riccati.c):
- * for the reference's tests and examples, not a throughput path. Field order and the layout of
- * `data` are the reference's (its tests read them directly).
- * ------------------------------------------------------------------------------------------- */
-typedef struct {
-  LQRProblem* prob;
-  int nhorizon, nstates, ninputs, nvars;
-  double* data;  /* P_k p_k K_k d_k per knot | solution [y0 x0 u0 y1 ...] | temporaries x2 */
-  Matrix* K;     /* N-1 feedback gains (m x n) */
-  Matrix* d;     /* N-1 feedforward terms (m) */
-  Matrix* P;     /* N cost-to-go Hessians (n x n) */
-  Matrix* p;     /* N cost-to-go gradients (n) */
-  Matrix* X;     /* N states */
-  Matrix* U;     /* N-1 inputs */
-  Matrix* Y;     /* N multipliers */
-  Matrix* Qx;    /* action-value temporaries, two of each */
-  Matrix* Qu;
-  Matrix* Qxx;
-  Matrix* Qux;
-  Matrix* Quu;
-  double t_solve_ms, t_backward_pass_ms, t_forward_pass_ms;
-} RiccatiSolver;
-
-RiccatiSolver* ndlqr_NewRiccatiSolver(LQRProblem* lqrprob);
-int ndlqr_FreeRiccatiSolver(RiccatiSolver* solver);
-int ndlqr_PrintRiccatiSummary(RiccatiSolver* solver);
-Matrix ndlqr_GetRiccatiSolution(RiccatiSolver* solver);
-int ndlqr_GetNumVarsRiccati(RiccatiSolver* solver);
-int ndlqr_CopyRiccatiSolution(RiccatiSolver* solver, double* soln);
-int ndlqr_GetRiccatiSolveTimes(RiccatiSolver* solver, double* t_solve, double* t_bp, double* t_fp);
-int ndlqr_SolveRiccati(RiccatiSolver* solver);
-int ndlqr_BackwardPass(RiccatiSolver* solver);
-int ndlqr_ForwardPass(RiccatiSolver* solver);
-
 /*
  * A batch of independent LQR problems of identical (nstates, ninputs, nhorizon) solved in one
  * launch sequence on one GPU (SURVEY.md 8b "New, additive"). ndlqr_Solve == batch of 1.

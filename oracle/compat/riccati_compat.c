@@ -1,6 +1,7 @@
 /*
- * riccati.c -- the reference's serial Riccati baseline behind its own API
- * (src/riccati_solver.h:44-178, src/riccati_solve.h:25-49), SURVEY.md 8(f)-4.
+ * riccati_compat.c -- TEST INFRASTRUCTURE (see riccati_compat.h): stand-in for the reference's serial
+ * Riccati comparison solver (src/riccati_solver.h:44-178, src/riccati_solve.h:25-49), linked only into
+ * the reference test programs that call it. Not part of librslqr_amd.so.
  *
  * Not part of the hot path and not a fallback for it: a second, independent solver for the same
  * LQR problem that the reference ships as a comparison (test/sample_problem_test.c prints rsLQR
@@ -19,7 +20,7 @@
 #include <string.h>
 #include <time.h>
 
-#include "ndlqr.h"
+#include "riccati_compat.h"
 
 static Matrix carve(double* base, size_t* cursor, int rows, int cols) {
   Matrix m = {rows, cols, base + *cursor};
