@@ -33,8 +33,8 @@ namespace ndlqr {
 // column -- the whole workgroup works on every pivot, no integer division in the loops. Every
 // element receives its updates in the reference's order (k resp. j ascending; descending in the
 // transposed sweep), so the results equal the left-looking / column-by-column reference loops.
-// P1MFMA (fast mode, n a multiple of 16, n+m of 4): the inner products run on
-// v_mfma_f64_16x16x4_f64, one 16x16 tile of S-bar / f_a per wavefront.
+// (Fast mode with n a multiple of 16 and n+m of 4 runs separator_mfma of kernels_mfma.hpp instead: the
+// same separator on v_mfma_f64_16x16x4_f64, blocked by 16 columns.)
 // Fast path of the blocked separator: lower Cholesky of one 16x16 diagonal block AND the inverse
 // of that factor by ONE wavefront in registers (lanes 0..15 own a row, then a column; broadcasts
 // with v_readlane, no barrier). With W = L11^-1 the panel below the block, the block rows of the
@@ -85,7 +85,7 @@ __device__ __forceinline__ bool chol16_and_inverse(double* Sblk, const int ns, d
   return bad;
 }
 
-template <bool STRICT, bool P1MFMA>
+template <bool STRICT>
 __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, double* F, double* z,
                                   int* __restrict__ info, double* __restrict__ rec) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -95,8 +95,7 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   int a, bb;
   outer_columns(base, l, N, a, bb);
   const int ns = n + 1, ncols = 2 * n + 1;
-  // MFMA path: the panel is padded to whole 16-column tiles (zeroed), +1 keeps the pitch odd
-  const int xs = P1MFMA ? ((ncols + 15) / 16) * 16 + 1 : ncols;
+  const int xs = ncols;
   double* S = sm;
   double* X = S + n * ns;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -112,76 +111,18 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
 
   // ---- P1: inner products. Row i of A_s, B_s against the state / input rows of knot s,
   //      minus the state rows of knot s+1 (its coupling block is [-I; 0]).
-  typedef double acc4 __attribute__((ext_vector_type(4)));
-  const int li = lane & 15, lk = lane >> 4;
-  if constexpr (P1MFMA) {
-    const int tiles = n / 16, ksteps = w / 4;
-    for (int item = wave; item < 2 * tiles * tiles; item += nwave) {
-      const int mat = item / (tiles * tiles), rt = (item / tiles) % tiles, ct = item % tiles;
-      const double* Bsrc = (mat == 0 ? Es : Fas) + (size_t)n * n;  // rows n.. of the block
-      const double* Arow = ab + (size_t)(16 * rt + li) * w + lk;
-      const double* Bcol = Bsrc + (size_t)lk * n + 16 * ct + li;
-      acc4 acc = {0.0, 0.0, 0.0, 0.0};
-      // operand fragments of ten k-steps at a time, all requested before the first product (one
-      // load pair + wait + product per trip costs a memory round trip per k-step)
-      constexpr int CH = 10;
-      for (int q0 = 0; q0 < ksteps; q0 += CH) {
-        double af[CH], bf[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int q = q0 + c < ksteps ? q0 + c : ksteps - 1;
-          af[c] = Arow[4 * q];
-          bf[c] = Bcol[(size_t)4 * q * n];
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c)  // surplus steps of the last chunk multiply by zero
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(q0 + c < ksteps ? af[c] : 0.0, bf[c], acc, 0, 0, 0);
-      }
-      if (mat == 0) {
-        double* dst = S + (16 * rt + lk) * ns + 16 * ct + li;
-        const double* e1 = Es1 + (size_t)(n + 16 * rt + lk) * n + 16 * ct + li;
-        double ev[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ev[g] = e1[4 * g * n];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dst[4 * g * ns] = acc[g] - ev[g];
-      } else {
-        double* dst = X + (16 * rt + lk) * xs + 16 * ct + li;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dst[4 * g * xs] = acc[g];
-      }
-    }
-    for (int i0 = wave; i0 < n; i0 += 4 * nwave) {  // four rows per trip, their loads first
-      for (int c = lane; c < n; c += 64) {
-        double t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * nwave < n ? i0 + u * nwave : i0;
-          t[u] = Fbs1[(size_t)(n + i) * n + c];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * nwave < n ? i0 + u * nwave : i0;
-          X[i * xs + n + c] = -t[u];
-        }
-      }
-    }
-    for (int i = wave; i < n; i += nwave)
-      for (int c = ncols + lane; c < xs; c += 64) X[i * xs + c] = 0.0;  // tile padding
-  } else {
-    for (int i = wave; i < n; i += nwave) {
-      const double* arow = ab + i * w;
-      for (int j = lane; j < n; j += 64) {
-        double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc = mad<STRICT>(arow[k], Es[(n + k) * n + j], acc);
-        for (int k = 0; k < m; ++k) acc = mad<STRICT>(arow[n + k], Es[(2 * n + k) * n + j], acc);
-        S[i * ns + j] = acc - Es1[(n + i) * n + j];
-        double acc2 = 0.0;
-        for (int k = 0; k < n; ++k) acc2 = mad<STRICT>(arow[k], Fas[(n + k) * n + j], acc2);
-        for (int k = 0; k < m; ++k) acc2 = mad<STRICT>(arow[n + k], Fas[(2 * n + k) * n + j], acc2);
-        X[i * xs + j] = acc2;
-        X[i * xs + n + j] = -Fbs1[(n + i) * n + j];
-      }
+  for (int i = wave; i < n; i += nwave) {
+    const double* arow = ab + i * w;
+    for (int j = lane; j < n; j += 64) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc = mad<STRICT>(arow[k], Es[(n + k) * n + j], acc);
+      for (int k = 0; k < m; ++k) acc = mad<STRICT>(arow[n + k], Es[(2 * n + k) * n + j], acc);
+      S[i * ns + j] = acc - Es1[(n + i) * n + j];
+      double acc2 = 0.0;
+      for (int k = 0; k < n; ++k) acc2 = mad<STRICT>(arow[k], Fas[(n + k) * n + j], acc2);
+      for (int k = 0; k < m; ++k) acc2 = mad<STRICT>(arow[n + k], Fas[(2 * n + k) * n + j], acc2);
+      X[i * xs + j] = acc2;
+      X[i * xs + n + j] = -Fbs1[(n + i) * n + j];
     }
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -210,103 +151,6 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
 
   // ---- P2: lower Cholesky in LDS, right-looking: finish column j, then subtract its outer
   //      product from the remaining lower triangle (wavefront per column c, lane per row i >= c).
-  //      MFMA path: blocked by 16 columns -- the rank-1 updates of a pivot only reach the end of
-  //      its 16-column panel, the rest of the lower triangle gets one rank-16 update per panel on
-  //      the matrix cores (different summation grouping than the reference: fast mode only).
-  if constexpr (P1MFMA) {
-    // blocked: diagonal block + its inverse in one wavefront, panel and trailing update on the
-    // matrix cores (see chol16_and_inverse)
-    double* Wd = X + (size_t)n * xs;  // n/16 blocks of 16 x 17
-    const int nb = n >> 4;
-    for (int jb = 0; jb < nb; ++jb) {
-      const int j0 = 16 * jb, rem = nb - 1 - jb;
-      if (wave == 0) {
-        const bool bad = chol16_and_inverse(S + j0 * ns + j0, ns, Wd + jb * 16 * 17, lane);
-        if (bad && lane == 0) flag_failure(info, d, b);
-      }
-      __syncthreads();
-      const double* Wb = Wd + jb * 16 * 17;
-      for (int it = jb + 1 + wave; it < nb; it += nwave) {  // L21 = A21 W'
-        acc4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                     Wb[li * 17 + 4 * q + lk], acc, 0, 0, 0);
-        double* Ct = S + (16 * it + lk) * ns + j0 + li;
-        Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
-      }
-      __syncthreads();
-      for (int item = wave; item < rem * rem; item += nwave) {  // trailing rank-16 update
-        const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
-        if (ct > it) continue;  // lower triangle of tiles only
-        double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
-        acc4 acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                     S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
-      }
-      if (rem > 0) __syncthreads();
-    }
-    SEG(42);
-    // substitutions, block rows at a time: X_blk <- W X_blk, rows below -= L[rows, blk] X_blk;
-    // then X_blk <- W' X_blk, rows above -= L[blk, rows]' X_blk
-    const int ctl = (ncols + 15) / 16;
-    for (int jb = 0; jb < nb; ++jb) {
-      const int j0 = 16 * jb;
-      const double* Wb = Wd + jb * 16 * 17;
-      for (int ct = wave; ct < ctl; ct += nwave) {
-        acc4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[li * 17 + 4 * q + lk],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
-      }
-      __syncthreads();
-      const int rem = nb - 1 - jb;
-      for (int item = wave; item < rem * ctl; item += nwave) {
-        const int it = jb + 1 + item / ctl, ct = item % ctl;
-        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
-      }
-      if (rem > 0) __syncthreads();
-    }
-    for (int jb = nb - 1; jb >= 0; --jb) {
-      const int j0 = 16 * jb;
-      const double* Wb = Wd + jb * 16 * 17;
-      for (int ct = wave; ct < ctl; ct += nwave) {
-        acc4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[(4 * q + lk) * 17 + li],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
-      }
-      __syncthreads();
-      for (int item = wave; item < jb * ctl; item += nwave) {
-        const int it = item / ctl, ct = item % ctl;
-        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(j0 + 4 * q + lk) * ns + 16 * it + li],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
-      }
-      if (jb > 0) __syncthreads();
-    }
-    __syncthreads();
-    SEG(43);
-  } else {
   for (int j = 0; j < n; ++j) {
     const double pivot = S[j * ns + j];
     if (!(pivot > 0.0)) {  // uniform: every thread reads the same LDS word
@@ -317,28 +161,11 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
     __syncthreads();
     for (int i = j + threadIdx.x; i < n; i += blockDim.x) S[i * ns + j] /= root;
     __syncthreads();
-    const int cend = P1MFMA ? ((j >> 4) + 1) << 4 : n;  // columns this pivot updates directly
-    for (int c = j + 1 + wave; c < cend; c += nwave) {
+    for (int c = j + 1 + wave; c < n; c += nwave) {
       const double lcj = S[c * ns + j];
       for (int i = c + lane; i < n; i += 64) S[i * ns + c] = mad<STRICT>(-S[i * ns + j], lcj, S[i * ns + c]);
     }
     __syncthreads();
-    if (P1MFMA && (j & 15) == 15 && j + 1 < n) {
-      // rank-16 update of the trailing lower triangle with the finished panel [j0, j0+16)
-      const int j0 = j - 15, jb = j >> 4, nb = n >> 4, rem = nb - 1 - jb;
-      for (int item = wave; item < rem * rem; item += nwave) {
-        const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
-        if (ct > it) continue;  // lower triangle of tiles only
-        double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
-        acc4 acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                     S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
-      }
-      __syncthreads();
-    }
   }
 
   // ---- P3: L Y = X (forward), then L' X = Y (transposed), all 2n+1 columns at once.
@@ -373,12 +200,11 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       }
     }
   };
-  const int ctiles = (ncols + 15) / 16;
   for (int j = 0; j < n; ++j) {
     const double piv = S[j * ns + j];
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
     __syncthreads();
-    const int iend = P1MFMA ? ((j >> 4) + 1) << 4 : n;  // MFMA path: rank-1 updates stay in the block
+    const int iend = n;
     if (ncols <= 64 * CH) {
       sweep_rows(j, j + 1, iend, false);
     } else {
@@ -388,27 +214,12 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       }
     }
     __syncthreads();
-    if (P1MFMA && (j & 15) == 15 && j + 1 < n) {
-      // rows below the block: X[it] -= L[it, block] * X[block]   (rank-16 update, matrix cores)
-      const int j0 = j - 15, jb = j >> 4, nb = n >> 4, rem = nb - 1 - jb;
-      for (int item = wave; item < rem * ctiles; item += nwave) {
-        const int it = jb + 1 + item / ctiles, ct = item % ctiles;
-        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
-      }
-      __syncthreads();
-    }
   }
   for (int j = n - 1; j >= 0; --j) {
     const double piv = S[j * ns + j];
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) X[j * xs + c] = X[j * xs + c] / piv;
     __syncthreads();
-    const int ibeg = P1MFMA ? (j >> 4) << 4 : 0;
+    const int ibeg = 0;
     if (ncols <= 64 * CH) {
       sweep_rows(j, ibeg, j, true);
     } else {
@@ -418,24 +229,8 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
       }
     }
     __syncthreads();
-    if (P1MFMA && (j & 15) == 0 && j > 0) {
-      // rows above the block: X[it] -= L[block, it]' * X[block]
-      const int j0 = j, jb = j >> 4;
-      for (int item = wave; item < jb * ctiles; item += nwave) {
-        const int it = item / ctiles, ct = item % ctiles;
-        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-        acc4 acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(j0 + 4 * q + lk) * ns + 16 * it + li],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
-      }
-      __syncthreads();
-    }
   }
 
-  }  // per-pivot path
 
   // ---- store into the lambda rows of knot s+1 (columns l, a, bb) and of the rhs
   // With records (fast mode without KEEP: boundary-first schedule, solution by back-substitution)

@@ -1,4 +1,4 @@
-// kernels_mfma.hpp -- large-block Schur update on the fp64 matrix cores (gfx950).
+// kernels_mfma.hpp -- large-block separator and Schur update on the fp64 matrix cores (gfx950).
 //
 // For block sizes that fill MFMA tiles (nstates a multiple of 16, 2*nstates + ninputs a multiple
 // of 16 -- e.g. the (64,16) shape of BASELINE.json config 5) the Schur update
@@ -11,11 +11,250 @@
 // A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], and C/D[row = (l >> 4) + 4 * reg][col = l & 15].
 #pragma once
 #include "kernels_common.hpp"
+#include "kernels_generic.hpp"  // chol16_and_inverse
 
 namespace ndlqr {
 
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 
+// ------------------------------------------------------------------------------------- separator
+// The separator of separator_generic (ndlqr_FactorInnerProduct nested_dissection.c:114-134, the
+// Cholesky of src/solve.c:87-98, ndlqr_SolveCholeskyFactor :136-152) for blocks that fill 16x16
+// tiles (n a multiple of 16, n + m of 4), fast mode: inner products, a Cholesky blocked by 16
+// columns (diagonal block + its inverse by one wavefront, chol16_and_inverse; panel and trailing
+// updates as rank-16 products) and both blocked substitutions on v_mfma_f64_16x16x4_f64.
+// The 2n + 1 right-hand-side columns [f_a | f_bb | z_sep] go through LDS in chunks of CT column
+// tiles: S-bar / L (n x (n + 1)), ONE chunk (n x (16 CT + 1)) and the inverses of the diagonal
+// blocks are resident -- 67 KB at n = 64 instead of 116 KB for the whole panel, so that two
+// workgroups share a CU and the barriers of one overlap with the products of the other.
+//   grid (N >> (l+1), batch), block 64 * nwave, dynamic LDS = n (n + 1) + n (16 min(CT, ctl) + 1) + 17 n doubles.
+template <int CT>
+__global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, double* F, double* z,
+                               int* __restrict__ info, double* __restrict__ rec) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = d.n, w = d.w, N = d.N;
+  const int b = blockIdx.y;
+  const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
+  int a, bb;
+  outer_columns(base, l, N, a, bb);
+  const int ns = n + 1, tiles = n >> 4, ctl = 2 * tiles + 1;  // column tiles: f_a, f_bb, [z_sep | padding]
+  const int ctc = ctl < CT ? ctl : CT, xs = 16 * ctc + 1;
+  double* S = sm;
+  double* X = S + n * ns;
+  double* Wd = X + (size_t)n * xs;  // n / 16 blocks of 16 x 17: inverses of the diagonal blocks of L
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+
+  const double* ab = AB + ((size_t)b * N + s) * n * w;
+  const double* Es = Fblk(F, d, b, l, s);
+  const double* Es1 = Fblk(F, d, b, l, s + 1);
+  const double* Fas = a >= 0 ? Fblk(F, d, b, a, s) : Es;
+  const double* Fbs1 = bb >= 0 ? Fblk(F, d, b, bb, s + 1) : Es1;
+  const double* zsl = z + ((size_t)b * N + s) * d.rows;
+  double* zs1 = z + ((size_t)b * N + s + 1) * d.rows;
+  const int ksteps = w / 4;
+
+  // 16x16 tile (rt, ct) of [A_s | B_s] * (state + input rows of a factor block): operand fragments of ten
+  // k-steps at a time, all requested before the first product
+  auto product_tile = [&](const double* Bsrc, const int rt, const int ct) -> mfma_acc_t {
+    const double* Arow = ab + (size_t)(16 * rt + li) * w + lk;
+    const double* Bcol = Bsrc + (size_t)n * n + (size_t)lk * n + 16 * ct + li;  // rows n.. of the block
+    mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+    constexpr int CH = 10;
+    for (int q0 = 0; q0 < ksteps; q0 += CH) {
+      double af[CH], bf[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = q0 + c < ksteps ? q0 + c : ksteps - 1;
+        af[c] = Arow[4 * q];
+        bf[c] = Bcol[(size_t)4 * q * n];
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)  // surplus steps of the last chunk multiply by zero
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(q0 + c < ksteps ? af[c] : 0.0, bf[c], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+
+  // ---- S-bar = [A_s | B_s] E(s).xu - E(s+1).x
+  for (int item = wave; item < tiles * tiles; item += nwave) {
+    const int rt = item / tiles, ct = item % tiles;
+    const mfma_acc_t acc = product_tile(Es, rt, ct);
+    double* dst = S + (16 * rt + lk) * ns + 16 * ct + li;
+    const double* e1 = Es1 + (size_t)(n + 16 * rt + lk) * n + 16 * ct + li;
+    double ev[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ev[g] = e1[4 * g * n];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dst[4 * g * ns] = acc[g] - ev[g];
+  }
+  __syncthreads();
+
+  // ---- blocked Cholesky (different summation grouping than the reference: fast mode only)
+  for (int jb = 0; jb < tiles; ++jb) {
+    const int j0 = 16 * jb, rem = tiles - 1 - jb;
+    if (wave == 0) {
+      const bool bad = chol16_and_inverse(S + j0 * ns + j0, ns, Wd + jb * 16 * 17, lane);
+      if (bad && lane == 0) flag_failure(info, d, b);
+    }
+    __syncthreads();
+    const double* Wb = Wd + jb * 16 * 17;
+    for (int it = jb + 1 + wave; it < tiles; it += nwave) {  // L21 = A21 W'
+      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * it + li) * ns + j0 + 4 * q + lk], Wb[li * 17 + 4 * q + lk], acc,
+                                                   0, 0, 0);
+      double* Ct = S + (16 * it + lk) * ns + j0 + li;
+      Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+    }
+    __syncthreads();
+    for (int item = wave; item < rem * rem; item += nwave) {  // trailing rank-16 update
+      const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
+      if (ct > it) continue;  // lower triangle of tiles only
+      double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
+      mfma_acc_t acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                   S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
+      Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+    }
+    if (rem > 0) __syncthreads();
+  }
+
+  // ---- the panel, CT column tiles at a time: build, substitute, store
+  double* outS = rec ? nullptr : Fblk(F, d, b, l, s + 1);
+  double* outa = (!rec && a >= 0) ? Fblk(F, d, b, a, s + 1) : nullptr;
+  double* outb = (!rec && bb >= 0) ? Fblk(F, d, b, bb, s + 1) : nullptr;
+  double* myrec = rec ? rec + ((size_t)b * d.N + s) * (2 * n * n + n) : nullptr;
+  if (outS) {  // the Cholesky factor goes to the lambda rows of knot s+1, column l (KEEP)
+    for (int i = wave; i < n; i += nwave)
+      for (int c = lane; c < n; c += 64) outS[i * n + c] = S[i * ns + c];
+  }
+  for (int t0 = 0; t0 < ctl; t0 += ctc) {
+    const int tc = ctl - t0 < ctc ? ctl - t0 : ctc;
+    // build the chunk's tiles: f_a = [A_s | B_s] Fa(s).xu, f_bb = -Fbb(s+1).x, z column = [A_s | B_s] z(s).xu - z(s+1)
+    for (int item = wave; item < tiles * tc; item += nwave) {
+      const int rt = item / tc, t = item % tc, gt = t0 + t;
+      double* dst = X + (16 * rt + lk) * xs + 16 * t + li;
+      if (gt < tiles) {
+        const mfma_acc_t acc = product_tile(Fas, rt, gt);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[4 * g * xs] = acc[g];
+      } else if (gt < 2 * tiles) {
+        const double* src = Fbs1 + (size_t)(n + 16 * rt + lk) * n + 16 * (gt - tiles) + li;
+        double tv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tv[g] = src[4 * g * n];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[4 * g * xs] = -tv[g];
+      } else {  // [z | padding] tile: the padding columns (column 0 is written below)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (li != 0) dst[4 * g * xs] = 0.0;
+      }
+    }
+    if (t0 + tc == ctl) {  // this chunk holds the right-hand-side column: [A_s | B_s] z(s).xu - z(s+1).lambda - z(s+1).x
+      const int zc = 16 * (ctl - 1 - t0);
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double* arow = ab + (size_t)i * w;
+        double acc = -zs1[i];  // beta = -1 on the old lambda entry (nested_dissection.c:125)
+        const double zlast = zs1[n + i];
+        for (int k0 = 0; k0 < w; k0 += 16) {  // operands fetched sixteen pairs at a time
+          double av[16], zv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int k = k0 + u < w ? k0 + u : w - 1;
+            av[u] = arow[k];
+            zv[u] = zsl[n + k];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (k0 + u < w) acc = fma(av[u], zv[u], acc);
+        }
+        X[i * xs + zc] = acc - zlast;
+      }
+    }
+    __syncthreads();
+    // forward: X_blk <- W X_blk, rows below -= L[rows, blk] X_blk; backward with the transposes
+    for (int jb = 0; jb < tiles; ++jb) {
+      const int j0 = 16 * jb;
+      const double* Wb = Wd + jb * 16 * 17;
+      for (int ct = wave; ct < tc; ct += nwave) {
+        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[li * 17 + 4 * q + lk], X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc,
+                                                     0, 0, 0);
+        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      __syncthreads();
+      const int rem = tiles - 1 - jb;
+      for (int item = wave; item < rem * tc; item += nwave) {
+        const int it = jb + 1 + item / tc, ct = item % tc;
+        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+        mfma_acc_t acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      if (rem > 0) __syncthreads();
+    }
+    for (int jb = tiles - 1; jb >= 0; --jb) {
+      const int j0 = 16 * jb;
+      const double* Wb = Wd + jb * 16 * 17;
+      for (int ct = wave; ct < tc; ct += nwave) {
+        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[(4 * q + lk) * 17 + li], X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc,
+                                                     0, 0, 0);
+        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      __syncthreads();
+      for (int item = wave; item < jb * tc; item += nwave) {
+        const int it = item / tc, ct = item % tc;
+        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+        mfma_acc_t acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(j0 + 4 * q + lk) * ns + 16 * it + li],
+                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
+        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      }
+      __syncthreads();
+    }
+    // stores of the chunk. With records (fast mode without KEEP) the lambda rows of the factor array
+    // are dead data (the boundary Schur pass takes f_a, f_bb from the record): only the record and the
+    // rhs entry are written.
+    for (int i = wave; i < n; i += nwave) {
+      for (int cc = lane; cc < 16 * tc; cc += 64) {
+        const int gt = t0 + (cc >> 4), cl = cc & 15;
+        const double v = X[i * xs + cc];
+        if (gt < tiles) {
+          const int c = 16 * gt + cl;
+          if (myrec) { if (a >= 0) myrec[i * n + c] = v; }
+          else if (outa) outa[i * n + c] = v;
+        } else if (gt < 2 * tiles) {
+          const int c = 16 * (gt - tiles) + cl;
+          if (myrec) { if (bb >= 0) myrec[n * n + i * n + c] = v; }
+          else if (outb) outb[i * n + c] = v;
+        } else if (cl == 0) {
+          zs1[i] = v;
+          if (myrec) myrec[2 * n * n + i] = v;
+        }
+      }
+    }
+    __syncthreads();  // the next chunk overwrites the panel
+  }
+}
+
+// ------------------------------------------------------------------------------------- Schur update
 // One workgroup (4 wavefronts) per knot; row tiles of 16 rows are dealt to the wavefronts.
 //   NB = nstates / 16. grid (N, batch) -- or (2 * (N >> (l+1)), batch) in boundary mode --, block 256,
 //   dynamic LDS = n * (n + 16) doubles.

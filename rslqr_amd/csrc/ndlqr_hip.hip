@@ -221,6 +221,8 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
 
 // lean (fast mode without KEEP): the Schur passes only keep the boundary knots of every subtree
 // up to date, the solution comes from the back-substitution over the separator records.
+constexpr int kSepChunkTiles = 3;  // column tiles of the right-hand-side panel resident in LDS (separator_mfma)
+
 template <bool STRICT>
 static int launch_generic(NdlqrHipCtx* c, bool lean) {
   const ndlqr::Dims& d = c->d;
@@ -231,27 +233,28 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
     hipLaunchKernelGGL((ndlqr::leaf_generic<STRICT>), dim3(d.N, d.batch), dim3(128), 0, c->stream, d,
                        c->AB, c->QR, c->rhs, c->F, c->z, c->info, lean ? 1 : 0);
   }
-  // S (n x (n+1)) + right-hand-side panel (n x pitch; pitch = 2n+1 padded to whole 16-column tiles + 1)
-  // (+ on the matrix-core path the inverses of the 16x16 diagonal blocks of the factor, pitch 17)
-  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (((2 * d.n + 1 + 15) / 16) * 16 + 1) +
-                                       (size_t)d.n * 17);
+  // S (n x (n+1)) + right-hand-side panel (n x (2n+1)); on the matrix-core path the panel goes through
+  // LDS in chunks of kSepChunkTiles column tiles (+ the inverses of the 16x16 diagonal blocks, pitch 17)
+  const bool p1mfma = !STRICT && d.n % 16 == 0 && d.w % 4 == 0 && !c->no_mfma;
+  const int ctl = 2 * (d.n / 16) + 1, ctc = ctl < kSepChunkTiles ? ctl : kSepChunkTiles;
+  const size_t lds = p1mfma ? sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (16 * ctc + 1) + (size_t)d.n * 17)
+                            : sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (2 * d.n + 1));
   if (lds > 160 * 1024) {
-    g_last_error = "nstates too large for the generic separator kernel's LDS staging";
+    g_last_error = "nstates too large for the separator kernel's LDS staging";
     return NDLQR_ERR_INVALID;
   }
-  // matrix-core separator: one wavefront per 16x16 tile of the products / updates, so the number of
-  // useful wavefronts grows with (n/16)^2 (measured at n = 64: 256 / 512 / 1024 threads -> 14.6 / 11.5 / 9.9 ms)
-  const int sep_threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 64 ? 1024 : (d.n >= 32 ? 512 : 256));
+  // matrix-core separator: one wavefront per 16x16 tile of the products / updates; 512 threads let two
+  // workgroups (67 KB of LDS each at n = 64) share a CU
+  const int sep_threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 32 ? 512 : 256);
   for (int l = 0; l < d.K; ++l) {
     const int nsub = d.N >> (l + 1);
     {
       ScopedSlot t(c, SLOT_SEP);
-      const bool p1mfma = !STRICT && d.n % 16 == 0 && d.w % 4 == 0 && !c->no_mfma;
       if (p1mfma)
-        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, true>), dim3(nsub, d.batch), dim3(sep_threads), lds,
+        hipLaunchKernelGGL((ndlqr::separator_mfma<kSepChunkTiles>), dim3(nsub, d.batch), dim3(sep_threads), lds,
                            c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
       else
-        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT, false>), dim3(nsub, d.batch), dim3(256), lds,
+        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT>), dim3(nsub, d.batch), dim3(256), lds,
                            c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
     }
     if (lean && l == d.K - 1) break;  // nothing above the root separator
