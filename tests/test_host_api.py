@@ -206,3 +206,10 @@ def test_solver_fails_loudly_without_a_device(ndlqr, L):
     assert L.ndlqr_hip_potrf_lower(3, p, 3) == -2  # dense helpers have no CPU fallback either
     L.ndlqr_FreeLQRProblem(prob)
     L.ndlqr_FreeNdLqrSolver(solver)
+
+
+def test_batch_limit_is_reported(ndlqr, L):
+    """The batch index rides on gridDim.y: more than 65 535 problems per solver are refused up front
+    with a clear message (not at the first launch, and not as 'no device')."""
+    assert not L.ndlqr_NewBatchSolver(4, 1, 8, 70000, -1)
+    assert b"65535" in L.ndlqr_hip_last_error()

@@ -61,6 +61,8 @@ def test_reference_device_programs_link(built):
         pytest.skip("reference absent")
     for name in DEVICE + ["sample_problem"]:
         assert os.access(os.path.join(BIN, name + "_test"), os.X_OK), name
+    for name in ("importexample", "installexample"):  # the reference's example callers
+        assert os.access(os.path.join(BIN, name + "_example"), os.X_OK), name
 
 
 @pytest.mark.gpu
@@ -70,6 +72,21 @@ def test_reference_program_on_gpu(name):
     if name == "nested_dissection":
         # the program prints its own final-solution error against lqr_prob.json's soln
         assert "Accuracy of final solution" in text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["importexample", "installexample"])
+def test_reference_example_program(name):
+    """examples/*/main.c of the reference -- read a problem, New / Initialize / Solve / PrintSolveSummary /
+    Free -- compiled unchanged against include/ and run against the drop-in."""
+    exe = os.path.join(BIN, name + "_example")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tests not built (needs /root/reference at build time)")
+    out = subprocess.run([exe], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert "rsLQR package" in text
+    assert "rsLQR Solve Summary" in text and "Device solve time" in text, text[-2000:]
 
 
 @pytest.mark.gpu
