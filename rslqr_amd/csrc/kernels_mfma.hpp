@@ -22,7 +22,7 @@ typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 // Cholesky of src/solve.c:87-98, ndlqr_SolveCholeskyFactor :136-152) for blocks that fill 16x16
 // tiles (n a multiple of 16, n + m of 4), fast mode: inner products, a Cholesky blocked by 16
 // columns (diagonal block + its inverse by one wavefront, chol16_and_inverse; panel and trailing
-// updates as rank-16 products) and both blocked substitutions on v_mfma_f64_16x16x4_f64.
+// updates as rank-16 products), the blocked inverse W = L^-1 and X = W'(W R) on v_mfma_f64_16x16x4_f64.
 // The 2n + 1 right-hand-side columns [f_a | f_bb | z_sep] go through LDS in chunks of CT column
 // tiles: S-bar / L (n x (n + 1)), ONE chunk (n x (16 CT + 1)) and the inverses of the diagonal
 // blocks are resident -- 67 KB at n = 64 instead of 116 KB for the whole panel, so that two
@@ -123,7 +123,6 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
     if (rem > 0) __syncthreads();
   }
 
-  // ---- the panel, CT column tiles at a time: build, substitute, store
   double* outS = rec ? nullptr : Fblk(F, d, b, l, s + 1);
   double* outa = (!rec && a >= 0) ? Fblk(F, d, b, a, s + 1) : nullptr;
   double* outb = (!rec && bb >= 0) ? Fblk(F, d, b, bb, s + 1) : nullptr;
@@ -131,7 +130,48 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
   if (outS) {  // the Cholesky factor goes to the lambda rows of knot s+1, column l (KEEP)
     for (int i = wave; i < n; i += nwave)
       for (int c = lane; c < n; c += 64) outS[i * n + c] = S[i * ns + c];
+    __syncthreads();
   }
+
+  // ---- W = L^-1, in place over the strictly lower blocks of L (diagonal blocks: Wd), block row by block
+  //      row: T_ij = sum_{k = j}^{i-1} L_ik W_kj,  W_ij = -W_ii T_ij  (j < i). With W the two triangular
+  //      sweeps of every panel chunk become two GEMMs whose tiles are all independent: 4 workgroup
+  //      barriers per chunk instead of 16 (the sweeps made this kernel barrier-bound: eight wavefronts
+  //      share 3..12 tiles per step).
+  for (int ib = 1; ib < tiles; ++ib) {
+    mfma_acc_t wij = {0.0, 0.0, 0.0, 0.0};
+    const int jb = wave;  // one tile of the block row per wavefront (host: nwave >= n / 16)
+    if (jb < ib) {
+      mfma_acc_t t = {0.0, 0.0, 0.0, 0.0};
+      for (int kb = jb; kb < ib; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double wkj = kb == jb ? Wd[jb * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * jb + li];
+          t = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * ib + li) * ns + 16 * kb + 4 * q + lk], wkj, t, 0, 0, 0);
+        }
+      }
+      // component q of an accumulator is element (4 q + lk, li): exactly the B operand of k-step q
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        wij = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[ib * 16 * 17 + li * 17 + 4 * q + lk], t[q], wij, 0, 0, 0);
+    }
+    __syncthreads();  // every L_ik of the block row has been read
+    if (jb < ib) {
+      double* Ct = S + (16 * ib + lk) * ns + 16 * jb + li;
+      Ct[0] = wij[0]; Ct[4 * ns] = wij[1]; Ct[8 * ns] = wij[2]; Ct[12 * ns] = wij[3];
+    }
+    __syncthreads();
+  }
+  // block (it, kb) of W as A operand (row li, k = 4 q + lk) and of W' (row li of W' = column of W)
+  auto w_frag = [&](const int it, const int kb, const int q) -> double {
+    return kb == it ? Wd[it * 16 * 17 + li * 17 + 4 * q + lk] : S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
+  };
+  auto wt_frag = [&](const int it, const int kb, const int q) -> double {  // W'(16 it + li, 16 kb + 4 q + lk)
+    return kb == it ? Wd[it * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
+  };
+  constexpr int MAXI = 3;  // panel tiles a wavefront may own: tiles * CT <= MAXI * nwave (checked on the host)
+
+  // ---- the panel, CT column tiles at a time: build, X = W' (W R), store
   for (int t0 = 0; t0 < ctl; t0 += ctc) {
     const int tc = ctl - t0 < ctc ? ctl - t0 : ctc;
     // build the chunk's tiles: f_a = [A_s | B_s] Fa(s).xu, f_bb = -Fbb(s+1).x, z column = [A_s | B_s] z(s).xu - z(s+1)
@@ -177,55 +217,61 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
       }
     }
     __syncthreads();
-    // forward: X_blk <- W X_blk, rows below -= L[rows, blk] X_blk; backward with the transposes
-    for (int jb = 0; jb < tiles; ++jb) {
-      const int j0 = 16 * jb;
-      const double* Wb = Wd + jb * 16 * 17;
-      for (int ct = wave; ct < tc; ct += nwave) {
-        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+    // Y = W R (block lower triangular), then X = W' Y: every tile of a product is independent; the
+    // wavefronts keep theirs in the accumulators across the barrier that separates reading from
+    // overwriting the panel
+    {
+      mfma_acc_t accs[MAXI];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[li * 17 + 4 * q + lk], X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc,
-                                                     0, 0, 0);
-        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      for (int idx = 0; idx < MAXI; ++idx) {
+        const int item = wave + idx * nwave;
+        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (item < tiles * tc) {
+          const int it = item / tc, ct = item % tc;
+          for (int kb = 0; kb <= it; ++kb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
+                                                         0, 0, 0);
+          }
+        }
+        accs[idx] = acc;
       }
       __syncthreads();
-      const int rem = tiles - 1 - jb;
-      for (int item = wave; item < rem * tc; item += nwave) {
-        const int it = jb + 1 + item / tc, ct = item % tc;
-        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-        mfma_acc_t acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
-      }
-      if (rem > 0) __syncthreads();
-    }
-    for (int jb = tiles - 1; jb >= 0; --jb) {
-      const int j0 = 16 * jb;
-      const double* Wb = Wd + jb * 16 * 17;
-      for (int ct = wave; ct < tc; ct += nwave) {
-        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wb[(4 * q + lk) * 17 + li], X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc,
-                                                     0, 0, 0);
-        double* Ct = X + (j0 + lk) * xs + 16 * ct + li;
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      for (int idx = 0; idx < MAXI; ++idx) {
+        const int item = wave + idx * nwave;
+        if (item < tiles * tc) {
+          const int it = item / tc, ct = item % tc;
+          double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+          Ct[0] = accs[idx][0]; Ct[4 * xs] = accs[idx][1]; Ct[8 * xs] = accs[idx][2]; Ct[12 * xs] = accs[idx][3];
+        }
       }
       __syncthreads();
-      for (int item = wave; item < jb * tc; item += nwave) {
-        const int it = item / tc, ct = item % tc;
-        double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-        mfma_acc_t acc = {Ct[0], Ct[4 * xs], Ct[8 * xs], Ct[12 * xs]};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(j0 + 4 * q + lk) * ns + 16 * it + li],
-                                                     X[(j0 + 4 * q + lk) * xs + 16 * ct + li], acc, 0, 0, 0);
-        Ct[0] = acc[0]; Ct[4 * xs] = acc[1]; Ct[8 * xs] = acc[2]; Ct[12 * xs] = acc[3];
+      for (int idx = 0; idx < MAXI; ++idx) {
+        const int item = wave + idx * nwave;
+        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (item < tiles * tc) {
+          const int it = item / tc, ct = item % tc;
+          for (int kb = it; kb < tiles; ++kb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
+                                                         0, 0, 0);
+          }
+        }
+        accs[idx] = acc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int idx = 0; idx < MAXI; ++idx) {
+        const int item = wave + idx * nwave;
+        if (item < tiles * tc) {
+          const int it = item / tc, ct = item % tc;
+          double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+          Ct[0] = accs[idx][0]; Ct[4 * xs] = accs[idx][1]; Ct[8 * xs] = accs[idx][2]; Ct[12 * xs] = accs[idx][3];
+        }
       }
       __syncthreads();
     }

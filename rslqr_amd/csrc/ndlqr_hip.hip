@@ -245,7 +245,12 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
   }
   // matrix-core separator: one wavefront per 16x16 tile of the products / updates; 512 threads let two
   // workgroups (67 KB of LDS each at n = 64) share a CU
-  const int sep_threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 32 ? 512 : 256);
+  int sep_threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 32 ? 512 : 256);
+  if (p1mfma) {  // separator_mfma: a wavefront per tile of a block row of W, at most three panel tiles per wavefront
+    const int need = (d.n / 16) > ((d.n / 16) * ctc + 2) / 3 ? (d.n / 16) : ((d.n / 16) * ctc + 2) / 3;
+    if (sep_threads < 64 * need) sep_threads = 64 * need;
+    if (sep_threads > 1024) { g_last_error = "nstates too large for separator_mfma"; return NDLQR_ERR_INVALID; }
+  }
   for (int l = 0; l < d.K; ++l) {
     const int nsub = d.N >> (l + 1);
     {
