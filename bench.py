@@ -82,8 +82,9 @@ def committed_traffic(n, m, N, batch, flags):
             tj = json.load(open(os.path.join(pdir, name)))
         except (OSError, ValueError):
             continue
-        if tj.get("workload") == [n, m, N, batch, flags]:
-            best = (name, tj)
+        if tj.get("workload") == [n, m, N, batch, flags] and (best is None or tj.get("csrc_sha") == sha or
+                                                              best[1].get("csrc_sha") != sha):
+            best = (name, tj)  # the newest one taken on this source tree, else the newest one
     if best is None:
         return {}, "no committed PMC summary for this workload"
     name, tj = best

@@ -20,7 +20,7 @@ SLOTS = [("bottom", ("bottom_reduced_mc", "bottom_small", "rb_bottom")),
          ("upper", ("reduced_level_mc", "level_small")),
          ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_states_generic")),
          ("leaf", ("leaf_generic",)),
-         ("separator", ("separator_generic",)),
+         ("separator", ("separator_generic", "separator_mfma")),
          ("schur_boundary", ("schur_mfma", "schur_generic")),
          ]
 
