@@ -48,7 +48,7 @@ struct NdlqrHipCtx {
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   double* ytop; // [batch][N/8][n] multipliers of the separators of level >= 3 (rb_backsub_top -> rb_backsub)
   double* red;  // [batch][N/4][4 n^2 + 2 n] accumulators of the separator-only schedule (size-specialised shapes)
-  bool rowbcast; // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom); NDLQR_ROWBCAST=0: bottom_reduced_mc
+  int rowbcast;  // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom): NDLQR_ROWBCAST=1 always, 0 never (bottom_reduced_mc), unset (-1): by block size
   int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
   int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; advance by two per solve
   int* info;

@@ -22,6 +22,7 @@
 // stores, one writer per element. Compared with the knot-based bottom kernel this drops the 28-row
 // knot states, their Schur updates, the LDS publishing and every workgroup barrier.
 #pragma once
+#include "kernels_dpp.hpp"
 #include "kernels_small.hpp"
 
 namespace ndlqr {
@@ -74,7 +75,8 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
   // v_cmp) instead of being kept in scalar registers across the whole kernel (spills)
   int lane = lane_in;
   asm volatile("" : "+v"(lane));
-  const int li = lane & 15, lk = lane >> 4, gi = lane % NX;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ri = li < NX ? li : NX - 1;  // lanes NX..15 of a 16-lane row are padding: they repeat row NX - 1
   SEG_INIT();
 #pragma unroll
   for (int g = 0; g < 4; ++g) m.scr[(lk + 4 * g) * SP + li] = c[g];
@@ -83,49 +85,29 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
   if constexpr (NX % 2 == 0) {
 #pragma unroll
     for (int j = 0; j < NX; j += 2) {
-      const double2 t = *reinterpret_cast<const double2*>(&m.scr[gi * SP + j]);
+      const double2 t = *reinterpret_cast<const double2*>(&m.scr[ri * SP + j]);
       acc[j] = t.x; acc[j + 1] = t.y;
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = m.scr[gi * SP + j];
+    for (int j = 0; j < NX; ++j) acc[j] = m.scr[ri * SP + j];
   }
-  // Left-looking Cholesky, one row per lane, fused with the forward substitution of the unit
-  // vectors (lane c < NX: column c of W = L^-1)
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    double v = acc[j], sacc = (j == lane) ? 1.0 : 0.0;  // lanes >= NX: zero columns (the padding of W)
-    // row j of L, broadcast once: each value feeds the row's own elimination and the column of W.
-    // (Reading the row back from LDS instead -- an LDS broadcast read is no vector-ALU instruction --
-    // was measured: fewer instructions but the per-step round trip is exposed, 10 % slower.)
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const double bc = readlane_f64(acc[k], j);
-      v = fma(-acc[k], bc, v);
-      sacc = fma(-bc, w[k], sacc);
-    }
-    const double pivot = readlane_f64(v, j);
-    // 1 / sqrt(pivot): hardware estimate (v_rsq_f64, ~2^-26) + one Newton step -- rsqrt() expands to
-    // a third-order step plus special-case selects; the second-order one is within a few ulp, far
-    // inside the fast-mode tolerance. A non-positive pivot turns into NaN here and stays NaN
-    // through every later pivot, so ONE test after the last step flags the separator.
-    const double y0 = __builtin_amdgcn_rsq(pivot);
-    const double e = fma(-pivot * y0, y0, 1.0);
-    const double rinv = fma(y0 * e, 0.5, y0);
-    if (j == NX - 1) bad = !((rinv > 0.0) & (rinv < 1.0e300));  // no short-circuit: one basic block
-    acc[j] = v * rinv;
-    w[j] = sacc * rinv;
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  // Left-looking Cholesky, one row per lane of every 16-lane DPP row (the four rows of the wavefront
+  // repeat it), fused with the forward substitution of the unit vectors (lane c < NX: column c of
+  // W = L^-1): step j takes row j of L from lane j inside the FMAs (v_fmac_f64_dpp row_newbcast,
+  // kernels_dpp.hpp) -- 132 FMAs + 12 broadcasts per separator where the v_readlane form of round 1
+  // needed 156 broadcast pairs + 132 FMAs. 1 / sqrt(pivot): hardware estimate (v_rsq_f64, ~2^-26) + one
+  // Newton step, within a few ulp; a non-positive pivot turns into NaN and stays NaN through every later
+  // pivot, so ONE test after the last step flags the separator.
+  const bool bad = rb_chol_inv<NX>(li, acc, w);
   SEG(30);
-  {  // every lane stores (lanes >= 16 their zeros into the pad column): a store under a lane
-     // predicate makes the compiler sink the whole W recurrence behind it, away from the broadcasts
+  {  // every lane stores (lanes >= 16 zeros into the pad column): a store under a lane predicate makes the
+     // compiler sink the whole W recurrence behind it
     const int wc = lane < 16 ? lane : 16;
 #pragma unroll
-    for (int r = 0; r < NX; ++r) m.W[r * WP + wc] = w[r];
+    for (int r = 0; r < NX; ++r) m.W[r * WP + wc] = lane < 16 ? w[r] : 0.0;
   }
-  if (lstore && lane < NX) store_row<NX>(lstore + gi * NX, acc);
+  if (lstore && lane < NX) store_row<NX>(lstore + li * NX, acc);
   wave_lds_sync();
   // S-bar^-1 = W'W as one tile; being symmetric, its accumulator components are at once its
   // A-operand fragments: X = S-bar^-1 [r_a | b~ | r_bb] needs no further data movement

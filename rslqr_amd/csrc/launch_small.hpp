@@ -50,8 +50,11 @@ static SmallPlan plan_small(const NdlqrHipCtx* c) {
       // compact level-0 records (S-bar^-1 only): not what a record-based re-solve reads, and the tree
       // schedule keeps the one-kernel back-substitution; rb_backsub's thread roles need 8 (2 nx + nu) <= 256
       p.compact = !p.tree && !p.store_l && d.N >= 16 && 8 * (2 * NX + NU) <= 256;
-      // row-broadcast bottom kernel: one DPP row holds the rows of S-bar and of [A | B]'
-      p.rowbcast = c->rowbcast && p.compact && NX <= 16 && NX + NU <= 16;
+      // row-broadcast bottom kernel (one DPP row holds the rows of S-bar and of [A | B]'): its cost falls
+      // with the block size, the matrix-core kernel's does not (16x16 tiles whatever n is). Measured bottom
+      // kernel, N = 256 x 1024: (6,3) 0.105 vs 0.170 ms, (8,4) 0.144 vs 0.190, (9,3) 0.202 vs 0.244,
+      // (10,4) 0.230 vs 0.271, (12,4) 0.301 vs 0.290 -- so it serves n <= 10 (NDLQR_ROWBCAST=0/1 overrides)
+      p.rowbcast = p.compact && NX <= 16 && NX + NU <= 16 && (c->rowbcast == 1 || (c->rowbcast < 0 && NX <= 10));
     }
   }
   // the separator-only schedule touches F only to park the factors of KEEP_RECORDS

@@ -281,7 +281,7 @@ def test_tree_schedule_fills_the_chip(ndlqr, oracle):
     n, m, N, batch, seed = 12, 4, 256, 32, 2100
     tree = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "1"})
     flat = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0", "NDLQR_ROWBCAST": "0"})
-    rowb = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0"})  # row-broadcast core, same size
+    rowb = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0", "NDLQR_ROWBCAST": "1"})  # row-broadcast bottom kernel
     err = np.linalg.norm(rowb - flat, axis=1) / np.linalg.norm(flat, axis=1)
     assert err.max() <= REL_TOL, err.max()
     err = np.linalg.norm(tree - flat, axis=1) / np.linalg.norm(flat, axis=1)
@@ -332,7 +332,8 @@ def test_separator_only_schedules_other_shapes(ndlqr, oracle, n, m, N, batch):
     seed = 500 + n
     probs = [synth(ndlqr, n, m, N, seed + b) for b in range(batch)]
     ref = np.stack([oracle.solve(p, 1)[0][: p.nvars] for p in probs])
-    for env in ({}, {"NDLQR_TREE": "0"}, {"NDLQR_TREE": "1"}, {"NDLQR_ROWBCAST": "0", "NDLQR_TREE": "0"}):
+    for env in ({}, {"NDLQR_TREE": "0"}, {"NDLQR_TREE": "1"}, {"NDLQR_ROWBCAST": "0", "NDLQR_TREE": "0"},
+                {"NDLQR_ROWBCAST": "1", "NDLQR_TREE": "0"}):
         got = _solve_in_subprocess(n, m, N, batch, seed, env)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         assert err <= REL_TOL, (env, err)
