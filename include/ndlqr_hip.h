@@ -16,7 +16,9 @@
  *                                       0..n-1 lambda, n..2n-1 state, 2n..2n+m-1 input.
  *                                       (reference: column-major sub-blocks, src/nddata.c:40-53)
  *           z   [batch][N][2n+m]     rhs in / solution out, same order as the reference
- *           info[batch+1]            non-positive Cholesky pivots per problem, batch total last
+ *           info[batch+1]            non-positive Cholesky pivots per problem, batch total last (cumulative
+ *                                    over solves; ndlqr_hip_cholesky_failures reports those since the last
+ *                                    synchronisation)
  */
 #ifndef NDLQR_HIP_H_
 #define NDLQR_HIP_H_

@@ -50,7 +50,9 @@ struct NdlqrHipCtx {
   double* red;  // [batch][N/4][4 n^2 + 2 n] accumulators of the separator-only schedule (size-specialised shapes)
   int rowbcast;  // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom): NDLQR_ROWBCAST=1 always, 0 never (bottom_reduced_mc), unset (-1): by block size
   int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
-  int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; advance by two per solve
+  int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; zero between solves (reset by the root's wavefront)
+  bool state_dirty;  // a solve failed to launch or to complete: counters / failure words are zeroed before the next one
+  int fail_base;     // value of the (cumulative) batch-wide failure counter at the last synchronisation
   int* info;
   const char* schedule;  // name of the launch sequence the last solve used (ndlqr_hip_schedule)
   int* h_fail;      // pinned host word: the batch-wide failure count, copied behind the last kernel of a solve

@@ -448,7 +448,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void re
 // pushes visible -- goes on to eliminate the parent (reduced_separator_mc), and so on up to the
 // root. Nobody ever waits: the first arriver simply exits. One launch for the whole factorisation
 // instead of 1 + (K - 2); the thinly populated upper levels of one problem overlap with the bottom
-// levels of the next ones. The counters advance by two per solve (tested for parity, never reset).
+// levels of the next ones. The wavefront that eliminates the root resets its problem's counters (a launch
+// that did not run to completion makes the host zero them before the next solve).
 // Correct on every placement (write-through pushes, L1-bypassing slot loads, slots padded to whole
 // lines; no fences: an agent-scope fence writes back / invalidates a whole L2 and made this 18 ms),
 // Used for small batches (all bottom wavefronts resident at once: (6,3,256)x1 0.053 -> 0.046 ms);
@@ -615,7 +616,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
     int l = 1, base = k0;  // finished: the level-l separator of subtree [base, base + 2^(l+1))
     for (;;) {
       const int T = 2 << l;
-      if (T >= N) break;  // that was the root
+      if (T >= N) {  // that was the root: every arrival of this problem has been counted -- leave the counters at zero
+        for (int e = lane; e < (N >> 2); e += 64) cnt[(size_t)b * (N >> 2) + e] = 0;
+        break;
+      }
       const bool left = (base & T) == 0;
       const int p = left ? base + T - 1 : base - 1;  // the parent separator (level l + 1)
       // every push of this wavefront has left the chip-side caches (write-through stores, atomics)

@@ -80,11 +80,6 @@ static int launch_small(NdlqrHipCtx* c) {
       // records have to serve a record-based re-solve (KEEP_RECORDS) or the tree schedule runs
       const bool compact = plan.compact;
       c->schedule = tree ? "reduced-tree" : (compact ? "reduced" : "reduced-records");
-      if (tree) {
-        // arrival counters start from zero in every solve: a launch that did not run to completion
-        // (error mid-graph, aborted stream) cannot leave odd counters behind for the next one
-        HIP_TRY(hipMemsetAsync(c->tree_cnt, 0, sizeof(int) * (size_t)d.batch * (d.N >> 2), c->stream));
-      }
       {
         ScopedSlot t(c, SLOT_BOTTOM);
         bool launched = false;

@@ -77,7 +77,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
-  c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false;
+  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false;
 
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->rowbcast = getenv("NDLQR_ROWBCAST") ? (atoi(getenv("NDLQR_ROWBCAST")) != 0 ? 1 : 0) : -1;  // -1: by block size
@@ -384,7 +384,7 @@ static bool solve_needs_F(const NdlqrHipCtx* c) {
 // Enqueue leaf/bottom + per-level + apply launches on the context's stream.
 static int enqueue_solve(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
-  HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int) * ((size_t)d.batch + 1), c->stream));
+  // (the failure counters are cumulative: no memset node; the host subtracts what it has seen)
   const bool strict = (c->flags & NDLQR_FLAG_STRICT_FP) != 0;
   int err = NDLQR_OK;
   bool done = false;
@@ -407,6 +407,16 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
     const int ferr = ndlqr_hip_ensure_F(c);
     if (ferr) return ferr;
   }
+  if (c->state_dirty) {
+    // the previous solve did not launch or complete: its arrival counters may be odd and its failure
+    // words meaningless -- start from zero (the kernels themselves leave both clean)
+    if (c->tree_cnt)
+      HIP_TRY(hipMemsetAsync(c->tree_cnt, 0, sizeof(int) * (size_t)c->d.batch * (c->d.N / 4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int) * ((size_t)c->d.batch + 1), c->stream));
+    c->fail_base = 0;
+    c->state_dirty = false;
+  }
+  c->state_dirty = true;  // until this solve is known to have been enqueued completely
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   int err = NDLQR_OK;
   if (c->flags & NDLQR_FLAG_PROFILE) {
@@ -437,6 +447,7 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->timing_pending = true;
+  c->state_dirty = false;
   // a complete factor array is on the device with KEEP, and on the strict runtime-sized path
   c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 ||
                   ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
@@ -513,13 +524,18 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
 int ndlqr_hip_synchronize(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  {
+    const hipError_t se = hipStreamSynchronize(c->stream);
+    if (se != hipSuccess) { c->state_dirty = true; return fail("hipStreamSynchronize(c->stream)", se); }
+  }
   if (c->timing_pending) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     c->last_ms = ms;
     c->timing_pending = false;
-    c->last_failures = *c->h_fail;  // info[batch] = batch-wide count of non-positive pivots of the last solve
+    // info[batch] = cumulative batch-wide count of non-positive pivots: failures since the last synchronisation
+    c->last_failures = *c->h_fail - c->fail_base;
+    c->fail_base = *c->h_fail;
   }
   for (auto& p : c->pending) {
     float ms = 0;
