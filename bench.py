@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with:
                   exactly this source tree (null when the tree differs).
   cpu_baseline -- the reference's own ndlqr_Solve (oracle/_ref/libref.so, "reference") or the
                   plain-C oracle ("port") timed on this host on a bounded sample (N=1, rank 0).
+  pipeline     -- depth of the solve pipeline behind `value` and the same steps strictly stream-ordered.
   transfers    -- H2D of the packed inputs and D2H of the solutions, timed separately (never in `value`).
   modes        -- N=1: strict mode, KEEP_FACT and the rhs-only re-solve on the same workload.
   gather       -- N>1: throughput including the all_gather of every shard's solutions.
@@ -253,6 +254,14 @@ def main():
     log("rank %d: %d steps in %.3f s" % (rank, steps, elapsed))
     fails = bs.cholesky_failures()
     schedule = bs.schedule()
+    # The same K steps strictly stream-ordered (pipeline depth 1: a step starts when the previous one has
+    # finished), next to the default two-deep pipeline of `value` (include/ndlqr_hip.h)
+    depth = bs.pipeline_depth()
+    elapsed_ordered = None
+    if depth > 1:
+        bs.set_pipeline_depth(1)
+        elapsed_ordered = sharding.timed_region(bs, steps, 2, barrier)
+        bs.set_pipeline_depth(depth)
 
     # Per-kernel durations for the roofline object: the SAME K steps once more with a HIP-event
     # pair around every launch on the launch stream. (Events force eager launches, so they cannot
@@ -313,6 +322,8 @@ def main():
                   "bytes_per_rank_per_step": 8 * batch * bs.nvars}
 
     red = [elapsed, float(fails), kkt_worst]
+    if elapsed_ordered is not None:
+        elapsed_ordered = sharding.max_over_ranks([elapsed_ordered], device="cuda" if backend == "nccl" else "cpu")[0]
     if gather:
         red += [gather["elapsed_s"], 0.0 if gather["own_shard_intact"] else 1.0]
     red = sharding.max_over_ranks(red, device="cuda" if backend == "nccl" else "cpu")
@@ -387,6 +398,12 @@ def main():
             "kernel_ms_note": "second pass of the same %d steps with per-launch HIP events (eager "
                               "launches): %.3f ms/step vs %.3f ms/step in the timed, graph-replayed region"
                               % (steps, elapsed_profiled / steps * 1e3, step_ms),
+            "pipeline": {"depth": depth,
+                         "note": "consecutive solves of one solver alternate between two output-buffer sets / "
+                                 "streams (each solve is complete; inputs resident and shared); depth 1 = a step "
+                                 "starts when the previous one has finished",
+                         "value_depth1": (total_solves / elapsed_ordered) if elapsed_ordered else None,
+                         "ms_per_step_depth1": (elapsed_ordered / steps * 1e3) if elapsed_ordered else None},
             "transfers": {"h2d_ms": h2d_ms, "h2d_bytes": in_bytes, "d2h_ms": d2h_ms,
                           "d2h_bytes": 8 * batch * bs.nvars,
                           "note": "rank 0, pageable host memory, whole shard; not part of `value`"},

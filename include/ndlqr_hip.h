@@ -57,7 +57,8 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* ctx, int p0, int count, const double* A
 int ndlqr_hip_pack_flat_device(NdlqrHipCtx* ctx, const double* A, const double* B, const double* Q,
                                const double* R, const double* q, const double* r, const double* d,
                                const double* x0);
-/* Device pointers for zero-copy producers (order: AB, QR, rhs, F, z). */
+/* Device pointers for zero-copy producers (order: AB, QR, rhs, F, z). Allocates the factor array and
+ * sets the pipeline depth to 1, so that z is THE solution buffer from then on. */
 int ndlqr_hip_device_pointers(NdlqrHipCtx* ctx, void** out5);
 
 /* ndlqr_Solve (src/solve.c:38-190) for the whole batch: leaf kernel + one kernel per tree level
@@ -65,6 +66,16 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* ctx, void** out5);
  * context's stream; HIP events bracket the sequence. */
 int ndlqr_hip_solve_async(NdlqrHipCtx* ctx);
 int ndlqr_hip_synchronize(NdlqrHipCtx* ctx);
+/* Solve pipeline. Depth 2 (default; NDLQR_PIPELINE): consecutive ndlqr_hip_solve_async calls of one
+ * context alternate between two sets of output buffers (records, accumulators, solution), each on its
+ * own stream, so that a solve starts while the previous one is still in its thinly populated upper tree
+ * levels / its HBM-bound back-substitution. Every solve is complete; ndlqr_hip_synchronize waits for all
+ * of them and the download functions return the most recent one. Applies to the schedules that keep
+ * nothing but the solution (no factor array, no kept records, no per-kernel events, own stream); depth 1
+ * = strictly stream-ordered solves. Inputs must not be replaced while solves are in flight: the upload /
+ * pack functions wait for them first. */
+int ndlqr_hip_set_pipeline_depth(NdlqrHipCtx* ctx, int depth);
+int ndlqr_hip_pipeline_depth(const NdlqrHipCtx* ctx);
 /* Factor / solve split: new right-hand side(s) against the factorisation cached by the last
  * ndlqr_hip_solve_async with NDLQR_FLAG_KEEP_FACT (the reference's solution sweep,
  * src/solve.c:137-182, alone). rhs layout as in ndlqr_hip_upload_inputs. */

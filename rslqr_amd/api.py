@@ -242,6 +242,8 @@ def lib():
     proto("ndlqr_hip_upload_inputs", ci, vp, ci, ci, dp, dp, dp)
     proto("ndlqr_hip_factors_valid", ci, vp)
     proto("ndlqr_hip_schedule", C.c_char_p, vp)
+    proto("ndlqr_hip_set_pipeline_depth", ci, vp, ci)
+    proto("ndlqr_hip_pipeline_depth", ci, vp)
     proto("ndlqr_hip_pack_solutions_device", ci, vp, vp)
     proto("ndlqr_hip_gemm", ci, ci, ci, ci, ci, ci, cd, dp, ci, dp, ci, cd, dp, ci)
     proto("ndlqr_hip_potrf_lower", ci, ci, dp, ci)
@@ -405,6 +407,13 @@ class BatchSolver:
     def schedule(self):
         """Name of the launch sequence the last solve used."""
         return self.L.ndlqr_hip_schedule(self.ctx).decode()
+
+    def set_pipeline_depth(self, depth):
+        """1: stream-ordered solves; 2: consecutive asynchronous solves alternate between two buffer sets."""
+        return self.L.ndlqr_hip_set_pipeline_depth(self.ctx, depth)
+
+    def pipeline_depth(self):
+        return self.L.ndlqr_hip_pipeline_depth(self.ctx)
 
     def profile_reset(self):
         self.L.ndlqr_hip_profile_reset(self.ctx)

@@ -34,6 +34,26 @@ struct PendingEvent {
   hipEvent_t start, stop;
 };
 
+// Second set of everything a solve writes (and of what orders it): consecutive solves of one context
+// alternate between the two sets, each on its own stream, so that the thinly populated upper-level
+// kernels and the HBM-bound back-substitution of one solve run beside the ALU-bound bottom kernel of
+// the next (only for schedules without cross-solve state: no factor array, no kept records).
+struct NdlqrAltSlot {
+  bool ready = false;
+  double* rec = nullptr;
+  double* red = nullptr;
+  double* ytop = nullptr;
+  double* z = nullptr;
+  int* tree_cnt = nullptr;
+  int* h_fail = nullptr;
+  hipStream_t stream = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  unsigned graph_flags = 0;
+  hipStream_t graph_stream = nullptr;
+  bool graph_rec_complete = false;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
 struct NdlqrHipCtx {
   ndlqr::Dims d;
   int device;
@@ -51,6 +71,13 @@ struct NdlqrHipCtx {
   int rowbcast;  // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom): NDLQR_ROWBCAST=1 always, 0 never (bottom_reduced_mc), unset (-1): by block size
   int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
   int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; zero between solves (reset by the root's wavefront)
+  NdlqrAltSlot alt;       // the other buffer set / stream of the two-deep solve pipeline
+  int pipeline;           // 1: stream-ordered solves; 2 (default, NDLQR_PIPELINE): consecutive solves alternate slots
+  unsigned solve_count;   // solves enqueued so far (parity picks the slot)
+  bool in_alt;            // the context's buffer / stream fields currently hold the alternate set
+  const double* z_latest; // solution of the most recent solve (either slot)
+  hipStream_t stream_latest;
+  int* h_fail_other;      // the failure word of the slot that is not current
   bool state_dirty;  // a solve failed to launch or to complete: counters / failure words are zeroed before the next one
   int fail_base;     // value of the (cumulative) batch-wide failure counter at the last synchronisation
   int* info;

@@ -6,6 +6,8 @@
 // Written for wave64 / gfx950 only; built with -ffp-contract=off so that every fused
 // multiply-add in the kernels is an explicit fma() (fast mode) or an explicit mul + add
 // (NDLQR_FLAG_STRICT_FP, which reproduces the reference's default CPU build bit for bit).
+#include <utility>
+
 #include "hip_context.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_mfma.hpp"
@@ -77,6 +79,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
+  c->pipeline = getenv("NDLQR_PIPELINE") ? atoi(getenv("NDLQR_PIPELINE")) : 2;
+  c->solve_count = 0; c->in_alt = false; c->z_latest = nullptr; c->stream_latest = nullptr; c->h_fail_other = nullptr;
   c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false;
 
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
@@ -119,9 +123,12 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   return c;
 }
 
+static void free_alt(NdlqrHipCtx* c);  // two-deep solve pipeline, below
+
 void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  free_alt(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
@@ -135,6 +142,83 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+
+// ------------------------------------------------------------------------------ two-deep solve pipeline
+
+// exchange the context's per-solve buffers, stream, graph and events with the alternate set
+static void swap_slot(NdlqrHipCtx* c) {
+  NdlqrAltSlot& a = c->alt;
+  std::swap(c->rec, a.rec); std::swap(c->red, a.red); std::swap(c->ytop, a.ytop); std::swap(c->z, a.z);
+  std::swap(c->tree_cnt, a.tree_cnt); std::swap(c->h_fail, a.h_fail); std::swap(c->stream, a.stream);
+  std::swap(c->graph_exec, a.graph_exec); std::swap(c->graph_flags, a.graph_flags);
+  std::swap(c->graph_stream, a.graph_stream); std::swap(c->graph_rec_complete, a.graph_rec_complete);
+  std::swap(c->ev_start, a.ev_start); std::swap(c->ev_stop, a.ev_stop);
+  c->in_alt = !c->in_alt;
+}
+
+static void free_alt(NdlqrHipCtx* c) {
+  if (c->in_alt) swap_slot(c);
+  NdlqrAltSlot& a = c->alt;
+  if (a.stream) (void)hipStreamSynchronize(a.stream);
+  if (a.graph_exec) (void)hipGraphExecDestroy(a.graph_exec);
+  (void)hipFree(a.rec); (void)hipFree(a.red); (void)hipFree(a.ytop); (void)hipFree(a.z); (void)hipFree(a.tree_cnt);
+  if (a.h_fail) (void)hipHostFree(a.h_fail);
+  if (a.ev_start) (void)hipEventDestroy(a.ev_start);
+  if (a.ev_stop) (void)hipEventDestroy(a.ev_stop);
+  if (a.stream) (void)hipStreamDestroy(a.stream);
+  a = NdlqrAltSlot();
+}
+
+// allocate the alternate set on first use; false (and depth 1 from then on) when it does not fit
+static bool ensure_alt(NdlqrHipCtx* c) {
+  NdlqrAltSlot& a = c->alt;
+  if (a.ready) return true;
+  const ndlqr::Dims& d = c->d;
+  const size_t slot_doubles = (4 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
+  const size_t red_bytes = sizeof(double) * (size_t)d.batch * (d.N / 4) * slot_doubles;
+  const size_t cnt_bytes = sizeof(int) * (size_t)d.batch * (d.N / 4);
+  bool ok = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&a.ev_start) == hipSuccess && hipEventCreate(&a.ev_stop) == hipSuccess &&
+            hipMalloc(&a.rec, bytes_rec(d)) == hipSuccess && hipMalloc(&a.z, bytes_z(d)) == hipSuccess &&
+            hipHostMalloc((void**)&a.h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  if (ok && c->red)
+    ok = hipMalloc(&a.red, red_bytes) == hipSuccess && hipMemsetAsync(a.red, 0, red_bytes, a.stream) == hipSuccess &&
+         hipMalloc(&a.ytop, sizeof(double) * (size_t)d.batch * (d.N / 8) * d.n) == hipSuccess &&
+         hipMalloc(&a.tree_cnt, cnt_bytes) == hipSuccess && hipMemsetAsync(a.tree_cnt, 0, cnt_bytes, a.stream) == hipSuccess;
+  ok = ok && hipMemsetAsync(a.z, 0, bytes_z(d), a.stream) == hipSuccess && hipStreamSynchronize(a.stream) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    free_alt(c);
+    c->pipeline = 1;
+    return false;
+  }
+  *a.h_fail = *c->h_fail;
+  a.ready = true;
+  return true;
+}
+
+// every solve in flight on either slot has finished
+static hipError_t sync_all(NdlqrHipCtx* c) {
+  hipError_t e = c->stream ? hipStreamSynchronize(c->stream) : hipSuccess;
+  if (c->alt.stream) { const hipError_t e2 = hipStreamSynchronize(c->alt.stream); if (e == hipSuccess) e = e2; }
+  return e;
+}
+
+int ndlqr_hip_set_pipeline_depth(NdlqrHipCtx* c, int depth) {
+  if (!c || depth < 1) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));
+  if (c->in_alt) {  // keep the latest solution where the single-slot code expects it
+    swap_slot(c);
+    if (c->alt.z && c->z_latest == c->alt.z) {
+      HIP_TRY(hipMemcpy(c->z, c->alt.z, bytes_z(c->d), hipMemcpyDeviceToDevice));
+      c->z_latest = c->z;
+    }
+  }
+  c->pipeline = depth > 2 ? 2 : depth;
+  return NDLQR_OK;
+}
+int ndlqr_hip_pipeline_depth(const NdlqrHipCtx* c) { return c ? c->pipeline : 0; }
 
 // The complete factor array [batch][K][N][2n+m][n] (5.6 GB at (12,4,256) x 1024, 87 GB at
 // (64,16,512) x 256) exists only for the schedules that touch it: strict mode, KEEP_FACT, the
@@ -168,7 +252,10 @@ unsigned ndlqr_hip_get_flags(const NdlqrHipCtx* c) { return c ? c->flags : 0u; }
 int ndlqr_hip_set_stream(NdlqrHipCtx* c, void* hip_stream) {
   if (!c) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
-  if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+  {
+    const int perr = ndlqr_hip_set_pipeline_depth(c, c->pipeline);  // drains both slots, primary set current
+    if (perr) return perr;
+  }
   if (c->own_stream && c->stream) HIP_TRY(hipStreamDestroy(c->stream));
   if (hip_stream) {
     c->stream = (hipStream_t)hip_stream;
@@ -186,6 +273,7 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   if (!c || !AB || !QR || !rhs || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
   const size_t sAB = (size_t)d.N * d.n * d.w, sQR = (size_t)d.N * d.w, sz = (size_t)d.N * d.rows;
   HIP_TRY(hipMemcpyAsync(c->AB + p0 * sAB, AB, sizeof(double) * sAB * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->QR + p0 * sQR, QR, sizeof(double) * sQR * count, hipMemcpyHostToDevice, c->stream));
@@ -201,6 +289,7 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
                                const double* x0) {
   if (!c || !A || !B || !Q || !R || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
   hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->d, A, B, Q, R,
                      q, r, d, x0, c->AB, c->QR, c->rhs);
   HIP_TRY(hipGetLastError());
@@ -213,6 +302,8 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
   if (!c || !out5) return NDLQR_ERR_INVALID;
   const int ferr = ndlqr_hip_ensure_F(c);  // the caller asks for the factor array: it has to exist
   if (ferr) return ferr;
+  const int perr = ndlqr_hip_set_pipeline_depth(c, 1);  // the caller holds raw pointers: one buffer set from now on
+  if (perr) return perr;
   out5[0] = c->AB; out5[1] = c->QR; out5[2] = c->rhs; out5[3] = c->F; out5[4] = c->z;
   return NDLQR_OK;
 }
@@ -410,12 +501,27 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   if (c->state_dirty) {
     // the previous solve did not launch or complete: its arrival counters may be odd and its failure
     // words meaningless -- start from zero (the kernels themselves leave both clean)
+    (void)sync_all(c);
     if (c->tree_cnt)
       HIP_TRY(hipMemsetAsync(c->tree_cnt, 0, sizeof(int) * (size_t)c->d.batch * (c->d.N / 4), c->stream));
+    if (c->alt.tree_cnt)
+      HIP_TRY(hipMemsetAsync(c->alt.tree_cnt, 0, sizeof(int) * (size_t)c->d.batch * (c->d.N / 4), c->stream));
     HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int) * ((size_t)c->d.batch + 1), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *c->h_fail = 0;
+    if (c->alt.h_fail) *c->alt.h_fail = 0;
     c->fail_base = 0;
     c->state_dirty = false;
   }
+  // Two-deep pipeline: solves that leave nothing behind but records and the solution alternate between two
+  // buffer sets, each on its own stream (the other set may still be in flight). Everything else -- factor
+  // array, kept records, per-kernel events, a caller-owned stream -- stays stream-ordered on the primary set.
+  const bool pipelined = c->pipeline >= 2 && c->own_stream && !solve_needs_F(c) &&
+                         !(c->flags & (NDLQR_FLAG_PROFILE | NDLQR_FLAG_KEEP_RECORDS | NDLQR_FLAG_KEEP_FACT));
+  const bool want_alt = pipelined && (c->solve_count & 1u) && ensure_alt(c);
+  if (!pipelined && c->alt.stream) HIP_TRY(hipStreamSynchronize(c->in_alt ? c->stream : c->alt.stream));
+  if (want_alt != c->in_alt) swap_slot(c);
+  ++c->solve_count;
   c->state_dirty = true;  // until this solve is known to have been enqueued completely
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   int err = NDLQR_OK;
@@ -448,6 +554,8 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->timing_pending = true;
   c->state_dirty = false;
+  c->z_latest = c->z;
+  c->stream_latest = c->stream;
   // a complete factor array is on the device with KEEP, and on the strict runtime-sized path
   c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 ||
                   ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
@@ -458,6 +566,7 @@ int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
   if (!c || !rhs || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));
   const size_t sz = (size_t)d.N * d.rows;
   HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -506,6 +615,8 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
     return NDLQR_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));
+  if (c->in_alt) swap_slot(c);  // cached records / factors live in the primary set
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   if (!try_launch_rhs_records(c)) {
     if (!c->fact_valid) {  // records only, but this shape / horizon has no record-based re-solve
@@ -518,6 +629,8 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->timing_pending = true;
+  c->z_latest = c->z;
+  c->stream_latest = c->stream;
   return NDLQR_OK;
 }
 
@@ -525,8 +638,8 @@ int ndlqr_hip_synchronize(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   {
-    const hipError_t se = hipStreamSynchronize(c->stream);
-    if (se != hipSuccess) { c->state_dirty = true; return fail("hipStreamSynchronize(c->stream)", se); }
+    const hipError_t se = sync_all(c);
+    if (se != hipSuccess) { c->state_dirty = true; return fail("hipStreamSynchronize", se); }
   }
   if (c->timing_pending) {
     float ms = 0;
@@ -534,8 +647,10 @@ int ndlqr_hip_synchronize(NdlqrHipCtx* c) {
     c->last_ms = ms;
     c->timing_pending = false;
     // info[batch] = cumulative batch-wide count of non-positive pivots: failures since the last synchronisation
-    c->last_failures = *c->h_fail - c->fail_base;
-    c->fail_base = *c->h_fail;
+    int seen = *c->h_fail;  // the counter is cumulative: the larger of the two slots' copies is the newer one
+    if (c->alt.h_fail && *c->alt.h_fail > seen) seen = *c->alt.h_fail;
+    c->last_failures = seen - c->fail_base;
+    c->fail_base = seen;
   }
   for (auto& p : c->pending) {
     float ms = 0;
@@ -574,8 +689,10 @@ int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln
   if (!c || !soln || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));
+  const double* zl = c->z_latest ? c->z_latest : c->z;
   const size_t nvars = (size_t)d.rows * d.N - d.m, pitch = (size_t)d.rows * d.N;
-  HIP_TRY(hipMemcpy2DAsync(soln, sizeof(double) * nvars, c->z + p0 * pitch, sizeof(double) * pitch,
+  HIP_TRY(hipMemcpy2DAsync(soln, sizeof(double) * nvars, zl + p0 * pitch, sizeof(double) * pitch,
                            sizeof(double) * nvars, (size_t)count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return NDLQR_OK;
@@ -589,7 +706,9 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* c, double* dst) {
   if (!c || !dst) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
-  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, c->stream, d, c->z, dst);
+  // on the stream of the latest solve: ordered behind it, asynchronous for the caller
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0,
+                     c->stream_latest ? c->stream_latest : c->stream, d, c->z_latest ? c->z_latest : c->z, dst);
   HIP_TRY(hipGetLastError());
   return NDLQR_OK;
 }
@@ -600,8 +719,9 @@ int ndlqr_hip_kkt_residual(NdlqrHipCtx* c, double* res, double* bnorm) {
   HIP_TRY(hipSetDevice(c->device));
   if (!c->kkt_out) HIP_TRY(hipMalloc(&c->kkt_out, sizeof(double) * 2 * (size_t)d.batch));
   double* out = c->kkt_out;
+  HIP_TRY(sync_all(c));
   hipLaunchKernelGGL(ndlqr::kkt_residual_generic, dim3(d.batch), dim3(256), 0, c->stream, d, c->AB, c->QR, c->rhs,
-                     c->z, out);
+                     c->z_latest ? c->z_latest : c->z, out);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(res, out, sizeof(double) * d.batch, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess && bnorm)
@@ -616,7 +736,9 @@ int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   const size_t pitch = (size_t)d.rows * d.N;
-  HIP_TRY(hipMemcpyAsync(z_full, c->z + p * pitch, sizeof(double) * pitch, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(sync_all(c));
+  HIP_TRY(hipMemcpyAsync(z_full, (c->z_latest ? c->z_latest : c->z) + p * pitch, sizeof(double) * pitch,
+                         hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return NDLQR_OK;
 }

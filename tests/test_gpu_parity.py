@@ -292,6 +292,46 @@ def test_tree_schedule_fills_the_chip(ndlqr, oracle):
         assert np.linalg.norm(tree[b] - ref) / np.linalg.norm(ref) <= REL_TOL
 
 
+def test_solve_pipeline(ndlqr, oracle):
+    """Two-deep solve pipeline (include/ndlqr_hip.h): consecutive asynchronous solves alternate between two
+    output-buffer sets / streams. Every solve is complete and identical to a stream-ordered one; replacing
+    the inputs waits for the solves in flight; the downloads return the most recent solve."""
+    n, m, N, batch = 12, 4, 64, 700  # 700 x 16 bottom wavefronts: the level-per-launch schedule
+    first = [ndlqr.generate_synthetic(n, m, N, 3000 + p) for p in range(batch)]
+    other = [ndlqr.generate_synthetic(n, m, N, 9000 + p) for p in range(batch)]
+    flat = lambda gen: [np.stack([g[k] for g in gen]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    assert bs.pipeline_depth() == 2
+    bs.initialize_flat(*flat(first))
+    for _ in range(5):  # odd number: the last solve ran on the primary set, the one before on the alternate
+        assert bs.solve_async() == 0
+    assert bs.synchronize() == 0
+    sol_a = bs.solutions()
+    assert bs.solve_async() == 0  # sixth solve: alternate set
+    assert bs.synchronize() == 0
+    assert np.array_equal(bs.solutions(), sol_a)
+    res, bn = bs.kkt_residuals()
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    # new inputs while two solves are in flight: the upload waits for them, the next solves see the new data
+    assert bs.solve_async() == 0 and bs.solve_async() == 0
+    bs.initialize_flat(*flat(other))
+    assert bs.solve_async() == 0 and bs.solve_async() == 0 and bs.solve_async() == 0
+    assert bs.synchronize() == 0
+    sol_b = bs.solutions()
+    assert bs.set_pipeline_depth(1) == 0  # stream-ordered from here on: same bits
+    assert bs.solve() == 0
+    assert np.array_equal(bs.solutions(), sol_b)
+    bs.initialize_flat(*flat(first))
+    assert bs.solve() == 0
+    assert np.array_equal(bs.solutions(), sol_a)
+    for p in (0, batch // 2, batch - 1):
+        g = other[p]
+        prob = Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+        ref = oracle.solve(prob, 1)[0][: prob.nvars]
+        assert np.linalg.norm(sol_b[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+    bs.close()
+
+
 def test_dropin_solve_flags(ndlqr, oracle):
     """ndlqr_Solve runs the batch API's default fast path; ndlqr_SetDeviceFlags selects strict mode
     (bit-identical to the reference's default build) or KEEP_FACT up front; ndlqr_SyncFactorsToHost
