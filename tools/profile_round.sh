@@ -15,6 +15,9 @@ root=$(pwd)
 export TMPDIR=/tmp
 python3 bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "[profile_round] bench done"
+# the profiler passes run the solves strictly stream-ordered: per-kernel durations then are those of the
+# kernel alone (what bench.py's `roofline.kernels` holds), not of two pipelined solves sharing the chip
+export NDLQR_PIPELINE=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o run -- python3 bench.py --no-cpu --no-modes "$@" \
     > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_stats.err
 echo "[profile_round] kernel trace done"
