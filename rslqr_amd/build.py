@@ -24,7 +24,7 @@ ARCH = "gfx950"
 C_SOURCES = ["containers.c", "synth.c", "json.c", "batch.c", "solver.c", "linalg.c", "stages.c"]
 HIP_MAIN = "ndlqr_hip.hip"            # context, generic / MFMA kernels, dispatch
 HIP_INSTANCE = "small_instance.hip"   # compiled once per line of small_instances.def
-HIP_DEPS = ["kernels_common.hpp", "kernels_leaf.hpp", "kernels_generic.hpp", "kernels_small.hpp", "kernels_bottom_reduced.hpp", "kernels_dpp.hpp", "kernels_rowbcast.hpp", "kernels_mfma.hpp",
+HIP_DEPS = ["kernels_common.hpp", "kernels_leaf.hpp", "kernels_generic.hpp", "kernels_small.hpp", "kernels_bottom_reduced.hpp", "kernels_dpp.hpp", "kernels_rowbcast.hpp", "kernels_mfma.hpp", "kernels_reduced_mfma.hpp",
             "hip_context.hpp", "launch_small.hpp", "small_instances.def"]
 
 

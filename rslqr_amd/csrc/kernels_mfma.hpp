@@ -17,6 +17,157 @@ namespace ndlqr {
 
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 
+// ------------------------------------------------------------------------------------- shared phases
+// Geometry of a separator workgroup: S-bar / L / W in LDS with row pitch ns = n + 1, ONE chunk of the
+// right-hand-side panel with row pitch xs, the inverses of the 16x16 diagonal blocks of L (pitch 17).
+struct SepGeom {
+  int n, ns, xs, tiles;
+  int lane, wave, nwave, li, lk;
+};
+constexpr int kSepMaxPanelTiles = 3;  // panel tiles a wavefront may own: tiles * CT <= 3 nwave (checked on the host)
+
+// Blocked Cholesky of S (lower triangle; different summation grouping than the reference: fast mode
+// only): diagonal block + its inverse by one wavefront (chol16_and_inverse), the panel below it and the
+// trailing update as rank-16 matrix-core products.
+__device__ __forceinline__ void sep_cholesky(const SepGeom& g, double* S, double* Wd, int* __restrict__ info,
+                                             const Dims& d, const int b) {
+  const int ns = g.ns, tiles = g.tiles, li = g.li, lk = g.lk;
+  for (int jb = 0; jb < tiles; ++jb) {
+    const int j0 = 16 * jb, rem = tiles - 1 - jb;
+    if (g.wave == 0) {
+      const bool bad = chol16_and_inverse(S + j0 * ns + j0, ns, Wd + jb * 16 * 17, g.lane);
+      if (bad && g.lane == 0) flag_failure(info, d, b);
+    }
+    __syncthreads();
+    const double* Wb = Wd + jb * 16 * 17;
+    for (int it = jb + 1 + g.wave; it < tiles; it += g.nwave) {  // L21 = A21 W'
+      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * it + li) * ns + j0 + 4 * q + lk], Wb[li * 17 + 4 * q + lk], acc,
+                                                   0, 0, 0);
+      double* Ct = S + (16 * it + lk) * ns + j0 + li;
+      Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+    }
+    __syncthreads();
+    for (int item = g.wave; item < rem * rem; item += g.nwave) {  // trailing rank-16 update
+      const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
+      if (ct > it) continue;  // lower triangle of tiles only
+      double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
+      mfma_acc_t acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
+                                                   S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
+      Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+    }
+    if (rem > 0) __syncthreads();
+  }
+}
+
+// W = L^-1, in place over the strictly lower blocks of L (diagonal blocks: Wd), block row by block
+// row: T_ij = sum_{k = j}^{i-1} L_ik W_kj,  W_ij = -W_ii T_ij  (j < i). With W the two triangular
+// sweeps of every panel chunk become two GEMMs whose tiles are all independent: 4 workgroup
+// barriers per chunk instead of 16 (the sweeps made the kernel barrier-bound: eight wavefronts
+// share 3..12 tiles per step). One tile of the block row per wavefront (host: nwave >= n / 16).
+__device__ __forceinline__ void sep_invert(const SepGeom& g, double* S, const double* Wd) {
+  const int ns = g.ns, tiles = g.tiles, li = g.li, lk = g.lk;
+  for (int ib = 1; ib < tiles; ++ib) {
+    mfma_acc_t wij = {0.0, 0.0, 0.0, 0.0};
+    const int jb = g.wave;
+    if (jb < ib) {
+      mfma_acc_t t = {0.0, 0.0, 0.0, 0.0};
+      for (int kb = jb; kb < ib; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double wkj = kb == jb ? Wd[jb * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * jb + li];
+          t = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * ib + li) * ns + 16 * kb + 4 * q + lk], wkj, t, 0, 0, 0);
+        }
+      }
+      // component q of an accumulator is element (4 q + lk, li): exactly the B operand of k-step q
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        wij = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[ib * 16 * 17 + li * 17 + 4 * q + lk], t[q], wij, 0, 0, 0);
+    }
+    __syncthreads();  // every L_ik of the block row has been read
+    if (jb < ib) {
+      double* Ct = S + (16 * ib + lk) * ns + 16 * jb + li;
+      Ct[0] = wij[0]; Ct[4 * ns] = wij[1]; Ct[8 * ns] = wij[2]; Ct[12 * ns] = wij[3];
+    }
+    __syncthreads();
+  }
+}
+
+// X <- W' (W X) for the tc column tiles of the panel chunk in LDS: Y = W R (block lower triangular),
+// then X = W' Y. Every tile of a product is independent; the wavefronts keep theirs in the
+// accumulators across the barrier that separates reading from overwriting the panel. Ends with a
+// workgroup barrier (the solved chunk is visible to everybody).
+__device__ __forceinline__ void sep_panel_solve(const SepGeom& g, const double* S, const double* Wd, double* X,
+                                                const int tc) {
+  const int ns = g.ns, xs = g.xs, tiles = g.tiles, li = g.li, lk = g.lk, wave = g.wave, nwave = g.nwave;
+  constexpr int MAXI = kSepMaxPanelTiles;
+  // block (it, kb) of W as A operand (row li, k = 4 q + lk) and of W' (row li of W' = column of W)
+  auto w_frag = [&](const int it, const int kb, const int q) -> double {
+    return kb == it ? Wd[it * 16 * 17 + li * 17 + 4 * q + lk] : S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
+  };
+  auto wt_frag = [&](const int it, const int kb, const int q) -> double {  // W'(16 it + li, 16 kb + 4 q + lk)
+    return kb == it ? Wd[it * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
+  };
+  mfma_acc_t accs[MAXI];
+#pragma unroll
+  for (int idx = 0; idx < MAXI; ++idx) {
+    const int item = wave + idx * nwave;
+    mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+    if (item < tiles * tc) {
+      const int it = item / tc, ct = item % tc;
+      for (int kb = 0; kb <= it; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
+                                                     0, 0, 0);
+      }
+    }
+    accs[idx] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int idx = 0; idx < MAXI; ++idx) {
+    const int item = wave + idx * nwave;
+    if (item < tiles * tc) {
+      const int it = item / tc, ct = item % tc;
+      double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+      Ct[0] = accs[idx][0]; Ct[4 * xs] = accs[idx][1]; Ct[8 * xs] = accs[idx][2]; Ct[12 * xs] = accs[idx][3];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int idx = 0; idx < MAXI; ++idx) {
+    const int item = wave + idx * nwave;
+    mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+    if (item < tiles * tc) {
+      const int it = item / tc, ct = item % tc;
+      for (int kb = it; kb < tiles; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
+                                                     0, 0, 0);
+      }
+    }
+    accs[idx] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int idx = 0; idx < MAXI; ++idx) {
+    const int item = wave + idx * nwave;
+    if (item < tiles * tc) {
+      const int it = item / tc, ct = item % tc;
+      double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
+      Ct[0] = accs[idx][0]; Ct[4 * xs] = accs[idx][1]; Ct[8 * xs] = accs[idx][2]; Ct[12 * xs] = accs[idx][3];
+    }
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------- separator
 // The separator of separator_generic (ndlqr_FactorInnerProduct nested_dissection.c:114-134, the
 // Cholesky of src/solve.c:87-98, ndlqr_SolveCholeskyFactor :136-152) for blocks that fill 16x16
@@ -44,6 +195,7 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
   double* Wd = X + (size_t)n * xs;  // n / 16 blocks of 16 x 17: inverses of the diagonal blocks of L
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
+  const SepGeom geo = {n, ns, xs, tiles, lane, wave, nwave, li, lk};
 
   const double* ab = AB + ((size_t)b * N + s) * n * w;
   const double* Es = Fblk(F, d, b, l, s);
@@ -90,38 +242,7 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
   }
   __syncthreads();
 
-  // ---- blocked Cholesky (different summation grouping than the reference: fast mode only)
-  for (int jb = 0; jb < tiles; ++jb) {
-    const int j0 = 16 * jb, rem = tiles - 1 - jb;
-    if (wave == 0) {
-      const bool bad = chol16_and_inverse(S + j0 * ns + j0, ns, Wd + jb * 16 * 17, lane);
-      if (bad && lane == 0) flag_failure(info, d, b);
-    }
-    __syncthreads();
-    const double* Wb = Wd + jb * 16 * 17;
-    for (int it = jb + 1 + wave; it < tiles; it += nwave) {  // L21 = A21 W'
-      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * it + li) * ns + j0 + 4 * q + lk], Wb[li * 17 + 4 * q + lk], acc,
-                                                   0, 0, 0);
-      double* Ct = S + (16 * it + lk) * ns + j0 + li;
-      Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
-    }
-    __syncthreads();
-    for (int item = wave; item < rem * rem; item += nwave) {  // trailing rank-16 update
-      const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
-      if (ct > it) continue;  // lower triangle of tiles only
-      double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
-      mfma_acc_t acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                   S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
-      Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
-    }
-    if (rem > 0) __syncthreads();
-  }
+  sep_cholesky(geo, S, Wd, info, d, b);
 
   double* outS = rec ? nullptr : Fblk(F, d, b, l, s + 1);
   double* outa = (!rec && a >= 0) ? Fblk(F, d, b, a, s + 1) : nullptr;
@@ -133,43 +254,7 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
     __syncthreads();
   }
 
-  // ---- W = L^-1, in place over the strictly lower blocks of L (diagonal blocks: Wd), block row by block
-  //      row: T_ij = sum_{k = j}^{i-1} L_ik W_kj,  W_ij = -W_ii T_ij  (j < i). With W the two triangular
-  //      sweeps of every panel chunk become two GEMMs whose tiles are all independent: 4 workgroup
-  //      barriers per chunk instead of 16 (the sweeps made this kernel barrier-bound: eight wavefronts
-  //      share 3..12 tiles per step).
-  for (int ib = 1; ib < tiles; ++ib) {
-    mfma_acc_t wij = {0.0, 0.0, 0.0, 0.0};
-    const int jb = wave;  // one tile of the block row per wavefront (host: nwave >= n / 16)
-    if (jb < ib) {
-      mfma_acc_t t = {0.0, 0.0, 0.0, 0.0};
-      for (int kb = jb; kb < ib; ++kb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double wkj = kb == jb ? Wd[jb * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * jb + li];
-          t = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * ib + li) * ns + 16 * kb + 4 * q + lk], wkj, t, 0, 0, 0);
-        }
-      }
-      // component q of an accumulator is element (4 q + lk, li): exactly the B operand of k-step q
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        wij = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[ib * 16 * 17 + li * 17 + 4 * q + lk], t[q], wij, 0, 0, 0);
-    }
-    __syncthreads();  // every L_ik of the block row has been read
-    if (jb < ib) {
-      double* Ct = S + (16 * ib + lk) * ns + 16 * jb + li;
-      Ct[0] = wij[0]; Ct[4 * ns] = wij[1]; Ct[8 * ns] = wij[2]; Ct[12 * ns] = wij[3];
-    }
-    __syncthreads();
-  }
-  // block (it, kb) of W as A operand (row li, k = 4 q + lk) and of W' (row li of W' = column of W)
-  auto w_frag = [&](const int it, const int kb, const int q) -> double {
-    return kb == it ? Wd[it * 16 * 17 + li * 17 + 4 * q + lk] : S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
-  };
-  auto wt_frag = [&](const int it, const int kb, const int q) -> double {  // W'(16 it + li, 16 kb + 4 q + lk)
-    return kb == it ? Wd[it * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
-  };
-  constexpr int MAXI = 3;  // panel tiles a wavefront may own: tiles * CT <= MAXI * nwave (checked on the host)
+  sep_invert(geo, S, Wd);
 
   // ---- the panel, CT column tiles at a time: build, X = W' (W R), store
   for (int t0 = 0; t0 < ctl; t0 += ctc) {
@@ -217,64 +302,7 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
       }
     }
     __syncthreads();
-    // Y = W R (block lower triangular), then X = W' Y: every tile of a product is independent; the
-    // wavefronts keep theirs in the accumulators across the barrier that separates reading from
-    // overwriting the panel
-    {
-      mfma_acc_t accs[MAXI];
-#pragma unroll
-      for (int idx = 0; idx < MAXI; ++idx) {
-        const int item = wave + idx * nwave;
-        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
-        if (item < tiles * tc) {
-          const int it = item / tc, ct = item % tc;
-          for (int kb = 0; kb <= it; ++kb) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
-                                                         0, 0, 0);
-          }
-        }
-        accs[idx] = acc;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int idx = 0; idx < MAXI; ++idx) {
-        const int item = wave + idx * nwave;
-        if (item < tiles * tc) {
-          const int it = item / tc, ct = item % tc;
-          double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-          Ct[0] = accs[idx][0]; Ct[4 * xs] = accs[idx][1]; Ct[8 * xs] = accs[idx][2]; Ct[12 * xs] = accs[idx][3];
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int idx = 0; idx < MAXI; ++idx) {
-        const int item = wave + idx * nwave;
-        mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
-        if (item < tiles * tc) {
-          const int it = item / tc, ct = item % tc;
-          for (int kb = it; kb < tiles; ++kb) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
-                                                         0, 0, 0);
-          }
-        }
-        accs[idx] = acc;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int idx = 0; idx < MAXI; ++idx) {
-        const int item = wave + idx * nwave;
-        if (item < tiles * tc) {
-          const int it = item / tc, ct = item % tc;
-          double* Ct = X + (16 * it + lk) * xs + 16 * ct + li;
-          Ct[0] = accs[idx][0]; Ct[4 * xs] = accs[idx][1]; Ct[8 * xs] = accs[idx][2]; Ct[12 * xs] = accs[idx][3];
-        }
-      }
-      __syncthreads();
-    }
+    sep_panel_solve(geo, S, Wd, X, tc);
     // stores of the chunk. With records (fast mode without KEEP) the lambda rows of the factor array
     // are dead data (the boundary Schur pass takes f_a, f_bb from the record): only the record and the
     // rhs entry are written.

@@ -11,6 +11,7 @@
 #include "hip_context.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_mfma.hpp"
+#include "kernels_reduced_mfma.hpp"
 #ifdef NDLQR_SINGLE_TU  // developer builds (tools/segtime.py): every instance in this translation unit
 #include "launch_small.hpp"
 #endif
@@ -181,7 +182,7 @@ static bool ensure_alt(NdlqrHipCtx* c) {
             hipEventCreate(&a.ev_start) == hipSuccess && hipEventCreate(&a.ev_stop) == hipSuccess &&
             hipMalloc(&a.rec, bytes_rec(d)) == hipSuccess && hipMalloc(&a.z, bytes_z(d)) == hipSuccess &&
             hipHostMalloc((void**)&a.h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
-  if (ok && c->red)
+  if (ok && c->tree_cnt)  // size-specialised shapes (the runtime-sized schedule's slots: ensure_red_generic)
     ok = hipMalloc(&a.red, red_bytes) == hipSuccess && hipMemsetAsync(a.red, 0, red_bytes, a.stream) == hipSuccess &&
          hipMalloc(&a.ytop, sizeof(double) * (size_t)d.batch * (d.N / 8) * d.n) == hipSuccess &&
          hipMalloc(&a.tree_cnt, cnt_bytes) == hipSuccess && hipMemsetAsync(a.tree_cnt, 0, cnt_bytes, a.stream) == hipSuccess;
@@ -313,6 +314,77 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
 // lean (fast mode without KEEP): the Schur passes only keep the boundary knots of every subtree
 // up to date, the solution comes from the back-substitution over the separator records.
 constexpr int kSepChunkTiles = 3;  // column tiles of the right-hand-side panel resident in LDS (separator_mfma)
+
+// Separator-only schedule for blocks that fill 16x16 matrix-core tiles (kernels_reduced_mfma.hpp): workgroup
+// size and LDS of separator_reduced_mfma, or false when the shape does not qualify (-> generic-lean).
+struct ReducedGenericPlan {
+  bool ok;
+  int threads;
+  size_t lds;
+};
+static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  ReducedGenericPlan p = {false, 0, 0};
+  if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_KEEP_RECORDS)) return p;
+  if (c->no_mfma || d.n % 16 != 0 || d.w % 4 != 0 || d.N < 2) return p;
+  const int tiles = d.n / 16, ctl = 2 * tiles + 1, ctc = ctl < kSepChunkTiles ? ctl : kSepChunkTiles;
+  int threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 32 ? 512 : 256);
+  // a wavefront per tile of a block row of W, at most three panel tiles and five S-bar tiles per wavefront
+  int need = tiles;
+  if ((tiles * ctc + 2) / 3 > need) need = (tiles * ctc + 2) / 3;
+  if ((tiles * tiles + 4) / 5 > need) need = (tiles * tiles + 4) / 5;
+  if (threads < 64 * need) threads = 64 * need;
+  if (threads > 1024) return p;
+  const size_t panel = (size_t)d.n * (d.n + 1) + (size_t)d.n * (16 * ctc + 1);
+  if ((size_t)d.n * ndlqr::reduced_stage_pitch(d.w) > panel) return p;  // the staged [A | B] lies over S and the chunk
+  p.lds = sizeof(double) * (panel + (size_t)d.n * 17 + 2 * (size_t)d.w + 2 * (size_t)d.n);
+  if (p.lds > 160 * 1024) return p;
+  p.threads = threads;
+  p.ok = true;
+  return p;
+}
+
+static size_t bytes_red_generic(const ndlqr::Dims& d) {
+  return sizeof(double) * (size_t)d.batch * (d.N / 2) * (4 * (size_t)d.n * d.n + 2 * d.n);
+}
+
+// slots of the separators of level >= 1 (runtime-sized separator-only schedule); allocated by the first
+// solve that takes it, for both buffer sets of the pipeline. Never zeroed: the level-0 launch stores
+// every accumulator block. Must run outside stream capture.
+static int ensure_red_generic(NdlqrHipCtx* c) {
+  if (c->d.N < 4) return NDLQR_OK;  // a single separator: no slots
+  for (int which = 0; which < 2; ++which) {
+    double** slot = which == 0 ? &c->red : &c->alt.red;
+    if (*slot || (which == 1 && !c->alt.ready)) continue;
+    if (hipMalloc(slot, bytes_red_generic(c->d)) != hipSuccess) {
+      *slot = nullptr;
+      (void)hipGetLastError();
+      g_last_error = "accumulator slots of the separator-only schedule do not fit on the device";
+      return NDLQR_ERR_INVALID;
+    }
+  }
+  return NDLQR_OK;
+}
+
+static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
+  const ndlqr::Dims& d = c->d;
+  c->schedule = "generic-reduced";
+  for (int l = 0; l < d.K; ++l) {
+    ScopedSlot t(c, SLOT_SEP);
+    hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<kSepChunkTiles>), dim3(d.N >> (l + 1), d.batch), dim3(p.threads),
+                       p.lds, c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);
+  }
+  {
+    ScopedSlot t(c, SLOT_APPLY);
+    for (int l = d.K - 1; l >= 0; --l)
+      hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
+                         d, l, c->rec, c->z);
+    const int work = d.N * d.rows;
+    hipLaunchKernelGGL(ndlqr::backsub_states_generic, dim3((work + 255) / 256, d.batch), dim3(256), 0, c->stream, d,
+                       c->AB, c->QR, c->rhs, c->z);
+  }
+  return NDLQR_OK;
+}
 
 template <bool STRICT>
 static int launch_generic(NdlqrHipCtx* c, bool lean) {
@@ -468,7 +540,7 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
 // does the launch sequence enqueue_solve is about to issue touch the factor array?
 static bool solve_needs_F(const NdlqrHipCtx* c) {
   const SmallInstance* inst = pick_small(c);
-  if (!inst) return true;  // the runtime-sized kernels work on F
+  if (!inst) return !plan_reduced_generic(c).ok;  // the other runtime-sized kernels work on F
   return inst->needs_F(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0) != 0;
 }
 
@@ -482,8 +554,10 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   c->rec_complete = false;
   done = try_launch_small(c, strict, &err);
   if (!done) {
+    const ReducedGenericPlan rp = plan_reduced_generic(c);
     const bool lean = !strict && !(c->flags & NDLQR_FLAG_KEEP_FACT);
-    err = strict ? launch_generic<true>(c, false) : launch_generic<false>(c, lean);
+    if (rp.ok) err = launch_reduced_generic(c, rp);
+    else err = strict ? launch_generic<true>(c, false) : launch_generic<false>(c, lean);
   }
   // the batch-wide failure count travels to pinned host memory behind the last kernel: the host
   // reads it after the stream synchronisation without another blocking copy
@@ -498,6 +572,7 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
     const int ferr = ndlqr_hip_ensure_F(c);
     if (ferr) return ferr;
   }
+  const bool red_generic = !pick_small(c) && plan_reduced_generic(c).ok;
   if (c->state_dirty) {
     // the previous solve did not launch or complete: its arrival counters may be odd and its failure
     // words meaningless -- start from zero (the kernels themselves leave both clean)
@@ -520,6 +595,10 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
                          !(c->flags & (NDLQR_FLAG_PROFILE | NDLQR_FLAG_KEEP_RECORDS | NDLQR_FLAG_KEEP_FACT));
   const bool want_alt = pipelined && (c->solve_count & 1u) && ensure_alt(c);
   if (!pipelined && c->alt.stream) HIP_TRY(hipStreamSynchronize(c->in_alt ? c->stream : c->alt.stream));
+  if (red_generic) {  // (after ensure_alt: both buffer sets get their slots)
+    const int rerr = ensure_red_generic(c);
+    if (rerr) return rerr;
+  }
   if (want_alt != c->in_alt) swap_slot(c);
   ++c->solve_count;
   c->state_dirty = true;  // until this solve is known to have been enqueued completely

@@ -129,6 +129,29 @@ def generic_lean_model(n, m, N):
     return out
 
 
+def generic_reduced_model(n, m, N):
+    """Separator-only schedule of the tile-filling block sizes (separator_reduced_mfma once per level,
+    back-substitution over the records): config 5's path since round 2."""
+    K = int(math.log2(N))
+    w, rows = n + m, 2 * n + m
+    rec = 2 * n * n + n
+    slot = 4 * n * n + 2 * n
+    push = 3 * n * n + 2 * n           # DR + gR, DL + gL, one coupling block
+    sep_b = 0
+    for l in range(K):
+        L = N >> (l + 1)
+        own = n * w + (w + n) + (rows + 2 * n)              # [A_s | B_s], weights and rhs of knots s, s+1
+        if l == 0:
+            sep_b += L * (own + n * n + rec + push)         # + A_{s+1} (r_bb); the pushes are stores
+        else:
+            sep_b += L * (own + slot + rec + push + (2 * n * n + 2 * n))  # + own slot; the pushes read-modify-write
+    return {
+        "separator": {"bytes": 8 * sep_b, "flops": (N - 1) * separator_flops(n, w), "launches": K},
+        "apply": {"bytes": 8 * ((N - 1) * rec + inputs_doubles(n, m, N) + N * rows),
+                  "flops": backsub_flops(n, m, N), "launches": 1},  # K + 1 launches inside ONE event bracket
+    }
+
+
 def model_for(schedule, n, m, N):
     """Per-slot model of the named launch sequence (ndlqr_hip_schedule), or None when this file has no
     model for it (strict / KEEP schedules stream the whole factor array: model (B) is their roofline)."""
@@ -140,6 +163,8 @@ def model_for(schedule, n, m, N):
         return knot_lean_model(n, m, N)
     if schedule == "generic-lean":
         return generic_lean_model(n, m, N)
+    if schedule == "generic-reduced":
+        return generic_reduced_model(n, m, N)
     return None
 
 
