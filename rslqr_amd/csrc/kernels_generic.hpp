@@ -19,6 +19,7 @@
 //     divisions -- the very operations the reference executes on the non-zero entries.
 #pragma once
 #include "kernels_common.hpp"
+#include "kernels_dpp.hpp"
 #include "kernels_leaf.hpp"
 
 namespace ndlqr {
@@ -36,8 +37,8 @@ namespace ndlqr {
 // (Fast mode with n a multiple of 16 and n+m of 4 runs separator_mfma of kernels_mfma.hpp instead: the
 // same separator on v_mfma_f64_16x16x4_f64, blocked by 16 columns.)
 // Fast path of the blocked separator: lower Cholesky of one 16x16 diagonal block AND the inverse
-// of that factor by ONE wavefront in registers (lanes 0..15 own a row, then a column; broadcasts
-// with v_readlane, no barrier). With W = L11^-1 the panel below the block, the block rows of the
+// of that factor by ONE wavefront in registers (lanes 0..15 own a row, then a column; row broadcasts
+// inside the FMAs, no barrier). With W = L11^-1 the panel below the block, the block rows of the
 // right-hand sides and their transposed counterparts all become 16x16 matrix-core products, so a
 // 16-column block costs a handful of workgroup barriers instead of three per pivot.
 // Sblk = &S[j0 * ns + j0] (LDS, row pitch ns), Wblk: 16 x 16, row pitch 17 (LDS).
@@ -46,31 +47,10 @@ __device__ __forceinline__ bool chol16_and_inverse(double* Sblk, const int ns, d
   double acc[16], w[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) acc[c] = Sblk[r * ns + c];
-  // Left-looking Cholesky, one row per lane, fused with the forward substitution of the unit
-  // vectors (lane c: column c of W = L11^-1): step j broadcasts row j of L once and uses it for
-  // both (see factor_solve_mc in kernels_bottom_reduced.hpp)
-  double rinv_last = 0.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double v = acc[j], sacc = (j == r) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const double bc = readlane_f64(acc[k], j);
-      v = fma(-acc[k], bc, v);
-      sacc = fma(-bc, w[k], sacc);
-    }
-    const double pivot = readlane_f64(v, j);
-    // 1 / sqrt(pivot): hardware estimate + one Newton step; a non-positive pivot turns into NaN
-    // and stays NaN through every later pivot: one test after the last step
-    const double y0 = __builtin_amdgcn_rsq(pivot);
-    const double e = fma(-pivot * y0, y0, 1.0);
-    const double rinv = fma(y0 * e, 0.5, y0);
-    acc[j] = v * rinv;
-    w[j] = sacc * rinv;
-    rinv_last = rinv;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const bool bad = !((rinv_last > 0.0) & (rinv_last < 1.0e300));
+  // Left-looking Cholesky, one row per lane of every 16-lane DPP row (the four rows of the wavefront
+  // repeat it), fused with the forward substitution of the unit vectors (lane c: column c of
+  // W = L11^-1): step j takes row j of L from lane j inside the FMAs (rb_chol_inv, kernels_dpp.hpp)
+  const bool bad = rb_chol_inv<16>(r, acc, w);
   {  // every lane stores (lanes >= 16, replicas, into the pad column): a store under a lane
      // predicate makes the compiler sink the W recurrence behind it, away from the broadcasts
     const int wc = lane < 16 ? lane : 16;

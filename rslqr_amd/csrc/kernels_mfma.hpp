@@ -26,6 +26,31 @@ struct SepGeom {
 };
 constexpr int kSepMaxPanelTiles = 3;  // panel tiles a wavefront may own: tiles * CT <= 3 nwave (checked on the host)
 
+// Four k-steps of a tile product: acc += A B with the operand fragments already in registers.
+__device__ __forceinline__ mfma_acc_t mfma4(const double (&a)[4], const double (&b)[4], mfma_acc_t acc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+  return acc;
+}
+
+// acc += sum_{kb = kb0}^{kb1 - 1} A_kb B_kb (16 x 16 blocks, four k-steps each); load(kb, a, b) fetches the
+// operand fragments of block kb from LDS. The fragments of block kb + 1 are requested before the products
+// of block kb are issued, so that only the first block pays the LDS round trip.
+template <class Load>
+__device__ __forceinline__ mfma_acc_t block_chain(mfma_acc_t acc, const int kb0, const int kb1, Load load) {
+  if (kb0 >= kb1) return acc;
+  double a0[4], b0[4];
+  load(kb0, a0, b0);
+  for (int kb = kb0; kb < kb1; ++kb) {
+    double a1[4], b1[4];
+    load(kb + 1 < kb1 ? kb + 1 : kb, a1, b1);
+    acc = mfma4(a0, b0, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a0[q] = a1[q]; b0[q] = b1[q]; }
+  }
+  return acc;
+}
+
 // Blocked Cholesky of S (lower triangle; different summation grouping than the reference: fast mode
 // only): diagonal block + its inverse by one wavefront (chol16_and_inverse), the panel below it and the
 // trailing update as rank-16 matrix-core products.
@@ -41,11 +66,10 @@ __device__ __forceinline__ void sep_cholesky(const SepGeom& g, double* S, double
     __syncthreads();
     const double* Wb = Wd + jb * 16 * 17;
     for (int it = jb + 1 + g.wave; it < tiles; it += g.nwave) {  // L21 = A21 W'
-      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+      double a[4], bw[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * it + li) * ns + j0 + 4 * q + lk], Wb[li * 17 + 4 * q + lk], acc,
-                                                   0, 0, 0);
+      for (int q = 0; q < 4; ++q) { a[q] = S[(16 * it + li) * ns + j0 + 4 * q + lk]; bw[q] = Wb[li * 17 + 4 * q + lk]; }
+      const mfma_acc_t acc = mfma4(a, bw, mfma_acc_t{0.0, 0.0, 0.0, 0.0});
       double* Ct = S + (16 * it + lk) * ns + j0 + li;
       Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
     }
@@ -54,11 +78,11 @@ __device__ __forceinline__ void sep_cholesky(const SepGeom& g, double* S, double
       const int it = jb + 1 + item / rem, ct = jb + 1 + item % rem;
       if (ct > it) continue;  // lower triangle of tiles only
       double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
-      mfma_acc_t acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
+      double a[4], bl[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[(16 * it + li) * ns + j0 + 4 * q + lk],
-                                                   S[(16 * ct + li) * ns + j0 + 4 * q + lk], acc, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) { a[q] = -S[(16 * it + li) * ns + j0 + 4 * q + lk]; bl[q] = S[(16 * ct + li) * ns + j0 + 4 * q + lk]; }
+      mfma_acc_t acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
+      acc = mfma4(a, bl, acc);
       Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
     }
     if (rem > 0) __syncthreads();
@@ -76,18 +100,19 @@ __device__ __forceinline__ void sep_invert(const SepGeom& g, double* S, const do
     mfma_acc_t wij = {0.0, 0.0, 0.0, 0.0};
     const int jb = g.wave;
     if (jb < ib) {
-      mfma_acc_t t = {0.0, 0.0, 0.0, 0.0};
-      for (int kb = jb; kb < ib; ++kb) {
+      const mfma_acc_t t = block_chain(mfma_acc_t{0.0, 0.0, 0.0, 0.0}, jb, ib, [&](const int kb, double (&a)[4], double (&bw)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const double wkj = kb == jb ? Wd[jb * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * jb + li];
-          t = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * ib + li) * ns + 16 * kb + 4 * q + lk], wkj, t, 0, 0, 0);
+          a[q] = S[(16 * ib + li) * ns + 16 * kb + 4 * q + lk];
+          bw[q] = kb == jb ? Wd[jb * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * jb + li];
         }
-      }
+      });
       // component q of an accumulator is element (4 q + lk, li): exactly the B operand of k-step q
+      double wd[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        wij = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[ib * 16 * 17 + li * 17 + 4 * q + lk], t[q], wij, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) wd[q] = -Wd[ib * 16 * 17 + li * 17 + 4 * q + lk];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wij = __builtin_amdgcn_mfma_f64_16x16x4f64(wd[q], t[q], wij, 0, 0, 0);
     }
     __syncthreads();  // every L_ik of the block row has been read
     if (jb < ib) {
@@ -106,13 +131,6 @@ __device__ __forceinline__ void sep_panel_solve(const SepGeom& g, const double* 
                                                 const int tc) {
   const int ns = g.ns, xs = g.xs, tiles = g.tiles, li = g.li, lk = g.lk, wave = g.wave, nwave = g.nwave;
   constexpr int MAXI = kSepMaxPanelTiles;
-  // block (it, kb) of W as A operand (row li, k = 4 q + lk) and of W' (row li of W' = column of W)
-  auto w_frag = [&](const int it, const int kb, const int q) -> double {
-    return kb == it ? Wd[it * 16 * 17 + li * 17 + 4 * q + lk] : S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
-  };
-  auto wt_frag = [&](const int it, const int kb, const int q) -> double {  // W'(16 it + li, 16 kb + 4 q + lk)
-    return kb == it ? Wd[it * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
-  };
   mfma_acc_t accs[MAXI];
 #pragma unroll
   for (int idx = 0; idx < MAXI; ++idx) {
@@ -120,12 +138,14 @@ __device__ __forceinline__ void sep_panel_solve(const SepGeom& g, const double* 
     mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
     if (item < tiles * tc) {
       const int it = item / tc, ct = item % tc;
-      for (int kb = 0; kb <= it; ++kb) {
+      // block (it, kb) of W as A operand (row li, k = 4 q + lk)
+      acc = block_chain(acc, 0, it + 1, [&](const int kb, double (&a)[4], double (&bx)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
-                                                     0, 0, 0);
-      }
+        for (int q = 0; q < 4; ++q) {
+          a[q] = kb == it ? Wd[it * 16 * 17 + li * 17 + 4 * q + lk] : S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
+          bx[q] = X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li];
+        }
+      });
     }
     accs[idx] = acc;
   }
@@ -146,12 +166,14 @@ __device__ __forceinline__ void sep_panel_solve(const SepGeom& g, const double* 
     mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
     if (item < tiles * tc) {
       const int it = item / tc, ct = item % tc;
-      for (int kb = it; kb < tiles; ++kb) {
+      // block (it, kb) of W': W'(16 it + li, 16 kb + 4 q + lk) = W(16 kb + 4 q + lk, 16 it + li)
+      acc = block_chain(acc, it, tiles, [&](const int kb, double (&a)[4], double (&bx)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt_frag(it, kb, q), X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li], acc,
-                                                     0, 0, 0);
-      }
+        for (int q = 0; q < 4; ++q) {
+          a[q] = kb == it ? Wd[it * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
+          bx[q] = X[(16 * kb + 4 * q + lk) * xs + 16 * ct + li];
+        }
+      });
     }
     accs[idx] = acc;
   }
@@ -193,7 +215,7 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
   double* S = sm;
   double* X = S + n * ns;
   double* Wd = X + (size_t)n * xs;  // n / 16 blocks of 16 x 17: inverses of the diagonal blocks of L
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwave = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const SepGeom geo = {n, ns, xs, tiles, lane, wave, nwave, li, lk};
 

@@ -326,20 +326,15 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   ReducedGenericPlan p = {false, 0, 0};
   if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_KEEP_RECORDS)) return p;
-  if (c->no_mfma || d.n % 16 != 0 || d.w % 4 != 0 || d.N < 2) return p;
+  if (c->no_mfma || d.n % 16 != 0 || d.n > 64 || d.w % 4 != 0 || d.N < 2) return p;
   const int tiles = d.n / 16, ctl = 2 * tiles + 1, ctc = ctl < kSepChunkTiles ? ctl : kSepChunkTiles;
-  int threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 32 ? 512 : 256);
-  // a wavefront per tile of a block row of W, at most three panel tiles and five S-bar tiles per wavefront
-  int need = tiles;
-  if ((tiles * ctc + 2) / 3 > need) need = (tiles * ctc + 2) / 3;
-  if ((tiles * tiles + 4) / 5 > need) need = (tiles * tiles + 4) / 5;
-  if (threads < 64 * need) threads = 64 * need;
-  if (threads > 1024) return p;
   const size_t panel = (size_t)d.n * (d.n + 1) + (size_t)d.n * (16 * ctc + 1);
   if ((size_t)d.n * ndlqr::reduced_stage_pitch(d.w) > panel) return p;  // the staged [A | B] lies over S and the chunk
+  if (2 * (size_t)d.n * (d.n + 1) > panel + (size_t)d.n * 17) return p;     // r_a, r_bb of the push phase over S, chunk, Wd
+  p.threads = d.n >= 48 ? 512 : 256;
+  if (d.w + d.n > p.threads) return p;                                      // one weight / rhs entry per thread
   p.lds = sizeof(double) * (panel + (size_t)d.n * 17 + 2 * (size_t)d.w + 2 * (size_t)d.n);
   if (p.lds > 160 * 1024) return p;
-  p.threads = threads;
   p.ok = true;
   return p;
 }
@@ -371,8 +366,23 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
   c->schedule = "generic-reduced";
   for (int l = 0; l < d.K; ++l) {
     ScopedSlot t(c, SLOT_SEP);
-    hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<kSepChunkTiles>), dim3(d.N >> (l + 1), d.batch), dim3(p.threads),
-                       p.lds, c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);
+    const dim3 grid(d.N >> (l + 1), d.batch);
+#define NDLQR_LAUNCH_SEP(NB_, NT_)                                                                              \
+  do {                                                                                                          \
+    if (l == 0)                                                                                                 \
+      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, kSepChunkTiles, true>), grid, dim3(NT_), p.lds, \
+                         c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);                       \
+    else                                                                                                        \
+      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, kSepChunkTiles, false>), grid, dim3(NT_), p.lds, \
+                         c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);                       \
+  } while (0)
+    switch (d.n / 16) {
+      case 1: NDLQR_LAUNCH_SEP(1, 256); break;
+      case 2: NDLQR_LAUNCH_SEP(2, 256); break;
+      case 3: NDLQR_LAUNCH_SEP(3, 512); break;
+      default: NDLQR_LAUNCH_SEP(4, 512); break;
+    }
+#undef NDLQR_LAUNCH_SEP
   }
   {
     ScopedSlot t(c, SLOT_APPLY);
