@@ -57,6 +57,14 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Orders LDS accesses of ONE wavefront: the DS unit executes a wavefront's operations in order,
+// so a compiler-level barrier plus draining the LDS counter is enough (no s_barrier).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Developer instrumentation (tools/segtime.py; never defined in the shipped build): cycles spent
 // between consecutive marks, summed over lane 0 of every wavefront, per segment id.
 #ifdef NDLQR_SEGTIME

@@ -38,48 +38,67 @@ __device__ __forceinline__ double* reduced_slot(double* red, const Dims& d, cons
 // matrix-core operand fetch touches (lane li: row, lk: four consecutive doubles) fall into disjoint banks
 __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 == 4) ? w : w + 4; }
 
-// NB = n / 16, NTHR threads (a multiple of 64), CT column tiles of the panel resident at a time.
-//   grid (N >> (l+1), batch), block NTHR;  host (plan_reduced_generic): NTHR / 64 >= NB,
-//   dynamic LDS = n (n + 1) + n (16 min(CT, 2 NB + 1) + 1) + 17 n + 2 (n + m) + 2 n doubles; the staged
-//   [A_s | B_s] (n rows of reduced_stage_pitch(w)) and later r_a | r_bb (2 n (n + 1)) lie over the first arrays.
+// NB = n / 16, NTHR threads (a multiple of 64, at least 64 NB).
+//   grid (N >> (l+1), batch), block NTHR;
+//   dynamic LDS = reduced_lds_doubles(n, w) doubles: the weights / rhs arrays, then a region that first holds the
+//   staged [A_s | B_s] (n rows of reduced_stage_pitch(w)), then S-bar / L / W (n x (n + 1)), the inverses of the
+//   diagonal blocks (17 n) and r_bb (n x (n + 1)); r_a goes over S-bar once W is dead. 77 KB at (64,16): two
+//   workgroups per CU.
 // LEVEL0: the launch of tree level 0 (couplings from the problem data, pushes are stores).
 //
-// Written for memory-level parallelism: every global operand is requested as early as its address is
-// known and consumed as late as possible (the slot blocks DL, DR, gL, gR and the first panel chunk at
-// kernel entry, the next panel chunk under the products of the current one), loads are unconditional
-// on clamped indices and LDS stores likewise (a store under a lane predicate makes the compiler sink its
-// load behind the predicate, and the loads then complete one after the other), and the matrix-core
-// loops fetch the operand fragments of several k-steps before the first product.
-template <int NB, int NTHR, int CT, bool LEVEL0>
+// Phases (workgroup barriers only between them):
+//   A  stage [A_s | B_s]; leafS tiles on the matrix cores; S-bar = leafS - DL - DR + Q_{s+1}^-1 into LDS; blocked
+//      Cholesky; blocked inverse W = L^-1 (sep_cholesky, sep_invert of kernels_mfma.hpp)
+//   B  the 2 NB column tiles of [r_a | r_bb] are dealt to the wavefronts (the column b~: vector ALU). A wavefront takes
+//      the operand fragments of its tile straight from global memory, forms Y = W R and X = W'Y in the
+//      accumulators -- an accumulator tile is at once the B operand of the next product, so nothing goes through
+//      LDS and nobody waits for anybody -- stores X into the record and KEEPS it in registers
+//   C  r_a into LDS over the dead S-bar / W, from the registers of phase B (r_bb went into its own array there):
+//      no operand is fetched twice
+//   D  pushes: the wavefront that holds column tile c of f_a forms DR[A](:, c) = r_a' f_a(:, c) and half of the
+//      coupling tiles of its rows (r_a' S-bar^-1 r_bb = f_a' r_bb), the one that holds tile c of f_bb forms
+//      DL[B](:, c) and the other half (r_a' f_bb): six tile products each, the solved operand from registers
+// Written for memory-level parallelism: loads are unconditional on clamped indices and requested as early as
+// their address is known, LDS stores likewise (a store under a lane predicate makes the compiler sink its load
+// behind the predicate, and the loads then complete one after the other).
+__host__ __device__ inline int reduced_lds_doubles(const int n, const int w) {
+  int big = n * reduced_stage_pitch(w);                 // staged [A_s | B_s]
+  const int later = n * (n + 1) + 17 * n + n * (n + 1);  // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
+  if (later > big) big = later;
+  return 2 * w + 2 * n + big;
+}
+
+template <int NB, int NTHR, bool LEVEL0>
 __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
                                                                   const double* __restrict__ rhs, double* red,
                                                                   double* __restrict__ rec, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  constexpr int n = 16 * NB, nn = n * n, ns = n + 1, tiles = NB, ctl = 2 * NB + 1;  // column tiles: f_a, f_bb, [z_sep | padding]
-  constexpr int ctc = ctl < CT ? ctl : CT, xs = 16 * ctc + 1, NW = NTHR / 64;
-  constexpr int MAXS = (NB * NB + NW - 1) / NW;        // S-bar tiles per wavefront
-  constexpr int PT = (16 * n + NTHR - 1) / NTHR;       // panel elements per thread and column tile
-  constexpr int PR = n + 1;                            // pitch of r_a, r_bb in the push phase
-  static_assert(NW >= NB && NB * ctc <= kSepMaxPanelTiles * NW && n / 4 <= 16, "work distribution of the shared phases");
+  constexpr int n = 16 * NB, nn = n * n, ns = n + 1, CTL = 2 * NB + 1;  // column tiles: f_a, f_bb, [z_sep | padding]
+  constexpr int NW = NTHR / 64;
+  constexpr int MAXS = (NB * NB + NW - 1) / NW;  // S-bar tiles per wavefront
+  constexpr int MAXT = (2 * NB + NW - 1) / NW;   // panel column tiles (of r_a, r_bb) per wavefront
+  constexpr int PR = n + 1;                      // pitch of r_a, r_bb in the push phase
+  static_assert(NW >= NB && n / 4 <= 16, "work distribution of the shared phases");
   const int w = d.w, N = d.N, rows = d.rows;
   const int b = blockIdx.y;
   const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
   const bool hasA = base > 0, hasB = base + T < N, leftchild = (base & T) == 0, first = s == 0;
-  double* S = sm;
-  double* X = S + n * ns;
-  double* Wd = X + n * xs;   // NB blocks of 16 x 17: inverses of the diagonal blocks of L
-  double* dq = Wd + n * 17;  // 1 / [Q_s | R_s]  (state entries of knot 0: zero -- its state is fixed)
+  double* dq = sm;           // 1 / [Q_s | R_s]  (state entries of knot 0: zero -- its state is fixed)
   double* zc = dq + w;       // rhs(s).xu scaled likewise (state entries of knot 0: -x0)
   double* q1 = zc + w;       // 1 / Q_{s+1}
-  double* bz = q1 + n;       // b~
-  double* stage = sm;        // [A_s | B_s], pitch P, over S and X until S-bar is formed
+  double* bz = q1 + n;       // b~, later z_sep
+  double* S = bz + n;        // S-bar / L / W
+  double* Wd = S + n * ns;   // NB blocks of 16 x 17: inverses of the diagonal blocks of L
+  double* stage = S;         // [A_s | B_s], pitch P, until S-bar is formed
+  double* Ra = S;            // r_a (pitch PR) once W is dead
+  double* Rb = Wd + 17 * n;  // r_bb (pitch PR), written in phase B
   const int P = reduced_stage_pitch(w);
   const int tid = threadIdx.x;
   // (the wavefront index as a scalar: everything that depends on it branches uniformly)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const SepGeom geo = {n, ns, xs, tiles, lane, wave, NW, li, lk};
+  const SepGeom geo = {n, ns, 0, NB, lane, wave, NW, li, lk};
   SEG_INIT();
 
   const double* ab = AB + ((size_t)b * N + s) * n * w;   // [A_s | B_s]
@@ -92,58 +111,26 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nn + n);
   const int ksteps = w / 4;
 
-  // ---- panel elements: thread -> (row i, column cl) of a column tile. Level 0 takes r_bb from the rows of
-  //      A_{s+1} (sixteen consecutive row indices = one 128-byte line of a row of A_{s+1} per sixteen lanes).
-  //      fetch = the raw global operand (uniform branches only), write = what enters the panel.
-  auto panel_index = [&](const int gt, const int e, int& i, int& cl) {
-    if (LEVEL0 && gt >= tiles && gt < 2 * tiles) { i = ((e >> 8) << 4) | (e & 15); cl = (e >> 4) & 15; }
-    else { i = e >> 4; cl = e & 15; }
-  };
-  auto panel_fetch = [&](const int t0, double (&pf)[ctc * PT]) {
-#pragma unroll
-    for (int t = 0; t < ctc; ++t) {
-      const int gt = t0 + t;
-#pragma unroll
-      for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * NTHR, ec = e < 16 * n ? e : 16 * n - 1;
-        int i, cl;
-        panel_index(gt, ec, i, cl);
-        double v = 0.0;
-        if (gt < tiles) {
-          if (hasA) v = LEVEL0 ? ab[(size_t)i * w + 16 * gt + cl] : myslot[2 * nn + i * n + 16 * gt + cl];
-        } else if (gt < 2 * tiles) {
-          const int c = 16 * (gt - tiles) + cl;
-          if (hasB) v = LEVEL0 ? ab1[(size_t)c * w + i] : myslot[3 * nn + i * n + c];
-        }
-        pf[t * PT + u] = v;
-      }
-    }
-  };
-  auto panel_write = [&](const int t0, const double (&pf)[ctc * PT]) {
-#pragma unroll
-    for (int t = 0; t < ctc; ++t) {
-      const int gt = t0 + t;
-      if (gt >= ctl) continue;
-#pragma unroll
-      for (int u = 0; u < PT; ++u) {
-        const int e = tid + u * NTHR, ec = e < 16 * n ? e : 16 * n - 1;  // (surplus threads rewrite the last element)
-        int i, cl;
-        panel_index(gt, ec, i, cl);
-        const double raw = pf[t * PT + u];
-        double v;
-        if (gt < tiles) v = LEVEL0 ? -raw * dq[16 * gt + cl] : -raw;
-        else if (gt < 2 * tiles) v = LEVEL0 ? -raw * q1[i] : -raw;
-        else v = cl == 0 ? bz[i] : 0.0;
-        X[i * xs + 16 * t + cl] = v;
-      }
-    }
-  };
-
+  // ================================================================================================= phase A
   // ---- requests at kernel entry: [A_s | B_s] and the weights / rhs of knots s, s + 1
   const int words = n * w / 2;               // 16-byte words of [A_s | B_s]
   const float inv_w = 1.0f / (float)w;
   const int kc = tid < w ? tid : w - 1, ic = tid < n ? tid : n - 1;
   const double qv = qr[kc], q1v = qr[w + ic], rxu = r0[n + kc], rl0 = r0[ic], za = r0[rows + ic], zb = r0[rows + n + ic];
+  // DL + DR of this wavefront's S-bar tiles and gL + gR: consumed behind the leafS products
+  double dlr[MAXS][8];
+#pragma unroll
+  for (int idx = 0; idx < MAXS; ++idx) {
+    const int item = wave + idx * NW, itc = item < NB * NB ? item : NB * NB - 1, rt = itc / NB, ct = itc % NB;
+    const double* p = myslot + (size_t)(16 * rt + lk) * n + 16 * ct + li;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      dlr[idx][gg] = LEVEL0 ? 0.0 : p[4 * gg * n];
+      dlr[idx][4 + gg] = LEVEL0 ? 0.0 : p[nn + 4 * gg * n];
+    }
+  }
+  double gl = 0.0, gr = 0.0;
+  if (!LEVEL0) { gl = myslot[4 * nn + ic]; gr = myslot[4 * nn + n + ic]; }
   // ---- stage [A_s | B_s] (rows of pitch P; n = 64, w = 80: one round) and the diagonal weights / rhs of knots s, s + 1
   constexpr int SG = 5;
   for (int e0 = 0; e0 < words; e0 += SG * NTHR) {
@@ -167,24 +154,6 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     zc[kc] = fx ? -rl0 : rxu * inv;
     q1[ic] = 1.0 / q1v;
   }
-  // requests of the later phases (the staging registers are free again): DL + DR of this wavefront's S-bar
-  // tiles and gL + gR (consumed behind the S-bar products), the first panel chunk
-  double dlr[MAXS][8];
-#pragma unroll
-  for (int idx = 0; idx < MAXS; ++idx) {
-    const int item = wave + idx * NW, itc = item < NB * NB ? item : NB * NB - 1, rt = itc / NB, ct = itc % NB;
-    const double* p = myslot + (size_t)(16 * rt + lk) * n + 16 * ct + li;
-#pragma unroll
-    for (int gg = 0; gg < 4; ++gg) {
-      dlr[idx][gg] = LEVEL0 ? 0.0 : p[4 * gg * n];
-      dlr[idx][4 + gg] = LEVEL0 ? 0.0 : p[nn + 4 * gg * n];
-    }
-  }
-  double gl = 0.0, gr = 0.0;
-  if (!LEVEL0) { gl = myslot[4 * nn + ic]; gr = myslot[4 * nn + n + ic]; }
-  double pf[ctc * PT];
-  panel_fetch(0, pf);
-
   __syncthreads();
   SEG(50);
 
@@ -219,28 +188,35 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
           sacc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[idx][c], bf[idx][c] * dv[c], sacc[idx], 0, 0, 0);
     }
   }
-  // b~ = [A_s | B_s] zc - z(s+1).lambda - z(s+1).x / Q_{s+1} - gL - gR   (threads < n; the others repeat row n - 1)
-  double bt;
-  {
-    const double* arow = stage + ic * P;
-    double acc = -fma(zb, q1[ic], za);
-    for (int k0 = 0; k0 < w; k0 += 8) {
-      double av[8], zv[8];
+  // b~ = [A_s | B_s] zc - z(s+1).lambda - z(s+1).x / Q_{s+1} - gL - gR: eight lanes per row (lane = (row, k mod 8):
+  // at most two-way bank conflicts where a row per lane has eight-way ones), rows dealt to the wavefronts
+  for (int i0 = 8 * wave; i0 < n; i0 += 8 * NW) {
+    const int i = i0 + (lane >> 3);
+    const double* arow = stage + i * P + (lane & 7);
+    double acc = 0.0;
+    for (int k0 = 0; k0 < w; k0 += 32) {
+      double av[4], zv[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = k0 + u < w ? k0 + u : w - 1;
-        av[u] = arow[k];
-        zv[u] = k0 + u < w ? zc[k] : 0.0;
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 8 * u + (lane & 7), kk = k < w ? k : w - 1;
+        av[u] = arow[kk - (lane & 7)];
+        zv[u] = k < w ? zc[kk] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc = fma(av[u], zv[u], acc);
+      for (int u = 0; u < 4; ++u) acc = fma(av[u], zv[u], acc);
     }
-    bt = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if ((lane & 7) == 0) bz[i] = acc;  // (bz is not read before the barrier below)
   }
   __syncthreads();
   SEG(51);
-  bz[ic] = bt - (gl + gr);
-  if (ctl > ctc) panel_write(0, pf);  // the staged block is dead: the first chunk (no b~ column in it) goes into the panel
+  {
+    // (an unconditional use of the early requests: under the predicate alone the compiler would sink the loads there)
+    const double corr = fma(zb, q1[ic], za) + (gl + gr);
+    if (tid < n) bz[tid] -= corr;
+  }
 #pragma unroll
   for (int idx = 0; idx < MAXS; ++idx) {
     const int item = wave + idx * NW;
@@ -259,133 +235,238 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 
   sep_cholesky(geo, S, Wd, info, d, b);
   SEG(53);
+  // the column tile(s) of [r_a | r_bb] this wavefront will solve: requested here, consumed behind the inverse
+  // (not before the Cholesky: its diagonal-block wavefront needs the registers, and a spilled load waits)
+  double rfk[MAXT][NB][4];  // element (16 kb + 4 q + lk, 16 c + li) of r_a / r_bb (raw operand until phase B)
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m) {
+    const int gt = wave + m * NW, gc = gt < 2 * NB ? gt : 2 * NB - 1, c = gc < NB ? gc : gc - NB;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 16 * kb + 4 * q + lk;
+        // (unconditional: a coupling block that does not exist is a valid address with arbitrary content,
+        //  masked in phase B.) level 0: r_bb(k, j) = -A_{s+1}(j, k) / Q_{s+1}(k)
+        if (gc < NB) rfk[m][kb][q] = LEVEL0 ? ab[(size_t)k * w + 16 * c + li] : myslot[2 * nn + k * n + 16 * c + li];
+        else rfk[m][kb][q] = LEVEL0 ? ab1[(size_t)(16 * c + li) * w + k] : myslot[3 * nn + k * n + 16 * c + li];
+      }
+  }
+
   sep_invert(geo, S, Wd);
   SEG(54);
-
-  // ---- the panel, CT column tiles at a time: build, X = W' (W R), record
-  for (int t0 = 0; t0 < ctl; t0 += ctc) {
-    const int tc = ctl - t0 < ctc ? ctl - t0 : ctc;
-    if (t0 > 0 || ctl <= ctc) panel_write(t0, pf);  // (the first chunk of a chunked panel is in place already)
-    // the next chunk: in flight under the products of this one (not earlier: registers that wait for a load
-    // across the Cholesky get spilled, and the spill waits for the load)
-    if (t0 + ctc < ctl) panel_fetch(t0 + ctc, pf);
-    if (t0 > 0 || ctl <= ctc) __syncthreads();
-    SEG(55);
-    sep_panel_solve(geo, S, Wd, X, tc);
-    SEG(56);
-    // record f_a | f_bb | z_sep (what the back-substitution reads -- and the push phase below): the chunk's
-    // elements dealt to the threads, LDS reads first, then the stores
-    {
-      constexpr int RE = (16 * ctc * n + NTHR - 1) / NTHR;  // element e: column e & 15 of tile (e >> 4) / n, row (e >> 4) % n
-      double v[RE];
+  // ---- z_sep = W'(W b~) on the vector ALU, all wavefronts: eight rows per wavefront, eight lanes per row (a
+  //      seventeenth column does not pay a matrix-core tile, and one wavefront alone would keep the others waiting)
+  auto w_ptr = [&](const int r, const int cidx) -> const double* {  // &W(r, cidx), cidx <= r
+    return (r >> 4) == (cidx >> 4) ? Wd + (r >> 4) * 16 * 17 + (r & 15) * 17 + (cidx & 15) : S + r * ns + cidx;
+  };
+  for (int i0 = 8 * wave; i0 < n; i0 += 8 * NW) {  // y = W b~
+    const int i = i0 + (lane >> 3), sg = lane & 7;
+    double wv[n / 8], bv[n / 8];
 #pragma unroll
-      for (int u = 0; u < RE; ++u) {
-        const int e = tid + u * NTHR, ec = e < 16 * tc * n ? e : 16 * tc * n - 1;
-        const int t = (ec >> 4) / n, i = (ec >> 4) % n;
-        v[u] = X[i * xs + 16 * t + (ec & 15)];
-      }
+    for (int u = 0; u < n / 8; ++u) {
+      const int k = sg + 8 * u, kk = k <= i ? k : i;  // (above the diagonal: a valid address, weight zero)
+      wv[u] = *w_ptr(i, kk);
+      bv[u] = bz[k];
+    }
+    double acc = 0.0;
 #pragma unroll
-      for (int u = 0; u < RE; ++u) {
-        const int e = tid + u * NTHR;
-        const int t = (e >> 4) / n, i = (e >> 4) % n, gt = t0 + t, cl = e & 15;  // (t is uniform over a wavefront: 64 | 16 n)
-        if (e < 16 * tc * n) {
-          if (gt < tiles) { if (hasA) myrec[i * n + 16 * gt + cl] = v[u]; }
-          else if (gt < 2 * tiles) { if (hasB) myrec[nn + i * n + 16 * (gt - tiles) + cl] = v[u]; }
-          else if (cl == 0) myrec[2 * nn + i] = v[u];
+    for (int u = 0; u < n / 8; ++u) acc = fma(sg + 8 * u <= i ? wv[u] : 0.0, bv[u], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sg == 0) zc[i] = acc;  // (zc is dead since the leafS products)
+  }
+  __syncthreads();
+  double zsep = 0.0;  // lanes with sg == 0: z_sep(i) of the row they reduced
+  int zrow = -1;
+  for (int i0 = 8 * wave; i0 < n; i0 += 8 * NW) {  // z_sep = W'y
+    const int i = i0 + (lane >> 3), sg = lane & 7;
+    double wv[n / 8], yv[n / 8];
+#pragma unroll
+    for (int u = 0; u < n / 8; ++u) {
+      const int k = sg + 8 * u, kk = k >= i ? k : i;
+      wv[u] = *w_ptr(kk, i);
+      yv[u] = zc[k];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < n / 8; ++u) acc = fma(sg + 8 * u >= i ? wv[u] : 0.0, yv[u], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sg == 0) { myrec[2 * nn + i] = acc; zsep = acc; zrow = i; }
+  }
+  // ================================================================================================= phase B
+  // Column tile gt of the panel: [0, NB) columns of r_a, [NB, 2 NB) of r_bb. xk[m][kb][q] =
+  // X(16 kb + 4 q + lk, 16 c + li): accumulator tile kb of the solved column tile -- as it stands the B operand
+  // of k-steps 4 kb .. 4 kb + 3 (and, transposed, the A operand) of the push products.
+  mfma_acc_t xk[MAXT][NB];
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m) {
+    const int gt = wave + m * NW;
+    double (&rf)[NB][4] = rfk[m];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      xk[m][kb] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+    }
+    if (gt >= 2 * NB) continue;
+    const int c = gt < NB ? gt : gt - NB;
+    if (gt < NB) {
+      const double dj = dq[16 * c + li];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rf[kb][q] = !hasA ? 0.0 : LEVEL0 ? -rf[kb][q] * dj : -rf[kb][q];
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rf[kb][q] = !hasB ? 0.0 : LEVEL0 ? -rf[kb][q] * q1[16 * kb + 4 * q + lk] : -rf[kb][q];
+          Rb[(16 * kb + 4 * q + lk) * PR + 16 * c + li] = rf[kb][q];  // operand of the push phase
         }
+    }
+    // Y = W R: block lower triangular; block (it, kb) of W as A operand (row li, k = 4 q + lk)
+    mfma_acc_t y[NB];
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kb = 0; kb <= it; ++kb) {
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          a[q] = kb == it ? Wd[it * 16 * 17 + li * 17 + 4 * q + lk] : S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
+        acc = mfma4(a, rf[kb], acc);
       }
+      y[it] = acc;
     }
-    __syncthreads();  // the next chunk overwrites the panel
-    SEG(57);
+    // X = W'Y: block (it, kb) of W' -- W'(16 it + li, 16 kb + 4 q + lk) = W(16 kb + 4 q + lk, 16 it + li); the
+    // accumulator tile y[kb] is the B operand as it stands
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kb = it; kb < NB; ++kb) {
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          a[q] = kb == it ? Wd[it * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], y[kb][q], acc, 0, 0, 0);
+      }
+      xk[m][it] = acc;
+    }
+    // record f_a | f_bb | z_sep (what the back-substitution reads): rows 16 it + lk + 4 g, columns 16 c + li
+    if (gt < NB ? hasA : hasB) {
+      double* dst = myrec + (gt < NB ? 0 : nn) + (size_t)lk * n + 16 * c + li;
+#pragma unroll
+      for (int it = 0; it < NB; ++it)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) dst[(size_t)(16 * it + 4 * gg) * n] = xk[m][it][gg];
+    }
   }
+  SEG(55);
+  __syncthreads();  // S-bar / W and b~ are dead
+  SEG(56);
 
-  // ---- pushes. S-bar / W, the panel chunk and the diagonal-block inverses are dead: r_a and r_bb (n x n each,
-  //      pitch n + 1) take their place in LDS and serve as matrix-core operands; the solved blocks come back
-  //      from the record this workgroup has just written (L2), all k-steps of a column tile per request round.
-  //      unit (X column tile, coupling block) -> NB output tiles:
-  //        [0, NB)        f_a tile,  r_a:   DR[A] += r_a' f_a
-  //        [NB, 2 NB)     f_bb tile, r_bb:  DL[B] += r_bb' f_bb
-  //        [2 NB, 3 NB)   f_bb tile, r_a:   CA[B] = f_bb' r_a (left child)  or  CB[A] = r_a' f_bb
-  //        3 NB           z_sep, r_a:       gR[A] += r_a' z_sep
-  //        3 NB + 1       z_sep, r_bb:      gL[B] += r_bb' z_sep
-  double* Ra = sm;
-  double* Rb = sm + n * PR;
-  {
-    constexpr int RS = (nn + NTHR - 1) / NTHR;
-    double ta[RS], tb[RS];
+  // ================================================================================================= phase C
 #pragma unroll
-    for (int u = 0; u < RS; ++u) {
-      const int e = tid + u * NTHR, ec = e < nn ? e : nn - 1, hi = ec / n, lo = ec % n;
-      ta[u] = 0.0; tb[u] = 0.0;
-      if (hasA) ta[u] = LEVEL0 ? ab[(size_t)hi * w + lo] : myslot[2 * nn + ec];
-      // level 0: r_bb(k, j) = -A_{s+1}(j, k) / Q_{s+1}(k): walk the rows of A_{s+1} (k fastest)
-      if (hasB) tb[u] = LEVEL0 ? ab1[(size_t)hi * w + lo] : myslot[3 * nn + ec];
-    }
+  for (int m = 0; m < MAXT; ++m) {
+    const int gt = wave + m * NW;
+    if (gt < NB) {
 #pragma unroll
-    for (int u = 0; u < RS; ++u) {
-      const int e = tid + u * NTHR, ec = e < nn ? e : nn - 1, hi = ec / n, lo = ec % n;
-      Ra[hi * PR + lo] = LEVEL0 ? -ta[u] * dq[lo] : -ta[u];
-      if (LEVEL0) Rb[lo * PR + hi] = -tb[u] * q1[lo];
-      else Rb[hi * PR + lo] = -tb[u];
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Ra[(16 * kb + 4 * q + lk) * PR + 16 * gt + li] = rfk[m][kb][q];
     }
   }
-  __threadfence_block();
+  // z_sep for the vector pushes (b~ is dead: the barrier above)
+  if (zrow >= 0) bz[zrow] = zsep;
   __syncthreads();
   SEG(58);
-  for (int unit = wave; unit < 3 * NB + 2; unit += NW) {
-    const int grp = unit < 3 * NB ? unit / NB : 3 + (unit - 3 * NB);  // 0 DR, 1 DL, 2 coupling, 3 gR, 4 gL
-    const int ct = unit < 3 * NB ? unit % NB : 0;
-    const bool use_ra = grp == 0 || grp == 2 || grp == 3;
-    if (use_ra && !hasA) continue;
-    if ((grp == 1 || grp == 2 || grp == 4) && !hasB) continue;
-    const bool vec = grp >= 3;
-    const bool xa = grp == 2 && leftchild;  // the solved tile is the A operand (CA = f_bb' r_a)
-    const double* Rl = (use_ra ? Ra : Rb) + lk * PR + li;
-    // destination: tile (orow, ocol) of an n x n block (row pitch n), or sixteen entries of a vector
-    double* dstb = grp == 0 ? slotA + nn : grp == 1 ? slotB : grp == 2 ? (leftchild ? slotB + 2 * nn : slotA + 3 * nn)
-                 : grp == 3 ? slotA + 4 * nn + n : slotB + 4 * nn;
-    const bool accumulate = !LEVEL0 && grp != 2;
-    const int pstep = vec ? 4 : 4 * n;
-    // operand fragments of the solved column tile (all n / 4 k-steps) and the tiles to be updated: one request round
-    double xf[n / 4];
-    mfma_acc_t acc[NB];
-    {
-      const double* xsrc = vec ? myrec + 2 * nn + lk : myrec + (grp == 0 ? 0 : nn) + (size_t)lk * n + 16 * ct + li;
+
+  // ================================================================================================= phase D
+  // tile product of the push phase: acc (+)= R(:, 16 rt ..)' X  (xa: X' R(:, 16 rt ..)), R from LDS, X from registers
+  const mfma_acc_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  auto push_tile = [&](const double* Rl, const int rt, const mfma_acc_t (&x)[NB], const bool xa, double* dst,
+                       mfma_acc_t acc) {
+    // dst: element (lk, li) of the destination tile, row pitch n; acc: what the tile starts from
+    const double* rl = Rl + lk * PR + 16 * rt + li;
+    double rv[n / 4];
 #pragma unroll
-      for (int q = 0; q < n / 4; ++q) xf[q] = vec ? xsrc[4 * q] : xsrc[(size_t)4 * q * n];
+    for (int q = 0; q < n / 4; ++q) rv[q] = rl[4 * q * PR];
+    if (xa) {
 #pragma unroll
-      for (int rt = 0; rt < NB; ++rt) {
-        const int orow = xa ? ct : rt, ocol = xa ? rt : ct;
-        const double* p = vec ? dstb + 16 * rt + lk : dstb + (size_t)(16 * orow + lk) * n + 16 * ocol + li;
+      for (int q = 0; q < n / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q / 4][q % 4], rv[q], acc, 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) acc[rt][gg] = accumulate ? p[gg * pstep] : 0.0;
-      }
-      if (vec) {
-#pragma unroll
-        for (int q = 0; q < n / 4; ++q) xf[q] = li == 0 ? xf[q] : 0.0;
-      }
+      for (int q = 0; q < n / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[q], x[q / 4][q % 4], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int rt = 0; rt < NB; ++rt) {
-      const double* rl = Rl + 16 * rt;
-      double rv[n / 4];
+    for (int gg = 0; gg < 4; ++gg) dst[(size_t)4 * gg * n] = acc[gg];
+  };
 #pragma unroll
-      for (int q = 0; q < n / 4; ++q) rv[q] = rl[4 * q * PR];
-      if (xa) {
+  for (int m = 0; m < MAXT; ++m) {
+    const int gt = wave + m * NW;
+    if (gt >= 2 * NB) continue;
+    const int c = gt < NB ? gt : gt - NB;
+    if (gt < NB ? !hasA : !hasB) continue;
+    // the tiles the accumulating pushes start from (DR[A](:, tile c) / DL[B](:, tile c)): requested first, consumed
+    // behind the coupling tiles
+    double* pd = (gt < NB ? slotA + nn : slotB) + (size_t)lk * n + 16 * c + li;
+    mfma_acc_t pacc[NB];
 #pragma unroll
-        for (int q = 0; q < n / 4; ++q) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[q], rv[q], acc[rt], 0, 0, 0);
-      } else {
+    for (int rt = 0; rt < NB; ++rt)
 #pragma unroll
-        for (int q = 0; q < n / 4; ++q) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[q], xf[q], acc[rt], 0, 0, 0);
+      for (int gg = 0; gg < 4; ++gg) pacc[rt][gg] = LEVEL0 ? 0.0 : pd[(size_t)(16 * rt + 4 * gg) * n];
+    if (gt < NB) {
+      // coupling tiles (a-tile c, bb-tile j), c + j even:  r_a' S-bar^-1 r_bb = f_a' r_bb
+      if (hasB) {
+        for (int j = c & 1; j < NB; j += 2) {
+          if (leftchild)  // CA[B] = (f_a' r_bb)' = r_bb' f_a: rows bb-tile j, columns a-tile c
+            push_tile(Rb, j, xk[m], false, slotB + 2 * nn + (size_t)(16 * j + lk) * n + 16 * c + li, zero4);
+          else            // CB[A] = f_a' r_bb: rows a-tile c, columns bb-tile j
+            push_tile(Rb, j, xk[m], true, slotA + 3 * nn + (size_t)(16 * c + lk) * n + 16 * j + li, zero4);
+        }
       }
+      // DR[A](:, tile c) += r_a' f_a(:, tile c)
+#pragma unroll
+      for (int rt = 0; rt < NB; ++rt) push_tile(Ra, rt, xk[m], false, pd + (size_t)16 * rt * n, pacc[rt]);
+    } else {
+      // coupling tiles (a-tile i, bb-tile c), i + c odd:  r_a' f_bb
+      if (hasA) {
+        for (int i = (c & 1) ^ 1; i < NB; i += 2) {
+          if (leftchild)  // CA[B] = (r_a' f_bb)' = f_bb' r_a: rows bb-tile c, columns a-tile i
+            push_tile(Ra, i, xk[m], true, slotB + 2 * nn + (size_t)(16 * c + lk) * n + 16 * i + li, zero4);
+          else            // CB[A] = r_a' f_bb: rows a-tile i, columns bb-tile c
+            push_tile(Ra, i, xk[m], false, slotA + 3 * nn + (size_t)(16 * i + lk) * n + 16 * c + li, zero4);
+        }
+      }
+      // DL[B](:, tile c) += r_bb' f_bb(:, tile c)
+#pragma unroll
+      for (int rt = 0; rt < NB; ++rt) push_tile(Rb, rt, xk[m], false, pd + (size_t)16 * rt * n, pacc[rt]);
     }
+  }
+  // vector pushes gR[A] += r_a' z_sep (first wavefront), gL[B] += r_bb' z_sep (last): a column of r per lane
+  if ((wave == 0 && hasA) || (wave == NW - 1 && hasB)) {
+    const bool ga = wave == 0 && hasA;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 0 ? !ga : !(wave == NW - 1 && hasB)) continue;
+      const double* R = pass == 0 ? Ra : Rb;
+      double* dst = pass == 0 ? slotA + 4 * nn + n : slotB + 4 * nn;
+      for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane < n ? j0 + lane : n - 1;
+        double acc = LEVEL0 ? 0.0 : dst[j];
+        for (int k0 = 0; k0 < n; k0 += 8) {
+          double rv[8], zv[8];
 #pragma unroll
-    for (int rt = 0; rt < NB; ++rt) {
-      const int orow = xa ? ct : rt, ocol = xa ? rt : ct;
-      double* p = vec ? dstb + 16 * rt + lk : dstb + (size_t)(16 * orow + lk) * n + 16 * ocol + li;
-      if (!vec || li == 0) {
+          for (int u = 0; u < 8; ++u) { rv[u] = R[(k0 + u) * PR + j]; zv[u] = bz[k0 + u]; }
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) p[gg * pstep] = acc[rt][gg];
+          for (int u = 0; u < 8; ++u) acc = fma(rv[u], zv[u], acc);
+        }
+        if (j0 + lane < n) dst[j] = acc;
       }
     }
   }

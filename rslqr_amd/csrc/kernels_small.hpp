@@ -23,13 +23,6 @@
 
 namespace ndlqr {
 
-// Orders LDS accesses of ONE wavefront: the DS unit executes a wavefront's operations in order,
-// so a compiler-level barrier plus draining the LDS counter is enough (no s_barrier).
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-  __builtin_amdgcn_wave_barrier();
-}
 
 
 // One factor-block row (NX doubles, 16-byte aligned when NX is even) <-> registers, as

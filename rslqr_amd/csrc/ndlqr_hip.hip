@@ -327,13 +327,9 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   ReducedGenericPlan p = {false, 0, 0};
   if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_KEEP_RECORDS)) return p;
   if (c->no_mfma || d.n % 16 != 0 || d.n > 64 || d.w % 4 != 0 || d.N < 2) return p;
-  const int tiles = d.n / 16, ctl = 2 * tiles + 1, ctc = ctl < kSepChunkTiles ? ctl : kSepChunkTiles;
-  const size_t panel = (size_t)d.n * (d.n + 1) + (size_t)d.n * (16 * ctc + 1);
-  if ((size_t)d.n * ndlqr::reduced_stage_pitch(d.w) > panel) return p;  // the staged [A | B] lies over S and the chunk
-  if (2 * (size_t)d.n * (d.n + 1) > panel + (size_t)d.n * 17) return p;     // r_a, r_bb of the push phase over S, chunk, Wd
   p.threads = d.n >= 48 ? 512 : 256;
-  if (d.w + d.n > p.threads) return p;                                      // one weight / rhs entry per thread
-  p.lds = sizeof(double) * (panel + (size_t)d.n * 17 + 2 * (size_t)d.w + 2 * (size_t)d.n);
+  if (d.w + d.n > p.threads) return p;  // one weight / rhs entry per thread
+  p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(d.n, d.w);
   if (p.lds > 160 * 1024) return p;
   p.ok = true;
   return p;
@@ -370,10 +366,10 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
 #define NDLQR_LAUNCH_SEP(NB_, NT_)                                                                              \
   do {                                                                                                          \
     if (l == 0)                                                                                                 \
-      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, kSepChunkTiles, true>), grid, dim3(NT_), p.lds, \
+      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, true>), grid, dim3(NT_), p.lds, \
                          c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);                       \
     else                                                                                                        \
-      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, kSepChunkTiles, false>), grid, dim3(NT_), p.lds, \
+      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, false>), grid, dim3(NT_), p.lds, \
                          c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);                       \
   } while (0)
     switch (d.n / 16) {

@@ -37,8 +37,8 @@ NAMES = {0: "level: stage operands", 1: "level core: P1", 2: "level core: P2 (Ch
          44: "generic separator: stores + drain",
          50: "reduced sep: stage [A|B], weights", 51: "reduced sep: leafS products + b~ (+ barrier)",
          52: "reduced sep: S-bar write-out (slot loads) + barrier", 53: "reduced sep: blocked Cholesky",
-         54: "reduced sep: blocked inverse", 55: "reduced sep: panel build + barrier", 56: "reduced sep: X = W'(W R)",
-         57: "reduced sep: record stores + barrier", 58: "reduced sep: stage r_a, r_bb + barrier", 59: "reduced sep: pushes",
+         54: "reduced sep: blocked inverse", 55: "reduced sep: column tiles X = W'(W R) + record (own work)", 56: "reduced sep: barrier behind the column tiles",
+         58: "reduced sep: stage r_a, r_bb + barrier", 59: "reduced sep: pushes",
          25: "bottom: row update + rotate", 26: "bottom: barrier end of level", 27: "bottom: hand-off"}
 
 
@@ -66,6 +66,8 @@ def main():
     n, m, N, batch = 12, 4, 256, 1024
     if "--config5" in sys.argv:
         n, m, N, batch = 64, 16, 512, 64
+    if "--horizon" in sys.argv:
+        N = int(sys.argv[sys.argv.index("--horizon") + 1])
     if "--batch" in sys.argv:
         batch = int(sys.argv[sys.argv.index("--batch") + 1])
     bs = rslqr_amd.BatchSolver(n, m, N, batch)
