@@ -153,6 +153,10 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     dq[kc] = fx ? 0.0 : inv;
     zc[kc] = fx ? -rl0 : rxu * inv;
     q1[ic] = 1.0 / q1v;
+    // the weights of knot s pass through exactly this separator (those of the last knot: Q through separator
+    // N - 2, its R is not part of the problem): a non-positive one fails the Cholesky of Q_k / R_k in the reference
+    // (src/nested_dissection.c:24-59) -- counted here, S-bar itself may well stay positive definite
+    if ((tid < w && !(qv > 0.0)) || (s == N - 2 && tid < n && !(q1v > 0.0))) flag_failure(info, d, b);
   }
   __syncthreads();
   SEG(50);

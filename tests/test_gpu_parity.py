@@ -166,6 +166,41 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
         bs.close()
 
 
+@pytest.mark.parametrize("n,m,N,batch", [(16, 4, 2, 2), (16, 4, 4, 3), (32, 8, 8, 2), (48, 12, 64, 2), (64, 16, 128, 3),
+                                         (64, 16, 512, 1)])
+def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch):
+    """Blocks that fill 16x16 matrix-core tiles take the separator-only schedule (kernels_reduced_mfma.hpp:
+    one launch per tree level, no factor array), down to a single separator (N = 2). Consecutive solves
+    alternate between the two buffer sets of the pipeline and replay the captured graph: every one of them
+    has to reproduce the oracle. A non-positive weight is reported like on every other path."""
+    probs = [synth(ndlqr, n, m, N, 1300 + p) for p in range(batch)]
+    refs = [oracle.solve(prob, 1)[0][: prob.nvars] for prob in probs]
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*stack(probs))
+    for _ in range(4):
+        assert bs.solve() == 0
+        assert bs.schedule() == "generic-reduced"
+        sol = bs.solutions()
+        for p, prob in enumerate(probs):
+            assert np.linalg.norm(sol[p] - refs[p]) / np.linalg.norm(refs[p]) <= REL_TOL
+    res, bnorm = bs.kkt_residuals()
+    assert np.all(res <= 1e-9 * np.maximum(1.0, bnorm))
+    # strict mode and KEEP_FACT leave the schedule (they need the factor array)
+    bs.set_flags(ndlqr.FLAG_KEEP_FACT)
+    assert bs.solve() == 0 and bs.schedule() == "generic-keep"
+    assert np.linalg.norm(bs.solution(0) - refs[0]) / np.linalg.norm(refs[0]) <= REL_TOL
+    bs.close()
+    if N >= 4:
+        bad = probs[0]
+        R = bad.R.copy()
+        R[N // 2, 0] = -1.0
+        bs = ndlqr.BatchSolver(n, m, N, 1)
+        bs.initialize_flat(*[np.asarray(a)[None] for a in (bad.A, bad.B, bad.Q, R, bad.q, bad.r, bad.d, bad.x0)])
+        assert bs.solve() == -3
+        assert bs.cholesky_failures() >= 1
+        bs.close()
+
+
 def test_non_spd_block_is_reported(ndlqr):
     """A non-positive R entry: the reference's Cholesky fails silently (src/linalg.c:80-85,
     src/solve.c:189); here the solve returns NDLQR_ERR_NOT_SPD and counts the failure."""
