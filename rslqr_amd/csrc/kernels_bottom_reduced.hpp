@@ -633,7 +633,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
       l = l + 1;
       base = left ? base : base - T;
       wave_lds_sync();
-      reduced_separator_mc<NX, NU, true>(d, l, base, b, lane, AB, QR, rhs, red, rec, F, info, store_l, lds);
+      // (the lane id is made opaque per round: otherwise every lane-dependent address of the body is hoisted out of
+      //  the loop -- 45 VGPRs of them ended up in scratch memory)
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      reduced_separator_mc<NX, NU, true>(d, l, base, b, lane_s, AB, QR, rhs, red, rec, F, info, store_l, lds);
     }
   }
 }
