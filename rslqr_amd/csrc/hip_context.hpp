@@ -42,6 +42,7 @@ struct NdlqrAltSlot {
   bool ready = false;
   double* rec = nullptr;
   double* red = nullptr;
+  size_t red_bytes = 0;
   double* ytop = nullptr;
   double* z = nullptr;
   int* tree_cnt = nullptr;
@@ -51,6 +52,7 @@ struct NdlqrAltSlot {
   unsigned graph_flags = 0;
   hipStream_t graph_stream = nullptr;
   bool graph_rec_complete = false;
+  const char* graph_schedule = "none";
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
@@ -67,7 +69,8 @@ struct NdlqrHipCtx {
   double* z;
   double* rec;  // [batch][N][2 n^2 + n] separator records f_a | f_bb | z_sep
   double* ytop; // [batch][N/8][n] multipliers of the separators of level >= 3 (rb_backsub_top -> rb_backsub)
-  double* red;  // [batch][N/4][4 n^2 + 2 n] accumulators of the separator-only schedule (size-specialised shapes)
+  double* red;  // accumulators of the separator-only schedules: [batch][N/4][slot] (size-specialised shapes, allocated with the context) or [batch][N/2][4 n^2 + 2 n] (runtime-sized schedule, on its first solve)
+  size_t red_bytes;
   int rowbcast;  // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom): NDLQR_ROWBCAST=1 always, 0 never (bottom_reduced_mc), unset (-1): by block size
   int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
   int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; zero between solves (reset by the root's wavefront)
@@ -87,6 +90,7 @@ struct NdlqrHipCtx {
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
   bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)
+  const char* graph_schedule;  // and its name
   int sep_threads;    // NDLQR_SEP_THREADS: workgroup size of the matrix-core separator (0 = by block size)
   hipEvent_t ev_start, ev_stop;
   bool timing_pending;

@@ -38,7 +38,7 @@ __device__ __forceinline__ double* reduced_slot(double* red, const Dims& d, cons
 // matrix-core operand fetch touches (lane li: row, lk: four consecutive doubles) fall into disjoint banks
 __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 == 4) ? w : w + 4; }
 
-// NB = n / 16, NTHR threads (a multiple of 64, at least 64 NB).
+// NB = ceil(n / 16), NTHR threads (a multiple of 64, at least 64 NB and max(16 NB, n + m rounded up to 4)).
 //   grid (N >> (l+1), batch), block NTHR;
 //   dynamic LDS = reduced_lds_doubles(n, w) doubles: the weights / rhs arrays, then a region that first holds the
 //   staged [A_s | B_s] (n rows of reduced_stage_pitch(w)), then S-bar / L / W (n x (n + 1)), the inverses of the
@@ -65,35 +65,39 @@ __host__ __device__ inline int reduced_lds_doubles(const int n, const int w) {
   int big = n * reduced_stage_pitch(w);                 // staged [A_s | B_s]
   const int later = n * (n + 1) + 17 * n + n * (n + 1);  // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
   if (later > big) big = later;
-  return 2 * w + 2 * n + big;
+  return w + (w > n ? w : n) + 2 * n + big;  // dq (w), zc (later y of the z column: max(w, n)), q1, b~ (n each)
 }
 
-template <int NB, int NTHR, bool LEVEL0>
+template <int NB, int NTHR, bool LEVEL0, bool PAD>
 __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
                                                                   const double* __restrict__ rhs, double* red,
                                                                   double* __restrict__ rec, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  constexpr int n = 16 * NB, nn = n * n, ns = n + 1, CTL = 2 * NB + 1;  // column tiles: f_a, f_bb, [z_sep | padding]
+  constexpr int n = 16 * NB, ns = n + 1;
   constexpr int NW = NTHR / 64;
   constexpr int MAXS = (NB * NB + NW - 1) / NW;  // S-bar tiles per wavefront
   constexpr int MAXT = (2 * NB + NW - 1) / NW;   // panel column tiles (of r_a, r_bb) per wavefront
   constexpr int PR = n + 1;                      // pitch of r_a, r_bb in the push phase
   static_assert(NW >= NB && n / 4 <= 16, "work distribution of the shared phases");
-  const int w = d.w, N = d.N, rows = d.rows;
+  // PAD: the block does not fill its tiles (nl < n rows / columns, or n + m not a multiple of 4). Everything in
+  // global memory keeps the problem's own pitch nl; LDS holds the padded tiles: zero rows / columns of [A | B], r_a,
+  // r_bb, DL, DR, unit diagonal of S-bar (so L, W are the identity there and the padding never reaches a result).
+  const int nl = PAD ? d.n : n, nnl = nl * nl;
+  const int w = d.w, wp = PAD ? (w + 3) / 4 * 4 : w, N = d.N, rows = d.rows;
   const int b = blockIdx.y;
   const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
   const bool hasA = base > 0, hasB = base + T < N, leftchild = (base & T) == 0, first = s == 0;
   double* dq = sm;           // 1 / [Q_s | R_s]  (state entries of knot 0: zero -- its state is fixed)
-  double* zc = dq + w;       // rhs(s).xu scaled likewise (state entries of knot 0: -x0)
-  double* q1 = zc + w;       // 1 / Q_{s+1}
+  double* zc = dq + wp;      // rhs(s).xu scaled likewise (state entries of knot 0: -x0)
+  double* q1 = zc + (wp > n ? wp : n);  // 1 / Q_{s+1}  (zc doubles as the y of the z column: n entries)
   double* bz = q1 + n;       // b~, later z_sep
   double* S = bz + n;        // S-bar / L / W
   double* Wd = S + n * ns;   // NB blocks of 16 x 17: inverses of the diagonal blocks of L
   double* stage = S;         // [A_s | B_s], pitch P, until S-bar is formed
   double* Ra = S;            // r_a (pitch PR) once W is dead
   double* Rb = Wd + 17 * n;  // r_bb (pitch PR), written in phase B
-  const int P = reduced_stage_pitch(w);
+  const int P = reduced_stage_pitch(wp);
   const int tid = threadIdx.x;
   // (the wavefront index as a scalar: everything that depends on it branches uniformly)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,62 +105,93 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   const SepGeom geo = {n, ns, 0, NB, lane, wave, NW, li, lk};
   SEG_INIT();
 
-  const double* ab = AB + ((size_t)b * N + s) * n * w;   // [A_s | B_s]
-  const double* ab1 = ab + (size_t)n * w;                 // [A_{s+1} | B_{s+1}]  (s + 1 <= N - 1)
+  const double* ab = AB + ((size_t)b * N + s) * nl * w;  // [A_s | B_s]
+  const double* ab1 = ab + (size_t)nl * w;                // [A_{s+1} | B_{s+1}]  (s + 1 <= N - 1)
   const double* qr = QR + ((size_t)b * N + s) * w;
   const double* r0 = rhs + ((size_t)b * N + s) * rows;
   const double* myslot = reduced_slot(red, d, b, LEVEL0 ? 1 : s);  // (not read at level 0)
   double* slotA = reduced_slot(red, d, b, hasA ? base - 1 : 1);
   double* slotB = reduced_slot(red, d, b, hasB ? base + T - 1 : 1);
-  double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nn + n);
-  const int ksteps = w / 4;
+  double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nnl + nl);
+  const int ksteps = wp / 4;
 
   // ================================================================================================= phase A
   // ---- requests at kernel entry: [A_s | B_s] and the weights / rhs of knots s, s + 1
-  const int words = n * w / 2;               // 16-byte words of [A_s | B_s]
-  const float inv_w = 1.0f / (float)w;
-  const int kc = tid < w ? tid : w - 1, ic = tid < n ? tid : n - 1;
-  const double qv = qr[kc], q1v = qr[w + ic], rxu = r0[n + kc], rl0 = r0[ic], za = r0[rows + ic], zb = r0[rows + n + ic];
+  const int kc = tid < w ? tid : w - 1, ic = tid < nl ? tid : nl - 1;
+  const double qv = qr[kc], q1v = qr[w + ic], rxu = r0[nl + kc], rl0 = r0[ic], za = r0[rows + ic], zb = r0[rows + nl + ic];
   // DL + DR of this wavefront's S-bar tiles and gL + gR: consumed behind the leafS products
   double dlr[MAXS][8];
 #pragma unroll
   for (int idx = 0; idx < MAXS; ++idx) {
     const int item = wave + idx * NW, itc = item < NB * NB ? item : NB * NB - 1, rt = itc / NB, ct = itc % NB;
-    const double* p = myslot + (size_t)(16 * rt + lk) * n + 16 * ct + li;
+    const int jc = 16 * ct + li < nl ? 16 * ct + li : nl - 1;  // (clamped addresses; the padding is masked at the use)
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
-      dlr[idx][gg] = LEVEL0 ? 0.0 : p[4 * gg * n];
-      dlr[idx][4 + gg] = LEVEL0 ? 0.0 : p[nn + 4 * gg * n];
+      const int i = 16 * rt + lk + 4 * gg, icl = i < nl ? i : nl - 1;
+      dlr[idx][gg] = LEVEL0 ? 0.0 : myslot[(size_t)icl * nl + jc];
+      dlr[idx][4 + gg] = LEVEL0 ? 0.0 : myslot[nnl + (size_t)icl * nl + jc];
     }
   }
   double gl = 0.0, gr = 0.0;
-  if (!LEVEL0) { gl = myslot[4 * nn + ic]; gr = myslot[4 * nn + n + ic]; }
+  if (!LEVEL0) { gl = myslot[4 * nnl + ic]; gr = myslot[4 * nnl + nl + ic]; }
   // ---- stage [A_s | B_s] (rows of pitch P; n = 64, w = 80: one round) and the diagonal weights / rhs of knots s, s + 1
-  constexpr int SG = 5;
-  for (int e0 = 0; e0 < words; e0 += SG * NTHR) {
-    double2 st[SG];
+  if constexpr (!PAD) {
+    const int words = n * w / 2;  // 16-byte words of [A_s | B_s]
+    const float inv_w = 1.0f / (float)w;
+    constexpr int SG = 5;
+    for (int e0 = 0; e0 < words; e0 += SG * NTHR) {
+      double2 st[SG];
 #pragma unroll
-    for (int u = 0; u < SG; ++u) {
-      const int e = e0 + tid + u * NTHR;
-      st[u] = reinterpret_cast<const double2*>(ab)[e < words ? e : words - 1];
+      for (int u = 0; u < SG; ++u) {
+        const int e = e0 + tid + u * NTHR;
+        st[u] = reinterpret_cast<const double2*>(ab)[e < words ? e : words - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        const int e = e0 + tid + u * NTHR, ec = e < words ? e : words - 1;
+        const int row = (int)(((float)(2 * ec) + 0.5f) * inv_w), col = 2 * ec - row * w;
+        *reinterpret_cast<double2*>(stage + row * P + col) = st[u];
+      }
     }
+  } else {
+    // every element of the padded block, zeros outside the nl x w data
+    const int total = n * P;
+    const float inv_p = 1.0f / (float)P;
+    constexpr int SG = 8;
+    for (int e0 = 0; e0 < total; e0 += SG * NTHR) {
+      double st[SG];
 #pragma unroll
-    for (int u = 0; u < SG; ++u) {
-      const int e = e0 + tid + u * NTHR, ec = e < words ? e : words - 1;
-      const int row = (int)(((float)(2 * ec) + 0.5f) * inv_w), col = 2 * ec - row * w;
-      *reinterpret_cast<double2*>(stage + row * P + col) = st[u];
+      for (int u = 0; u < SG; ++u) {
+        const int e = e0 + tid + u * NTHR, ec = e < total ? e : total - 1;
+        const int row = (int)(((float)ec + 0.5f) * inv_p), col = ec - row * P;
+        st[u] = ab[(size_t)(row < nl ? row : nl - 1) * w + (col < w ? col : w - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        const int e = e0 + tid + u * NTHR, ec = e < total ? e : total - 1;
+        const int row = (int)(((float)ec + 0.5f) * inv_p), col = ec - row * P;
+        stage[ec] = (row < nl && col < w) ? st[u] : 0.0;
+      }
     }
   }
   {
-    const bool fx = first && kc < n;
+    const bool fx = first && kc < nl;
     const double inv = 1.0 / qv;
-    dq[kc] = fx ? 0.0 : inv;
-    zc[kc] = fx ? -rl0 : rxu * inv;
-    q1[ic] = 1.0 / q1v;
+    if constexpr (!PAD) {
+      dq[kc] = fx ? 0.0 : inv;
+      zc[kc] = fx ? -rl0 : rxu * inv;
+      q1[ic] = 1.0 / q1v;
+    } else {
+      // (the selects use the loaded values unconditionally; only the LDS stores sit under the predicates)
+      const double dv = tid < w ? (fx ? 0.0 : inv) : 0.0, zv = tid < w ? (fx ? -rl0 : rxu * inv) : 0.0;
+      const double qq = tid < nl ? 1.0 / q1v : 1.0;
+      if (tid < wp) { dq[tid] = dv; zc[tid] = zv; }
+      if (tid < n) q1[tid] = qq;
+    }
     // the weights of knot s pass through exactly this separator (those of the last knot: Q through separator
     // N - 2, its R is not part of the problem): a non-positive one fails the Cholesky of Q_k / R_k in the reference
     // (src/nested_dissection.c:24-59) -- counted here, S-bar itself may well stay positive definite
-    if ((tid < w && !(qv > 0.0)) || (s == N - 2 && tid < n && !(q1v > 0.0))) flag_failure(info, d, b);
+    if ((tid < w && !(qv > 0.0)) || (s == N - 2 && tid < nl && !(q1v > 0.0))) flag_failure(info, d, b);
   }
   __syncthreads();
   SEG(50);
@@ -219,7 +254,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   {
     // (an unconditional use of the early requests: under the predicate alone the compiler would sink the loads there)
     const double corr = fma(zb, q1[ic], za) + (gl + gr);
-    if (tid < n) bz[tid] -= corr;
+    if (tid < nl) bz[tid] -= corr;
   }
 #pragma unroll
   for (int idx = 0; idx < MAXS; ++idx) {
@@ -230,7 +265,8 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 #pragma unroll
       for (int gg = 0; gg < 4; ++gg) {
         const int i = 16 * rt + lk + 4 * gg, j = 16 * ct + li;
-        dst[4 * gg * ns] = sacc[idx][gg] + (i == j ? q1[i] : 0.0) - (dlr[idx][gg] + dlr[idx][4 + gg]);
+        const double dd = (!PAD || (i < nl && j < nl)) ? dlr[idx][gg] + dlr[idx][4 + gg] : 0.0;
+        dst[4 * gg * ns] = sacc[idx][gg] + (i == j ? q1[i] : 0.0) - dd;
       }
     }
   }
@@ -249,11 +285,11 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int k = 16 * kb + 4 * q + lk;
-        // (unconditional: a coupling block that does not exist is a valid address with arbitrary content,
-        //  masked in phase B.) level 0: r_bb(k, j) = -A_{s+1}(j, k) / Q_{s+1}(k)
-        if (gc < NB) rfk[m][kb][q] = LEVEL0 ? ab[(size_t)k * w + 16 * c + li] : myslot[2 * nn + k * n + 16 * c + li];
-        else rfk[m][kb][q] = LEVEL0 ? ab1[(size_t)(16 * c + li) * w + k] : myslot[3 * nn + k * n + 16 * c + li];
+        const int k0 = 16 * kb + 4 * q + lk, k = k0 < nl ? k0 : nl - 1, j = 16 * c + li < nl ? 16 * c + li : nl - 1;
+        // (unconditional on clamped indices: a coupling block that does not exist is a valid address with
+        //  arbitrary content; it and the padding are masked in phase B.) level 0: r_bb(k, j) = -A_{s+1}(j, k) / Q_{s+1}(k)
+        if (gc < NB) rfk[m][kb][q] = LEVEL0 ? ab[(size_t)k * w + j] : myslot[2 * nnl + k * nl + j];
+        else rfk[m][kb][q] = LEVEL0 ? ab1[(size_t)j * w + k] : myslot[3 * nnl + k * nl + j];
       }
   }
 
@@ -299,7 +335,10 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if (sg == 0) { myrec[2 * nn + i] = acc; zsep = acc; zrow = i; }
+    if (sg == 0) {
+      if (i < nl) myrec[2 * nnl + i] = acc;
+      zsep = acc; zrow = i;
+    }
   }
   // ================================================================================================= phase B
   // Column tile gt of the panel: [0, NB) columns of r_a, [NB, 2 NB) of r_bb. xk[m][kb][q] =
@@ -321,13 +360,17 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rf[kb][q] = !hasA ? 0.0 : LEVEL0 ? -rf[kb][q] * dj : -rf[kb][q];
+        for (int q = 0; q < 4; ++q) {
+          const bool in = hasA && (!PAD || (16 * kb + 4 * q + lk < nl && 16 * c + li < nl));
+          rf[kb][q] = !in ? 0.0 : LEVEL0 ? -rf[kb][q] * dj : -rf[kb][q];
+        }
     } else {
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          rf[kb][q] = !hasB ? 0.0 : LEVEL0 ? -rf[kb][q] * q1[16 * kb + 4 * q + lk] : -rf[kb][q];
+          const bool in = hasB && (!PAD || (16 * kb + 4 * q + lk < nl && 16 * c + li < nl));
+          rf[kb][q] = !in ? 0.0 : LEVEL0 ? -rf[kb][q] * q1[16 * kb + 4 * q + lk] : -rf[kb][q];
           Rb[(16 * kb + 4 * q + lk) * PR + 16 * c + li] = rf[kb][q];  // operand of the push phase
         }
     }
@@ -363,12 +406,13 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
       xk[m][it] = acc;
     }
     // record f_a | f_bb | z_sep (what the back-substitution reads): rows 16 it + lk + 4 g, columns 16 c + li
-    if (gt < NB ? hasA : hasB) {
-      double* dst = myrec + (gt < NB ? 0 : nn) + (size_t)lk * n + 16 * c + li;
+    if ((gt < NB ? hasA : hasB) && (!PAD || 16 * c + li < nl)) {
+      double* dst = myrec + (gt < NB ? 0 : nnl) + (size_t)lk * nl + 16 * c + li;
 #pragma unroll
       for (int it = 0; it < NB; ++it)
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) dst[(size_t)(16 * it + 4 * gg) * n] = xk[m][it][gg];
+        for (int gg = 0; gg < 4; ++gg)
+          if (!PAD || 16 * it + 4 * gg + lk < nl) dst[(size_t)(16 * it + 4 * gg) * nl] = xk[m][it][gg];
     }
   }
   SEG(55);
@@ -394,9 +438,9 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   // ================================================================================================= phase D
   // tile product of the push phase: acc (+)= R(:, 16 rt ..)' X  (xa: X' R(:, 16 rt ..)), R from LDS, X from registers
   const mfma_acc_t zero4 = {0.0, 0.0, 0.0, 0.0};
-  auto push_tile = [&](const double* Rl, const int rt, const mfma_acc_t (&x)[NB], const bool xa, double* dst,
-                       mfma_acc_t acc) {
-    // dst: element (lk, li) of the destination tile, row pitch n; acc: what the tile starts from
+  // blk: n x n block of a slot (row pitch nl), the tile at rows 16 orow .., columns 16 ocol ..; acc: what it starts from
+  auto push_tile = [&](const double* Rl, const int rt, const mfma_acc_t (&x)[NB], const bool xa, double* blk,
+                       const int orow, const int ocol, mfma_acc_t acc) {
     const double* rl = Rl + lk * PR + 16 * rt + li;
     double rv[n / 4];
 #pragma unroll
@@ -408,8 +452,12 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 #pragma unroll
       for (int q = 0; q < n / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[q], x[q / 4][q % 4], acc, 0, 0, 0);
     }
+    if (!PAD || 16 * ocol + li < nl) {
+      double* dst = blk + (size_t)(16 * orow + lk) * nl + 16 * ocol + li;
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) dst[(size_t)4 * gg * n] = acc[gg];
+      for (int gg = 0; gg < 4; ++gg)
+        if (!PAD || 16 * orow + lk + 4 * gg < nl) dst[(size_t)4 * gg * nl] = acc[gg];
+    }
   };
 #pragma unroll
   for (int m = 0; m < MAXT; ++m) {
@@ -419,38 +467,44 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     if (gt < NB ? !hasA : !hasB) continue;
     // the tiles the accumulating pushes start from (DR[A](:, tile c) / DL[B](:, tile c)): requested first, consumed
     // behind the coupling tiles
-    double* pd = (gt < NB ? slotA + nn : slotB) + (size_t)lk * n + 16 * c + li;
+    double* pblk = gt < NB ? slotA + nnl : slotB;
     mfma_acc_t pacc[NB];
+    {
+      const int jc = 16 * c + li < nl ? 16 * c + li : nl - 1;
 #pragma unroll
-    for (int rt = 0; rt < NB; ++rt)
+      for (int rt = 0; rt < NB; ++rt)
 #pragma unroll
-      for (int gg = 0; gg < 4; ++gg) pacc[rt][gg] = LEVEL0 ? 0.0 : pd[(size_t)(16 * rt + 4 * gg) * n];
+        for (int gg = 0; gg < 4; ++gg) {
+          const int i = 16 * rt + lk + 4 * gg;
+          pacc[rt][gg] = LEVEL0 ? 0.0 : pblk[(size_t)(i < nl ? i : nl - 1) * nl + jc];  // (padding: never stored)
+        }
+    }
     if (gt < NB) {
       // coupling tiles (a-tile c, bb-tile j), c + j even:  r_a' S-bar^-1 r_bb = f_a' r_bb
       if (hasB) {
         for (int j = c & 1; j < NB; j += 2) {
           if (leftchild)  // CA[B] = (f_a' r_bb)' = r_bb' f_a: rows bb-tile j, columns a-tile c
-            push_tile(Rb, j, xk[m], false, slotB + 2 * nn + (size_t)(16 * j + lk) * n + 16 * c + li, zero4);
+            push_tile(Rb, j, xk[m], false, slotB + 2 * nnl, j, c, zero4);
           else            // CB[A] = f_a' r_bb: rows a-tile c, columns bb-tile j
-            push_tile(Rb, j, xk[m], true, slotA + 3 * nn + (size_t)(16 * c + lk) * n + 16 * j + li, zero4);
+            push_tile(Rb, j, xk[m], true, slotA + 3 * nnl, c, j, zero4);
         }
       }
       // DR[A](:, tile c) += r_a' f_a(:, tile c)
 #pragma unroll
-      for (int rt = 0; rt < NB; ++rt) push_tile(Ra, rt, xk[m], false, pd + (size_t)16 * rt * n, pacc[rt]);
+      for (int rt = 0; rt < NB; ++rt) push_tile(Ra, rt, xk[m], false, pblk, rt, c, pacc[rt]);
     } else {
       // coupling tiles (a-tile i, bb-tile c), i + c odd:  r_a' f_bb
       if (hasA) {
         for (int i = (c & 1) ^ 1; i < NB; i += 2) {
           if (leftchild)  // CA[B] = (r_a' f_bb)' = f_bb' r_a: rows bb-tile c, columns a-tile i
-            push_tile(Ra, i, xk[m], true, slotB + 2 * nn + (size_t)(16 * c + lk) * n + 16 * i + li, zero4);
+            push_tile(Ra, i, xk[m], true, slotB + 2 * nnl, c, i, zero4);
           else            // CB[A] = r_a' f_bb: rows a-tile i, columns bb-tile c
-            push_tile(Ra, i, xk[m], false, slotA + 3 * nn + (size_t)(16 * i + lk) * n + 16 * c + li, zero4);
+            push_tile(Ra, i, xk[m], false, slotA + 3 * nnl, i, c, zero4);
         }
       }
       // DL[B](:, tile c) += r_bb' f_bb(:, tile c)
 #pragma unroll
-      for (int rt = 0; rt < NB; ++rt) push_tile(Rb, rt, xk[m], false, pd + (size_t)16 * rt * n, pacc[rt]);
+      for (int rt = 0; rt < NB; ++rt) push_tile(Rb, rt, xk[m], false, pblk, rt, c, pacc[rt]);
     }
   }
   // vector pushes gR[A] += r_a' z_sep (first wavefront), gL[B] += r_bb' z_sep (last): a column of r per lane
@@ -459,9 +513,9 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     for (int pass = 0; pass < 2; ++pass) {
       if (pass == 0 ? !ga : !(wave == NW - 1 && hasB)) continue;
       const double* R = pass == 0 ? Ra : Rb;
-      double* dst = pass == 0 ? slotA + 4 * nn + n : slotB + 4 * nn;
-      for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane < n ? j0 + lane : n - 1;
+      double* dst = pass == 0 ? slotA + 4 * nnl + nl : slotB + 4 * nnl;
+      for (int j0 = 0; j0 < nl; j0 += 64) {
+        const int j = j0 + lane < nl ? j0 + lane : nl - 1;
         double acc = LEVEL0 ? 0.0 : dst[j];
         for (int k0 = 0; k0 < n; k0 += 8) {
           double rv[8], zv[8];
@@ -470,7 +524,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc = fma(rv[u], zv[u], acc);
         }
-        if (j0 + lane < n) dst[j] = acc;
+        if (j0 + lane < nl) dst[j] = acc;
       }
     }
   }

@@ -79,10 +79,11 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.K = 0; while ((1 << d.K) < nhorizon) ++d.K;
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
+  c->red_bytes = 0;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
   c->pipeline = getenv("NDLQR_PIPELINE") ? atoi(getenv("NDLQR_PIPELINE")) : 2;
   c->solve_count = 0; c->in_alt = false; c->z_latest = nullptr; c->stream_latest = nullptr; c->h_fail_other = nullptr;
-  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false;
+  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false; c->graph_schedule = "none";
 
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->rowbcast = getenv("NDLQR_ROWBCAST") ? (atoi(getenv("NDLQR_ROWBCAST")) != 0 ? 1 : 0) : -1;  // -1: by block size
@@ -105,6 +106,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
     const size_t slot_doubles = (4 * (size_t)nstates * nstates + 2 * nstates + 15) / 16 * 16;
     const size_t red_bytes = sizeof(double) * (size_t)batch * (nhorizon / 4) * slot_doubles;
     ok = hipMalloc(&c->red, red_bytes) == hipSuccess && hipMemsetAsync(c->red, 0, red_bytes, c->stream) == hipSuccess;
+    if (ok) c->red_bytes = red_bytes;
     ok = ok && hipMalloc(&c->ytop, sizeof(double) * (size_t)batch * (nhorizon / 8) * nstates) == hipSuccess;
     const size_t cnt_bytes = sizeof(int) * (size_t)batch * (nhorizon / 4);
     ok = ok && hipMalloc(&c->tree_cnt, cnt_bytes) == hipSuccess &&
@@ -149,10 +151,11 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
 // exchange the context's per-solve buffers, stream, graph and events with the alternate set
 static void swap_slot(NdlqrHipCtx* c) {
   NdlqrAltSlot& a = c->alt;
-  std::swap(c->rec, a.rec); std::swap(c->red, a.red); std::swap(c->ytop, a.ytop); std::swap(c->z, a.z);
+  std::swap(c->rec, a.rec); std::swap(c->red, a.red); std::swap(c->red_bytes, a.red_bytes); std::swap(c->ytop, a.ytop); std::swap(c->z, a.z);
   std::swap(c->tree_cnt, a.tree_cnt); std::swap(c->h_fail, a.h_fail); std::swap(c->stream, a.stream);
   std::swap(c->graph_exec, a.graph_exec); std::swap(c->graph_flags, a.graph_flags);
   std::swap(c->graph_stream, a.graph_stream); std::swap(c->graph_rec_complete, a.graph_rec_complete);
+  std::swap(c->graph_schedule, a.graph_schedule);
   std::swap(c->ev_start, a.ev_start); std::swap(c->ev_stop, a.ev_stop);
   c->in_alt = !c->in_alt;
 }
@@ -184,6 +187,7 @@ static bool ensure_alt(NdlqrHipCtx* c) {
             hipHostMalloc((void**)&a.h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (ok && c->tree_cnt)  // size-specialised shapes (the runtime-sized schedule's slots: ensure_red_generic)
     ok = hipMalloc(&a.red, red_bytes) == hipSuccess && hipMemsetAsync(a.red, 0, red_bytes, a.stream) == hipSuccess &&
+         ((a.red_bytes = red_bytes), true) &&
          hipMalloc(&a.ytop, sizeof(double) * (size_t)d.batch * (d.N / 8) * d.n) == hipSuccess &&
          hipMalloc(&a.tree_cnt, cnt_bytes) == hipSuccess && hipMemsetAsync(a.tree_cnt, 0, cnt_bytes, a.stream) == hipSuccess;
   ok = ok && hipMemsetAsync(a.z, 0, bytes_z(d), a.stream) == hipSuccess && hipStreamSynchronize(a.stream) == hipSuccess;
@@ -321,15 +325,20 @@ struct ReducedGenericPlan {
   bool ok;
   int threads;
   size_t lds;
+  int nb;    // 16 x 16 tiles per block row
+  bool pad;  // the block does not fill them
 };
 static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
-  ReducedGenericPlan p = {false, 0, 0};
+  ReducedGenericPlan p = {false, 0, 0, 0, false};
   if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_KEEP_RECORDS)) return p;
-  if (c->no_mfma || d.n % 16 != 0 || d.n > 64 || d.w % 4 != 0 || d.N < 2) return p;
-  p.threads = d.n >= 48 ? 512 : 256;
-  if (d.w + d.n > p.threads) return p;  // one weight / rhs entry per thread
-  p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(d.n, d.w);
+  if (c->no_mfma || d.n > 64 || d.N < 2) return p;
+  p.nb = (d.n + 15) / 16;
+  const int npad = 16 * p.nb, wpad = (d.w + 3) / 4 * 4;
+  p.pad = npad != d.n || wpad != d.w;  // blocks that do not fill their tiles: zero-padded in LDS (PAD instances)
+  p.threads = p.nb >= 3 ? 512 : 256;
+  if (wpad > p.threads) return p;  // one weight / rhs entry per thread
+  p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(npad, wpad);
   if (p.lds > 160 * 1024) return p;
   p.ok = true;
   return p;
@@ -344,15 +353,26 @@ static size_t bytes_red_generic(const ndlqr::Dims& d) {
 // every accumulator block. Must run outside stream capture.
 static int ensure_red_generic(NdlqrHipCtx* c) {
   if (c->d.N < 4) return NDLQR_OK;  // a single separator: no slots
+  const size_t need = bytes_red_generic(c->d);
   for (int which = 0; which < 2; ++which) {
     double** slot = which == 0 ? &c->red : &c->alt.red;
-    if (*slot || (which == 1 && !c->alt.ready)) continue;
-    if (hipMalloc(slot, bytes_red_generic(c->d)) != hipSuccess) {
+    size_t* have = which == 0 ? &c->red_bytes : &c->alt.red_bytes;
+    if (which == 1 && !c->alt.ready) continue;
+    if (*slot && *have >= need) continue;
+    // (a context of a size-specialised shape under NDLQR_FLAG_GENERIC comes with the smaller array of ITS schedule)
+    HIP_TRY(sync_all(c));
+    if (*slot) { (void)hipFree(*slot); *slot = nullptr; *have = 0; }
+    // a launch sequence captured on this buffer set holds the old address
+    hipGraphExec_t* ge = which == 0 ? &c->graph_exec : &c->alt.graph_exec;
+    if (*ge) { (void)hipGraphExecDestroy(*ge); *ge = nullptr; }
+    if (hipMalloc(slot, need) != hipSuccess) {
       *slot = nullptr;
       (void)hipGetLastError();
       g_last_error = "accumulator slots of the separator-only schedule do not fit on the device";
       return NDLQR_ERR_INVALID;
     }
+    *have = need;
+    HIP_TRY(hipMemset(*slot, 0, need));
   }
   return NDLQR_OK;
 }
@@ -363,21 +383,23 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
   for (int l = 0; l < d.K; ++l) {
     ScopedSlot t(c, SLOT_SEP);
     const dim3 grid(d.N >> (l + 1), d.batch);
-#define NDLQR_LAUNCH_SEP(NB_, NT_)                                                                              \
-  do {                                                                                                          \
-    if (l == 0)                                                                                                 \
-      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, true>), grid, dim3(NT_), p.lds, \
-                         c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);                       \
-    else                                                                                                        \
-      hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, false>), grid, dim3(NT_), p.lds, \
-                         c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->info);                       \
+#define NDLQR_LAUNCH_SEP2(NB_, NT_, L0_, PAD_)                                                                     \
+  hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, L0_, PAD_>), grid, dim3(NT_), p.lds, c->stream, d, l, \
+                     c->AB, c->QR, c->rhs, c->red, c->rec, c->info)
+#define NDLQR_LAUNCH_SEP(NB_, NT_)                                          \
+  do {                                                                      \
+    if (l == 0 && p.pad) NDLQR_LAUNCH_SEP2(NB_, NT_, true, true);           \
+    else if (l == 0) NDLQR_LAUNCH_SEP2(NB_, NT_, true, false);              \
+    else if (p.pad) NDLQR_LAUNCH_SEP2(NB_, NT_, false, true);               \
+    else NDLQR_LAUNCH_SEP2(NB_, NT_, false, false);                         \
   } while (0)
-    switch (d.n / 16) {
+    switch (p.nb) {
       case 1: NDLQR_LAUNCH_SEP(1, 256); break;
       case 2: NDLQR_LAUNCH_SEP(2, 256); break;
       case 3: NDLQR_LAUNCH_SEP(3, 512); break;
       default: NDLQR_LAUNCH_SEP(4, 512); break;
     }
+#undef NDLQR_LAUNCH_SEP2
 #undef NDLQR_LAUNCH_SEP
   }
   {
@@ -630,9 +652,11 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
       c->graph_flags = c->flags;
       c->graph_stream = c->stream;
       c->graph_rec_complete = c->rec_complete;  // what the captured sequence leaves behind
+      c->graph_schedule = c->schedule;
     }
     HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
     c->rec_complete = c->graph_rec_complete;
+    c->schedule = c->graph_schedule;
   }
   if (err) return err;
   HIP_TRY(hipGetLastError());

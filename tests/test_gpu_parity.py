@@ -139,11 +139,12 @@ def test_json_fixture_through_dropin_api(ndlqr, oracle, fname):
 
 
 @pytest.mark.parametrize("n,m,N,batch", [(64, 16, 32, 2), (32, 8, 64, 2), (20, 20, 16, 3), (32, 16, 64, 2),
-                                         (16, 16, 128, 3), (48, 16, 16, 2)])
+                                         (16, 16, 128, 3), (48, 16, 16, 2), (72, 8, 8, 1), (80, 16, 4, 1)])
 def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
     """Shapes without a specialised instance (config 5 family, nx=64 nu=16) run the runtime-sized
     kernels; where the blocks fill 16x16 tiles the fast mode puts the Schur update on
-    v_mfma_f64_16x16x4_f64 (kernels_mfma.hpp). Strict mode bit-exact, fast mode within tolerance."""
+    v_mfma_f64_16x16x4_f64 (kernels_mfma.hpp). Strict mode bit-exact, fast mode within tolerance. (Fast mode
+    without KEEP: the separator-only schedule up to 64 states, the knot-based lean schedule beyond.)"""
     probs = [synth(ndlqr, n, m, N, 900 + p) for p in range(batch)]
     # strict + KEEP, fast + KEEP (full Schur passes), fast without KEEP (boundary knots only +
     # back-substitution over the separator records)
@@ -152,6 +153,8 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
                                (ndlqr.FLAG_KEEP_FACT if keep else 0))
         bs.initialize_flat(*stack(probs))
         assert bs.solve() == 0
+        if not strict and not keep:
+            assert bs.schedule() == ("generic-reduced" if n <= 64 else "generic-lean")
         sol = bs.solutions()
         for p, prob in enumerate(probs):
             z, fact, _, fails = oracle.solve(prob, 8, want_fact=True)
@@ -167,12 +170,16 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
 
 
 @pytest.mark.parametrize("n,m,N,batch", [(16, 4, 2, 2), (16, 4, 4, 3), (32, 8, 8, 2), (48, 12, 64, 2), (64, 16, 128, 3),
-                                         (64, 16, 512, 1)])
+                                         (64, 16, 512, 1),
+                                         # blocks that do not fill their tiles: zero-padded in LDS (PAD instances)
+                                         (20, 20, 16, 3), (7, 9, 16, 2), (5, 3, 32, 2), (1, 1, 4, 2), (17, 3, 16, 2),
+                                         (33, 5, 8, 2), (50, 10, 64, 2), (63, 1, 16, 2), (64, 15, 16, 1), (3, 1, 2, 2)])
 def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch):
-    """Blocks that fill 16x16 matrix-core tiles take the separator-only schedule (kernels_reduced_mfma.hpp:
-    one launch per tree level, no factor array), down to a single separator (N = 2). Consecutive solves
-    alternate between the two buffer sets of the pipeline and replay the captured graph: every one of them
-    has to reproduce the oracle. A non-positive weight is reported like on every other path."""
+    """Every block size up to 64 states without a size-specialised instance takes the separator-only schedule on
+    the matrix cores (kernels_reduced_mfma.hpp: one launch per tree level, no factor array), down to a single
+    separator (N = 2); blocks that do not fill 16x16 tiles are zero-padded in LDS. Consecutive solves alternate
+    between the two buffer sets of the pipeline and replay the captured graph: every one of them has to
+    reproduce the oracle. A non-positive weight is reported like on every other path."""
     probs = [synth(ndlqr, n, m, N, 1300 + p) for p in range(batch)]
     refs = [oracle.solve(prob, 1)[0][: prob.nvars] for prob in probs]
     bs = ndlqr.BatchSolver(n, m, N, batch)
@@ -199,6 +206,29 @@ def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch):
         assert bs.solve() == -3
         assert bs.cholesky_failures() >= 1
         bs.close()
+
+
+def test_generic_flag_switch_on_specialised_shape(ndlqr, oracle):
+    """A context of a size-specialised shape comes with the (smaller) accumulator array of ITS separator-only
+    schedule; NDLQR_FLAG_GENERIC sends it through the runtime-sized schedule, which needs its own, larger one:
+    reallocated on the first such solve, for both buffer sets of the pipeline, and the captured launch
+    sequences that hold the old address are dropped. Switching back and forth keeps every solve right."""
+    n, m, N, batch = 12, 4, 64, 5
+    probs = [synth(ndlqr, n, m, N, 1500 + p) for p in range(batch)]
+    refs = [oracle.solve(prob, 1)[0][: prob.nvars] for prob in probs]
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*stack(probs))
+    for flags, name in ((0, "reduced-tree"), (0, "reduced-tree"), (ndlqr.FLAG_GENERIC, "generic-reduced"),
+                        (0, "reduced-tree"), (ndlqr.FLAG_GENERIC, "generic-reduced"),
+                        (ndlqr.FLAG_GENERIC, "generic-reduced"), (0, "reduced-tree"), (0, "reduced-tree"),
+                        (0, "reduced-tree")):
+        bs.set_flags(flags)
+        assert bs.solve() == 0
+        assert bs.schedule() == name  # (a small batch: the one-launch tree variant of the specialised schedule)
+        sol = bs.solutions()
+        for p in range(batch):
+            assert np.linalg.norm(sol[p] - refs[p]) / np.linalg.norm(refs[p]) <= REL_TOL
+    bs.close()
 
 
 def test_non_spd_block_is_reported(ndlqr):

@@ -12,7 +12,12 @@ from support import Oracle, Problem  # noqa: E402
 
 orc = Oracle()
 shapes = [(16, 4, 2, 2), (16, 4, 4, 2), (16, 4, 8, 3), (16, 16, 128, 3), (32, 8, 64, 2), (48, 16, 16, 2), (64, 16, 32, 2),
-          (64, 16, 512, 2), (20, 20, 16, 2)]
+          (64, 16, 512, 2),
+          # blocks that do not fill their tiles (zero-padded in LDS)
+          (20, 20, 16, 2), (7, 9, 16, 3), (3, 1, 2, 2), (1, 1, 4, 2), (5, 3, 32, 3), (24, 6, 32, 2), (17, 3, 16, 2),
+          (33, 5, 8, 2), (50, 10, 64, 2), (64, 15, 16, 2), (63, 1, 16, 2), (15, 2, 256, 2),
+          # beyond 64 states: the knot-based runtime-sized kernels
+          (72, 8, 8, 1)]
 for (n, m, N, batch) in shapes:
     bs = R.BatchSolver(n, m, N, batch)
     bs.initialize_synthetic(11)
