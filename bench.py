@@ -417,16 +417,19 @@ def main():
                 "bytes_per_rank_per_step": gather["bytes_per_rank_per_step"],
                 "every_rank_found_its_shard_intact": g_bad == 0.0,
                 "note": "solve, pack kernel, host sync, all_gather of [batch, nvars] per step; `value` excludes it"}
-        if world == 1 and not args.no_modes and not big and args.flags == 0:
-            log("secondary modes (strict / KEEP_FACT / rhs-only)")
+        if world == 1 and not args.no_modes and args.flags == 0:
             msteps = min(steps, 20)
-            result["modes"] = {
-                "strict_fp (flags=1, bit-identical to the reference)":
-                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 1, msteps),
-                "keep_fact (flags=8, complete factor array materialised)":
-                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 8, msteps),
-                "rhs_only (flags=16 records kept, new right-hand side per step)":
-                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 16, msteps, rhs_only=True)}
+            result["modes"] = {}
+            if not big:  # (at (64,16,512) x 256 the factor array of these two modes is 87 GB)
+                log("secondary modes (strict / KEEP_FACT)")
+                result["modes"]["strict_fp (flags=1, bit-identical to the reference)"] = \
+                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 1, msteps)
+                result["modes"]["keep_fact (flags=8, complete factor array materialised)"] = \
+                    time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 8, msteps)
+            log("secondary mode (rhs-only re-solve)")
+            bs.close()  # the second solver of this leg needs the memory at the large-block sizes
+            result["modes"]["rhs_only (flags=16 records kept, new right-hand side per step)"] = \
+                time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 16, msteps, rhs_only=True)
         if world == 1 and not args.no_cpu:
             cores = host_cores()
             log("cpu_baseline leg on %d cores" % cores)

@@ -98,7 +98,8 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* ctx, double* dst);
 int ndlqr_hip_kkt_residual(NdlqrHipCtx* ctx, double* res, double* bnorm);
 int ndlqr_hip_cholesky_failures(NdlqrHipCtx* ctx);
 /* Name of the launch sequence the last solve used (for reports): "reduced", "reduced-tree",
- * "reduced-records", "knot-lean", "knot-strict", "knot-keep", "generic-reduced", "generic-lean",
+ * "reduced-records", "knot-lean", "knot-strict", "knot-keep", "generic-reduced",
+ * "generic-reduced-records", "generic-lean",
  * "generic-strict", "generic-keep" (DESIGN.md section 3). */
 const char* ndlqr_hip_schedule(const NdlqrHipCtx* ctx);
 

@@ -61,6 +61,10 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 // Written for memory-level parallelism: loads are unconditional on clamped indices and requested as early as
 // their address is known, LDS stores likewise (a store under a lane predicate makes the compiler sink its load
 // behind the predicate, and the loads then complete one after the other).
+// what a separator keeps for the record-based re-solve: the n x (n + 1) array that holds W below its diagonal
+// blocks, then the inverses of the diagonal blocks (n / 16 blocks of 16 x 17); n = padded block size
+__host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * (n + 1) + 17 * n; }
+
 __host__ __device__ inline int reduced_lds_doubles(const int n, const int w) {
   int big = n * reduced_stage_pitch(w);                 // staged [A_s | B_s]
   const int later = n * (n + 1) + 17 * n + n * (n + 1);  // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
@@ -72,7 +76,8 @@ template <int NB, int NTHR, bool LEVEL0, bool PAD>
 __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
                                                                   const double* __restrict__ rhs, double* red,
-                                                                  double* __restrict__ rec, int* __restrict__ info) {
+                                                                  double* __restrict__ rec, int* __restrict__ info,
+                                                                  double* __restrict__ wfac) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int n = 16 * NB, ns = n + 1;
   constexpr int NW = NTHR / 64;
@@ -295,6 +300,11 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 
   sep_invert(geo, S, Wd);
   SEG(54);
+  if (wfac) {  // NDLQR_FLAG_KEEP_RECORDS: W = L^-1 (strictly lower blocks in S, diagonal blocks in Wd) for rhs-only re-solves
+    constexpr int WF = reduced_wfac_doubles(n);
+    double* wf = wfac + ((size_t)b * N + s) * WF;
+    for (int e = tid; e < WF; e += NTHR) wf[e] = S[e];  // (S and Wd are contiguous)
+  }
   // ---- z_sep = W'(W b~) on the vector ALU, all wavefronts: eight rows per wavefront, eight lanes per row (a
   //      seventeenth column does not pay a matrix-core tile, and one wavefront alone would keep the others waiting)
   auto w_ptr = [&](const int r, const int cidx) -> const double* {  // &W(r, cidx), cidx <= r
@@ -529,6 +539,134 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     }
   }
   SEG(59);
+}
+
+
+// ------------------------------------------------------------------------------------- rhs-only re-solve
+// New q, r, d, x0 against the factorisation of a separator_reduced_mfma sweep that ran with
+// NDLQR_FLAG_KEEP_RECORDS: per level, vector work only --
+//     b~ = leafb - gL - gR,   z_sep = W'(W b~)  -> record,   gR[A] (+)= r_a' z_sep,   gL[B] (+)= r_bb' z_sep
+// with W from `wfac`, r_a = -CA, r_bb = -CB from the slots the factorisation left behind (level 0: from the
+// problem data); f_a, f_bb of the records stay. The back-substitution then runs as after a full solve.
+// Runtime-sized; np = padded block size of the factorisation.
+//   grid (N >> (l+1), batch), block 256, dynamic LDS = 2 (n + m) + n + 3 np + 256 doubles.
+static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l, int np, const double* __restrict__ AB,
+                                                                  const double* __restrict__ QR,
+                                                                  const double* __restrict__ rhs, double* red,
+                                                                  double* __restrict__ rec,
+                                                                  const double* __restrict__ wfac) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int nl = d.n, nnl = nl * nl, w = d.w, N = d.N, rows = d.rows, ns = np + 1;
+  const int b = blockIdx.y;
+  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
+  const bool hasA = base > 0, hasB = base + T < N, first = s == 0, level0 = l == 0;
+  double* dq = sm;        // 1 / [Q_s | R_s] (state entries of knot 0: zero)
+  double* zc = dq + w;    // rhs(s).xu scaled likewise (state entries of knot 0: -x0)
+  double* q1 = zc + w;    // 1 / Q_{s+1}
+  double* bz = q1 + nl;   // b~
+  double* yv = bz + np;   // W b~
+  double* zs = yv + np;   // z_sep
+  double* part = zs + np; // partial column sums: 256 / np segments of the summation index per column
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* ab = AB + ((size_t)b * N + s) * nl * w;
+  const double* ab1 = ab + (size_t)nl * w;
+  const double* qr = QR + ((size_t)b * N + s) * w;
+  const double* r0 = rhs + ((size_t)b * N + s) * rows;
+  const double* myslot = reduced_slot(red, d, b, level0 ? 1 : s);
+  double* slotA = reduced_slot(red, d, b, hasA ? base - 1 : 1);
+  double* slotB = reduced_slot(red, d, b, hasB ? base + T - 1 : 1);
+  double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nnl + nl);
+  const double* Sg = wfac + ((size_t)b * N + s) * reduced_wfac_doubles(np);
+  const double* Wdg = Sg + (size_t)np * ns;
+  auto w_at = [&](const int r, const int c) -> double {  // W(r, c), c <= r
+    return (r >> 4) == (c >> 4) ? Wdg[(r >> 4) * 16 * 17 + (r & 15) * 17 + (c & 15)] : Sg[(size_t)r * ns + c];
+  };
+  auto wave_sum = [](double v) -> double {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+
+  for (int k = tid; k < w; k += 256) {
+    const bool fx = first && k < nl;
+    const double inv = 1.0 / qr[k];
+    dq[k] = fx ? 0.0 : inv;
+    zc[k] = fx ? -r0[k] : r0[nl + k] * inv;
+  }
+  for (int i = tid; i < nl; i += 256) q1[i] = 1.0 / qr[w + i];
+  __syncthreads();
+  // b~: a row per wavefront and round, lanes along the row
+  for (int i = wave; i < np; i += 4) {
+    double acc = 0.0;
+    if (i < nl)
+      for (int k = lane; k < w; k += 64) acc = fma(ab[(size_t)i * w + k], zc[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      double v = 0.0;
+      if (i < nl) {
+        v = acc - fma(r0[rows + nl + i], q1[i], r0[rows + i]);
+        if (!level0) v -= myslot[4 * nnl + i] + myslot[4 * nnl + nl + i];
+      }
+      bz[i] = v;
+    }
+  }
+  __syncthreads();
+  for (int i = wave; i < np; i += 4) {  // y = W b~
+    double acc = 0.0;
+    for (int k = lane; k <= i; k += 64) acc = fma(w_at(i, k), bz[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) yv[i] = acc;
+  }
+  __syncthreads();
+  // column sums sum_k f(k, j): thread (j, seg) takes k = seg, seg + nseg, ..; consecutive threads read consecutive
+  // words of a row of the operand
+  const int nseg = 256 / np, cj = tid % np, cseg = tid / np;
+  auto column_sums = [&](auto f, const int kend) -> double {  // returns the sum of column cj to the threads of segment 0
+    double acc = 0.0;
+    if (cseg < nseg)
+      for (int k = cseg; k < kend; k += nseg) acc += f(k, cj);
+    if (cseg < nseg) part[cseg * np + cj] = acc;
+    __syncthreads();
+    double tot = 0.0;
+    if (cseg == 0)
+      for (int g = 0; g < nseg; ++g) tot += part[g * np + cj];
+    __syncthreads();
+    return tot;
+  };
+  {  // z_sep = W'y
+    const double zi = column_sums([&](const int k, const int j) { return k >= j ? w_at(k, j) * yv[k] : 0.0; }, np);
+    if (cseg == 0) {
+      zs[cj] = zi;
+      if (cj < nl) myrec[2 * nnl + cj] = zi;
+    }
+  }
+  __syncthreads();
+  // gR[A] (+)= r_a' z_sep: a column of r_a per thread
+  if (hasA) {  // (uniform)
+    double* dst = slotA + 4 * nnl + nl;
+    const double g = column_sums([&](const int k, const int j) {
+      if (j >= nl) return 0.0;
+      return (level0 ? -ab[(size_t)k * w + j] * dq[j] : -myslot[2 * nnl + k * nl + j]) * zs[k];
+    }, nl);
+    if (cseg == 0 && cj < nl) dst[cj] = level0 ? g : dst[cj] + g;
+  }
+  // gL[B] (+)= r_bb' z_sep; level 0: r_bb(k, j) = -A_{s+1}(j, k) / Q_{s+1}(k) -- a row of A_{s+1} per wavefront and round
+  if (hasB) {
+    double* dst = slotB + 4 * nnl;
+    if (level0) {
+      for (int j = wave; j < nl; j += 4) {
+        double acc = 0.0;
+        for (int k = lane; k < nl; k += 64) acc = fma(-q1[k] * ab1[(size_t)j * w + k], zs[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) dst[j] = acc;
+      }
+    } else {
+      const double g = column_sums([&](const int k, const int j) {
+        return j < nl ? -myslot[3 * nnl + k * nl + j] * zs[k] : 0.0;
+      }, nl);
+      if (cseg == 0 && cj < nl) dst[cj] += g;
+    }
+  }
 }
 
 }  // namespace ndlqr

@@ -80,6 +80,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->red_bytes = 0;
+  c->wfac = nullptr;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
   c->pipeline = getenv("NDLQR_PIPELINE") ? atoi(getenv("NDLQR_PIPELINE")) : 2;
   c->solve_count = 0; c->in_alt = false; c->z_latest = nullptr; c->stream_latest = nullptr; c->h_fail_other = nullptr;
@@ -138,7 +139,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
-  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop);
+  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->wfac);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -327,12 +328,14 @@ struct ReducedGenericPlan {
   size_t lds;
   int nb;    // 16 x 16 tiles per block row
   bool pad;  // the block does not fill them
+  bool keep; // NDLQR_FLAG_KEEP_RECORDS
 };
 static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
-  ReducedGenericPlan p = {false, 0, 0, 0, false};
-  if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT | NDLQR_FLAG_KEEP_RECORDS)) return p;
+  ReducedGenericPlan p = {false, 0, 0, 0, false, false};
+  if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT)) return p;
   if (c->no_mfma || d.n > 64 || d.N < 2) return p;
+  p.keep = (c->flags & NDLQR_FLAG_KEEP_RECORDS) != 0;  // W of every separator kept for rhs-only re-solves
   p.nb = (d.n + 15) / 16;
   const int npad = 16 * p.nb, wpad = (d.w + 3) / 4 * 4;
   p.pad = npad != d.n || wpad != d.w;  // blocks that do not fill their tiles: zero-padded in LDS (PAD instances)
@@ -352,6 +355,16 @@ static size_t bytes_red_generic(const ndlqr::Dims& d) {
 // solve that takes it, for both buffer sets of the pipeline. Never zeroed: the level-0 launch stores
 // every accumulator block. Must run outside stream capture.
 static int ensure_red_generic(NdlqrHipCtx* c) {
+  if ((c->flags & NDLQR_FLAG_KEEP_RECORDS) && !c->wfac) {
+    const int np = (c->d.n + 15) / 16 * 16;
+    const size_t bytes = sizeof(double) * (size_t)c->d.batch * c->d.N * ndlqr::reduced_wfac_doubles(np);
+    if (hipMalloc(&c->wfac, bytes) != hipSuccess) {
+      c->wfac = nullptr;
+      (void)hipGetLastError();
+      g_last_error = "separator factors of NDLQR_FLAG_KEEP_RECORDS do not fit on the device";
+      return NDLQR_ERR_INVALID;
+    }
+  }
   if (c->d.N < 4) return NDLQR_OK;  // a single separator: no slots
   const size_t need = bytes_red_generic(c->d);
   for (int which = 0; which < 2; ++which) {
@@ -377,15 +390,29 @@ static int ensure_red_generic(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
+// back-substitution over the separator records (runtime-sized schedules): multipliers level by level, then the
+// states and inputs of every knot
+static void launch_backsub_generic(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  ScopedSlot t(c, SLOT_APPLY);
+  for (int l = d.K - 1; l >= 0; --l)
+    hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
+                       c->rec, c->z);
+  const int work = d.N * d.rows;
+  hipLaunchKernelGGL(ndlqr::backsub_states_generic, dim3((work + 255) / 256, d.batch), dim3(256), 0, c->stream, d,
+                     c->AB, c->QR, c->rhs, c->z);
+}
+
 static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
   const ndlqr::Dims& d = c->d;
-  c->schedule = "generic-reduced";
+  c->schedule = p.keep ? "generic-reduced-records" : "generic-reduced";
+  c->rec_complete = p.keep;  // records, slots and W of every separator stay: rhs-only re-solves (launch_rhs_reduced_generic)
   for (int l = 0; l < d.K; ++l) {
     ScopedSlot t(c, SLOT_SEP);
     const dim3 grid(d.N >> (l + 1), d.batch);
 #define NDLQR_LAUNCH_SEP2(NB_, NT_, L0_, PAD_)                                                                     \
   hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, L0_, PAD_>), grid, dim3(NT_), p.lds, c->stream, d, l, \
-                     c->AB, c->QR, c->rhs, c->red, c->rec, c->info)
+                     c->AB, c->QR, c->rhs, c->red, c->rec, c->info, p.keep ? c->wfac : (double*)nullptr)
 #define NDLQR_LAUNCH_SEP(NB_, NT_)                                          \
   do {                                                                      \
     if (l == 0 && p.pad) NDLQR_LAUNCH_SEP2(NB_, NT_, true, true);           \
@@ -402,16 +429,21 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
 #undef NDLQR_LAUNCH_SEP2
 #undef NDLQR_LAUNCH_SEP
   }
-  {
-    ScopedSlot t(c, SLOT_APPLY);
-    for (int l = d.K - 1; l >= 0; --l)
-      hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
-                         d, l, c->rec, c->z);
-    const int work = d.N * d.rows;
-    hipLaunchKernelGGL(ndlqr::backsub_states_generic, dim3((work + 255) / 256, d.batch), dim3(256), 0, c->stream, d,
-                       c->AB, c->QR, c->rhs, c->z);
-  }
+  launch_backsub_generic(c);
   return NDLQR_OK;
+}
+
+// rhs-only re-solve on the records, slots and separator factors of a generic-reduced-records sweep
+static void launch_rhs_reduced_generic(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  const int np = (d.n + 15) / 16 * 16;
+  const size_t lds = sizeof(double) * (2 * (size_t)d.w + d.n + 3 * (size_t)np + 256);
+  for (int l = 0; l < d.K; ++l) {
+    ScopedSlot t(c, SLOT_SEP);
+    hipLaunchKernelGGL(ndlqr::rhs_reduced_generic, dim3(d.N >> (l + 1), d.batch), dim3(256), lds, c->stream, d, l, np,
+                       c->AB, c->QR, c->rhs, c->red, c->rec, c->wfac);
+  }
+  launch_backsub_generic(c);
 }
 
 template <bool STRICT>
@@ -707,7 +739,13 @@ static void launch_rhs_sweep(NdlqrHipCtx* c) {
 
 static bool try_launch_rhs_records(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
-  if (!c->rec_complete || (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_GENERIC))) return false;
+  if (!c->rec_complete || (c->flags & NDLQR_FLAG_STRICT_FP)) return false;
+  if (!pick_small(c)) {  // runtime-sized separator-only schedule: records + slots + W of every separator
+    if (!plan_reduced_generic(c).ok || !c->wfac) return false;
+    launch_rhs_reduced_generic(c);
+    return true;
+  }
+  if (c->flags & NDLQR_FLAG_GENERIC) return false;
   if (d.N < 8 || (size_t)(d.N / 8) * d.n * sizeof(double) > 60 * 1024) return false;
   const SmallInstance* inst = find_small(d);
   if (!inst || (d.K + 4) * inst->nx > 256) return false;

@@ -163,7 +163,7 @@ def model_for(schedule, n, m, N):
         return knot_lean_model(n, m, N)
     if schedule == "generic-lean":
         return generic_lean_model(n, m, N)
-    if schedule == "generic-reduced":
+    if schedule in ("generic-reduced", "generic-reduced-records"):
         return generic_reduced_model(n, m, N)
     return None
 

@@ -245,11 +245,14 @@ def test_non_spd_block_is_reported(ndlqr):
         bs.close()
 
 
-@pytest.mark.parametrize("n,m,N", [(12, 4, 64), (12, 4, 256), (6, 3, 32), (13, 4, 16), (4, 1, 8), (10, 4, 128)])
+@pytest.mark.parametrize("n,m,N", [(12, 4, 64), (12, 4, 256), (6, 3, 32), (13, 4, 16), (4, 1, 8), (10, 4, 128),
+                                   # runtime-sized separator-only schedule: records + slots + W of every separator
+                                   (16, 4, 16), (20, 20, 16), (64, 16, 32), (7, 9, 8), (16, 4, 2), (33, 5, 4), (48, 16, 64)])
 def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
     """NDLQR_FLAG_KEEP_RECORDS: the lean fast-mode solve keeps just the separator records and
     factors; new right-hand sides are then solved without the factor array -- also after the
-    matrices were replaced and the (graph-replayed) solve ran again."""
+    matrices were replaced and the (graph-replayed) solve ran again. Size-specialised shapes and, up to 64
+    states, every other one (records + accumulator slots + W = L^-1 of every separator)."""
     batch = 3
     first = [synth(ndlqr, n, m, N, 300 + p) for p in range(batch)]
     other = [synth(ndlqr, n, m, N, 700 + p) for p in range(batch)]
@@ -272,8 +275,8 @@ def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
     with pytest.raises(RuntimeError):  # no factor array in this mode
         bs.factors(0)
     bs.close()
-    # a shape without a size-specialised instance cannot re-solve from records
-    bs = ndlqr.BatchSolver(7, 2, 16, 2, flags=ndlqr.FLAG_KEEP_RECORDS)
+    # beyond 64 states (knot-based runtime-sized kernels) a re-solve needs the factor array: NDLQR_FLAG_KEEP_FACT
+    bs = ndlqr.BatchSolver(72, 2, 4, 1, flags=ndlqr.FLAG_KEEP_RECORDS)
     bs.initialize_synthetic(5)
     assert bs.solve() == 0
     assert bs.solve_rhs_only() == -1
