@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(512) void rhs_forward_upper(Dims d, const double* _
 // schur_generic run level by level.
 //   grid (N >> JB, batch), block 32 << JB threads. Requires N > 2^JB.
 template <int NX, int NU, bool STRICT, bool KEEP, int JB>
-__global__ __launch_bounds__(32 << JB, 3) void bottom_small(Dims d, const double* __restrict__ AB,
+__global__ __launch_bounds__(32 << JB, (KEEP && !STRICT) ? 2 : 3) void bottom_small(Dims d, const double* __restrict__ AB,
                                                          const double* __restrict__ QR,
                                                          const double* __restrict__ rhs, double* F,
                                                          double* z, int* __restrict__ info,
