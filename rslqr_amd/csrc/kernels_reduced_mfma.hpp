@@ -55,9 +55,11 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 //      LDS and nobody waits for anybody -- stores X into the record and KEEPS it in registers
 //   C  r_a into LDS over the dead S-bar / W, from the registers of phase B (r_bb went into its own array there):
 //      no operand is fetched twice
-//   D  pushes: the wavefront that holds column tile c of f_a forms DR[A](:, c) = r_a' f_a(:, c) and half of the
-//      coupling tiles of its rows (r_a' S-bar^-1 r_bb = f_a' r_bb), the one that holds tile c of f_bb forms
-//      DL[B](:, c) and the other half (r_a' f_bb): six tile products each, the solved operand from registers
+//   D  pushes: the wavefront that holds column tile c of f_a forms the tiles of DR[A](:, c) = r_a' f_a(:, c) on and
+//      below the diagonal (DR, DL and S-bar are symmetric: their upper tiles are neither computed, stored nor
+//      read anywhere) and the coupling tiles (c, j <= c) as f_a' r_bb (= r_a' S-bar^-1 r_bb); the one that holds
+//      tile c of f_bb forms the lower tiles of DL[B](:, c) and the coupling tiles (i < c, c) as r_a' f_bb: NB + 1
+//      and NB tile products, the solved operand from registers
 // Written for memory-level parallelism: loads are unconditional on clamped indices and requested as early as
 // their address is known, LDS stores likewise (a store under a lane predicate makes the compiler sink its load
 // behind the predicate, and the loads then complete one after the other).
@@ -72,6 +74,13 @@ __host__ __device__ inline int reduced_lds_doubles(const int n, const int w) {
   return w + (w > n ? w : n) + 2 * n + big;  // dq (w), zc (later y of the z column: max(w, n)), q1, b~ (n each)
 }
 
+// lower-triangle tile t -> its block row (block column: t - row (row + 1) / 2)
+__device__ __forceinline__ int tri_row(const int t) {
+  int r = 0;
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  return r;
+}
+
 template <int NB, int NTHR, bool LEVEL0, bool PAD>
 __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
@@ -81,7 +90,8 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int n = 16 * NB, ns = n + 1;
   constexpr int NW = NTHR / 64;
-  constexpr int MAXS = (NB * NB + NW - 1) / NW;  // S-bar tiles per wavefront
+  constexpr int NT = NB * (NB + 1) / 2;          // tiles of the lower triangle of S-bar / DL / DR: all that is ever read
+  constexpr int MAXS = (NT + NW - 1) / NW;       // S-bar tiles per wavefront
   constexpr int MAXT = (2 * NB + NW - 1) / NW;   // panel column tiles (of r_a, r_bb) per wavefront
   constexpr int PR = n + 1;                      // pitch of r_a, r_bb in the push phase
   static_assert(NW >= NB && n / 4 <= 16, "work distribution of the shared phases");
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   double dlr[MAXS][8];
 #pragma unroll
   for (int idx = 0; idx < MAXS; ++idx) {
-    const int item = wave + idx * NW, itc = item < NB * NB ? item : NB * NB - 1, rt = itc / NB, ct = itc % NB;
+    const int item = wave + idx * NW, itc = item < NT ? item : NT - 1, rt = tri_row(itc), ct = itc - rt * (rt + 1) / 2;
     const int jc = 16 * ct + li < nl ? 16 * ct + li : nl - 1;  // (clamped addresses; the padding is masked at the use)
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     const double* brow[MAXS];
 #pragma unroll
     for (int idx = 0; idx < MAXS; ++idx) {
-      const int item = wave + idx * NW, itc = item < NB * NB ? item : NB * NB - 1, rt = itc / NB, ct = itc % NB;
+      const int item = wave + idx * NW, itc = item < NT ? item : NT - 1, rt = tri_row(itc), ct = itc - rt * (rt + 1) / 2;
       arow[idx] = stage + (16 * rt + li) * P + lk;
       brow[idx] = stage + (16 * ct + li) * P + lk;
 #pragma unroll
@@ -264,8 +274,8 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 #pragma unroll
   for (int idx = 0; idx < MAXS; ++idx) {
     const int item = wave + idx * NW;
-    if (item < NB * NB) {
-      const int rt = item / NB, ct = item % NB;
+    if (item < NT) {
+      const int rt = tri_row(item), ct = item - rt * (rt + 1) / 2;
       double* dst = S + (16 * rt + lk) * ns + 16 * ct + li;
 #pragma unroll
       for (int gg = 0; gg < 4; ++gg) {
@@ -486,35 +496,40 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
           const int i = 16 * rt + lk + 4 * gg;
-          pacc[rt][gg] = LEVEL0 ? 0.0 : pblk[(size_t)(i < nl ? i : nl - 1) * nl + jc];  // (padding: never stored)
+          // (tiles above the diagonal are neither kept nor read; padding: never stored)
+          pacc[rt][gg] = (LEVEL0 || rt < c) ? 0.0 : pblk[(size_t)(i < nl ? i : nl - 1) * nl + jc];
         }
     }
     if (gt < NB) {
-      // coupling tiles (a-tile c, bb-tile j), c + j even:  r_a' S-bar^-1 r_bb = f_a' r_bb
+      // coupling tiles (a-tile c, bb-tile j), j <= c:  r_a' S-bar^-1 r_bb = f_a' r_bb  (with the NB - c tiles of DR
+      // below: NB + 1 tile products for every wavefront of this half, NB for the other)
       if (hasB) {
-        for (int j = c & 1; j < NB; j += 2) {
+        for (int j = 0; j <= c; ++j) {
           if (leftchild)  // CA[B] = (f_a' r_bb)' = r_bb' f_a: rows bb-tile j, columns a-tile c
             push_tile(Rb, j, xk[m], false, slotB + 2 * nnl, j, c, zero4);
           else            // CB[A] = f_a' r_bb: rows a-tile c, columns bb-tile j
             push_tile(Rb, j, xk[m], true, slotA + 3 * nnl, c, j, zero4);
         }
       }
-      // DR[A](:, tile c) += r_a' f_a(:, tile c)
+      // DR[A](tiles on and below the diagonal, tile column c) += r_a' f_a(:, tile c): DR is symmetric and only its
+      // lower tiles are ever read
 #pragma unroll
-      for (int rt = 0; rt < NB; ++rt) push_tile(Ra, rt, xk[m], false, pblk, rt, c, pacc[rt]);
+      for (int rt = 0; rt < NB; ++rt)
+        if (rt >= c) push_tile(Ra, rt, xk[m], false, pblk, rt, c, pacc[rt]);
     } else {
-      // coupling tiles (a-tile i, bb-tile c), i + c odd:  r_a' f_bb
+      // coupling tiles (a-tile i, bb-tile c), i < c:  r_a' f_bb
       if (hasA) {
-        for (int i = (c & 1) ^ 1; i < NB; i += 2) {
+        for (int i = 0; i < c; ++i) {
           if (leftchild)  // CA[B] = (r_a' f_bb)' = f_bb' r_a: rows bb-tile c, columns a-tile i
             push_tile(Ra, i, xk[m], true, slotB + 2 * nnl, c, i, zero4);
           else            // CB[A] = r_a' f_bb: rows a-tile i, columns bb-tile c
             push_tile(Ra, i, xk[m], false, slotA + 3 * nnl, i, c, zero4);
         }
       }
-      // DL[B](:, tile c) += r_bb' f_bb(:, tile c)
+      // DL[B](tiles on and below the diagonal, tile column c) += r_bb' f_bb(:, tile c)
 #pragma unroll
-      for (int rt = 0; rt < NB; ++rt) push_tile(Rb, rt, xk[m], false, pblk, rt, c, pacc[rt]);
+      for (int rt = 0; rt < NB; ++rt)
+        if (rt >= c) push_tile(Rb, rt, xk[m], false, pblk, rt, c, pacc[rt]);
     }
   }
   // vector pushes gR[A] += r_a' z_sep (first wavefront), gL[B] += r_bb' z_sep (last): a column of r per lane

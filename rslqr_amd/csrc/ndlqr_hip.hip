@@ -385,7 +385,11 @@ static int ensure_red_generic(NdlqrHipCtx* c) {
       return NDLQR_ERR_INVALID;
     }
     *have = need;
+    // (zeros for the size-specialised schedule, should the context go back to it. hipMemset runs on the null
+    //  stream and may return before it is done; the solver's streams are non-blocking: wait here, or the
+    //  level-0 launch races with it)
     HIP_TRY(hipMemset(*slot, 0, need));
+    HIP_TRY(hipDeviceSynchronize());
   }
   return NDLQR_OK;
 }

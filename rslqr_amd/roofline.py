@@ -130,13 +130,15 @@ def generic_lean_model(n, m, N):
 
 
 def generic_reduced_model(n, m, N):
-    """Separator-only schedule of the tile-filling block sizes (separator_reduced_mfma once per level,
-    back-substitution over the records): config 5's path since round 2."""
+    """Separator-only schedule of the runtime-sized blocks (separator_reduced_mfma once per level,
+    back-substitution over the records): config 5's path since round 2. DL, DR (and S-bar) are symmetric: only
+    the 16x16 tiles on and below the diagonal are computed, stored and read."""
     K = int(math.log2(N))
     w, rows = n + m, 2 * n + m
     rec = 2 * n * n + n
-    slot = 4 * n * n + 2 * n
-    push = 3 * n * n + 2 * n           # DR + gR, DL + gL, one coupling block
+    sym = min(n * n, n * (n + 16) // 2)  # doubles of the lower tiles of an n x n block
+    slot = 2 * sym + 2 * n * n + 2 * n   # DL, DR (lower tiles) | CA | CB | gL | gR
+    push = 2 * sym + n * n + 2 * n       # DR + gR, DL + gL, one coupling block
     sep_b = 0
     for l in range(K):
         L = N >> (l + 1)
@@ -144,7 +146,7 @@ def generic_reduced_model(n, m, N):
         if l == 0:
             sep_b += L * (own + n * n + rec + push)         # + A_{s+1} (r_bb); the pushes are stores
         else:
-            sep_b += L * (own + slot + rec + push + (2 * n * n + 2 * n))  # + own slot; the pushes read-modify-write
+            sep_b += L * (own + slot + rec + push + (2 * sym + 2 * n))  # + own slot; the pushes read-modify-write
     return {
         "separator": {"bytes": 8 * sep_b, "flops": (N - 1) * separator_flops(n, w), "launches": K},
         "apply": {"bytes": 8 * ((N - 1) * rec + inputs_doubles(n, m, N) + N * rows),
