@@ -218,6 +218,8 @@ int ndlqr_hip_set_pipeline_depth(NdlqrHipCtx* c, int depth) {
     swap_slot(c);
     if (c->alt.z && c->z_latest == c->alt.z) {
       HIP_TRY(hipMemcpy(c->z, c->alt.z, bytes_z(c->d), hipMemcpyDeviceToDevice));
+      HIP_TRY(hipDeviceSynchronize());  // (a device-to-device copy on the null stream need not be finished on return;
+                                        //  the solver's streams do not wait for the null stream)
       c->z_latest = c->z;
     }
   }
