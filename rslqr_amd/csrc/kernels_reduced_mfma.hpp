@@ -1,7 +1,8 @@
-// kernels_reduced_mfma.hpp -- the separator-only ("reduced") schedule for blocks that fill 16x16
-// matrix-core tiles (nstates a multiple of 16, nstates + ninputs of 4: BASELINE.json config 5's
-// (64,16)). Fast mode without KEEP. One kernel, launched once per tree level; no factor array, no
-// knot states, no leaf pass, no Schur pass.
+// kernels_reduced_mfma.hpp -- the separator-only ("reduced") schedule for every block size up to 64 states
+// that has no size-specialised instance, on 16x16 matrix-core tiles (BASELINE.json config 5's (64,16) fills
+// them; other sizes are zero-padded in LDS). Fast mode without KEEP_FACT. One kernel, launched once per tree
+// level; no factor array, no knot states, no leaf pass, no Schur pass. With NDLQR_FLAG_KEEP_RECORDS the sweep
+// also keeps W = L^-1 of every separator, and rhs_reduced_generic (below) re-solves for new right-hand sides.
 //
 // DESIGN.md section 3.1 (same algebra as kernels_bottom_reduced.hpp, which serves 6 <= n <= 15):
 // eliminating the states and inputs of every knot (ndlqr_SolveLeaf, src/nested_dissection.c:10-105)
@@ -40,11 +41,12 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 
 // NB = ceil(n / 16), NTHR threads (a multiple of 64, at least 64 NB and max(16 NB, n + m rounded up to 4)).
 //   grid (N >> (l+1), batch), block NTHR;
-//   dynamic LDS = reduced_lds_doubles(n, w) doubles: the weights / rhs arrays, then a region that first holds the
-//   staged [A_s | B_s] (n rows of reduced_stage_pitch(w)), then S-bar / L / W (n x (n + 1)), the inverses of the
-//   diagonal blocks (17 n) and r_bb (n x (n + 1)); r_a goes over S-bar once W is dead. 77 KB at (64,16): two
-//   workgroups per CU.
-// LEVEL0: the launch of tree level 0 (couplings from the problem data, pushes are stores).
+//   dynamic LDS = reduced_lds_doubles(padded n, padded w) doubles: the weights / rhs arrays, then a region that
+//   first holds the staged [A_s | B_s] (n rows of reduced_stage_pitch(w)), then S-bar / L / W (n x (n + 1)), the
+//   inverses of the diagonal blocks (17 n) and r_bb (n x (n + 1)); r_a goes over S-bar once W is dead. 77 KB at
+//   (64,16): two workgroups per CU.
+// LEVEL0: the launch of tree level 0 (couplings from the problem data, pushes are stores). PAD: see below.
+// wfac != nullptr: NDLQR_FLAG_KEEP_RECORDS.
 //
 // Phases (workgroup barriers only between them):
 //   A  stage [A_s | B_s]; leafS tiles on the matrix cores; S-bar = leafS - DL - DR + Q_{s+1}^-1 into LDS; blocked
@@ -63,6 +65,7 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 // Written for memory-level parallelism: loads are unconditional on clamped indices and requested as early as
 // their address is known, LDS stores likewise (a store under a lane predicate makes the compiler sink its load
 // behind the predicate, and the loads then complete one after the other).
+
 // what a separator keeps for the record-based re-solve: the n x (n + 1) array that holds W below its diagonal
 // blocks, then the inverses of the diagonal blocks (n / 16 blocks of 16 x 17); n = padded block size
 __host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * (n + 1) + 17 * n; }
