@@ -16,7 +16,7 @@
 // A = base - 1 and B = base + 2^(l+1) - 1 (both of a higher level):
 //     S-bar = leafS - DL - DR      R = [r_a | r_bb | b~],  r_a = -CA, r_bb = -CB (level 0: from the data),
 //                                  b~ = leafb - gL - gR
-//     X = S-bar^-1 R = [f_a | f_bb | z_sep]                  -> record of s (back-substitution)
+//     X = S-bar^-1 R = [f_a | f_bb | z_sep]                  -> record of s (back-substitution; level 0: W | z_sep)
 //     DR[A] += r_a' f_a    gR[A] += r_a' z_sep    DL[B] += r_bb' f_bb    gL[B] += r_bb' z_sep
 //     left child of B:  CA[B] = f_bb' r_a          right child of A:  CB[A] = r_a' f_bb
 // Every slot block has ONE writer per launch (a separator has one left and one right neighbour, a
@@ -318,6 +318,17 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     double* wf = wfac + ((size_t)b * N + s) * WF;
     for (int e = tid; e < WF; e += NTHR) wf[e] = S[e];  // (S and Wd are contiguous)
   }
+  if constexpr (LEVEL0) {
+    // compact level-0 record: W, lower triangle packed with the problem's own size (entry (i, k), k <= i, at
+    // i (i + 1) / 2 + k), instead of f_a | f_bb -- a quarter of the bytes; the back-substitution of level 0
+    // (backsub_level0_states_generic) forms f_a y_A + f_bb y_B = W'W (r_a y_A + r_bb y_B) from the problem data it
+    // reads anyway. A row per wavefront and round.
+    for (int i = wave; i < nl; i += NW) {
+      double* dst = myrec + (size_t)i * (i + 1) / 2;
+      for (int k = lane; k <= i; k += 64)
+        dst[k] = (i >> 4) == (k >> 4) ? Wd[(i >> 4) * 16 * 17 + (i & 15) * 17 + (k & 15)] : S[i * ns + k];
+    }
+  }
   // ---- z_sep = W'(W b~) on the vector ALU, all wavefronts: eight rows per wavefront, eight lanes per row (a
   //      seventeenth column does not pay a matrix-core tile, and one wavefront alone would keep the others waiting)
   auto w_ptr = [&](const int r, const int cidx) -> const double* {  // &W(r, cidx), cidx <= r
@@ -429,7 +440,8 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
       xk[m][it] = acc;
     }
     // record f_a | f_bb | z_sep (what the back-substitution reads): rows 16 it + lk + 4 g, columns 16 c + li
-    if ((gt < NB ? hasA : hasB) && (!PAD || 16 * c + li < nl)) {
+    // (level 0 keeps the compact record written above instead)
+    if (!LEVEL0 && (gt < NB ? hasA : hasB) && (!PAD || 16 * c + li < nl)) {
       double* dst = myrec + (gt < NB ? 0 : nnl) + (size_t)lk * nl + 16 * c + li;
 #pragma unroll
       for (int it = 0; it < NB; ++it)
@@ -684,6 +696,142 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
       }, nl);
       if (cseg == 0 && cj < nl) dst[cj] += g;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------- back-substitution, level 0
+// The last step of the back-substitution of the separator-only schedule above, one workgroup per level-0
+// separator s = 2 j, i.e. per pair of knots (s, s + 1): its multiplier from the compact record
+//     y_s = z_sep - W'W (r_a y_{s-1} + r_bb y_{s+1}),   r_a = -A_s Q_s^-1,  r_bb = -Q_{s+1}^-1 A_{s+1}'
+// (the multipliers next to it are final: levels >= 1 ran before, backsub_multipliers_generic), then the states
+// and inputs of both knots (the arithmetic of backsub_states_generic) -- [A | B] of the two knots comes from HBM
+// once for both, and level 0's f_a | f_bb never exist in memory.
+//   grid (N / 2, batch), block 256, dynamic LDS = n (n + 1) / 2 + 5 n + 4 (n + m) + 2 (2 n + m) + 256 doubles.
+static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims d, const double* __restrict__ AB,
+                                                                            const double* __restrict__ QR,
+                                                                            const double* __restrict__ rhs,
+                                                                            const double* __restrict__ rec,
+                                                                            double* z) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = d.n, w = d.w, N = d.N, rows = d.rows, nn = n * n;
+  const int b = blockIdx.y, s = 2 * blockIdx.x;
+  const bool hasA = s > 0, hasB = s + 2 < N;
+  double* Wp = sm;                      // W, packed lower triangle
+  double* yA = Wp + n * (n + 1) / 2;    // y_{s-1}, then y_{s-1} / Q_s
+  double* yB = yA + n;                  // y_{s+1}
+  double* ys = yB + n;                  // y_s
+  double* tv = ys + n;                  // r_a y_A + r_bb y_B, then W t
+  double* zs = tv + n;                  // z_sep
+  double* d0 = zs + n;                  // [A_s | B_s]' y_s
+  double* d1 = d0 + w;                  // [A_{s+1} | B_{s+1}]' y_{s+1}
+  double* qv = d1 + w;                  // [Q | R] of knots s, s + 1
+  double* rv = qv + 2 * w;              // raw right-hand sides of knots s, s + 1
+  double* part = rv + 2 * rows;         // partial column sums (256)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* ab = AB + ((size_t)b * N + s) * n * w;
+  const double* ab1 = ab + (size_t)n * w;
+  const double* qr = QR + ((size_t)b * N + s) * w;
+  const double* r0 = rhs + ((size_t)b * N + s) * rows;
+  const double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nn + n);
+  double* zk = z + ((size_t)b * N + s) * rows;  // knot s; y_{s-1} lives in its lambda rows, y_s in those of knot s + 1
+  auto wave_sum = [](double v) -> double {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  // out[c] = sum_j m[j * w + c] y[j], c < w (a block transposed times a vector): thread (c, seg) sums the rows
+  // j = seg, seg + nseg, .. -- consecutive threads read consecutive words of a row of the block
+  auto block_t_times = [&](const double* m, const double* y, double* out) {
+    const int nseg = w <= 128 ? 256 / w : 1;
+    if (nseg > 1) {
+      const int c = tid % w, seg = tid / w;
+      double acc = 0.0;
+      if (seg < nseg) {
+        for (int j0 = seg; j0 < n; j0 += 4 * nseg) {  // four loads in flight
+          double mv[4], yv4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * nseg, jc = j < n ? j : n - 1;
+            mv[u] = m[(size_t)jc * w + c];
+            yv4[u] = j < n ? y[jc] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = fma(mv[u], yv4[u], acc);
+        }
+        part[tid] = acc;
+      }
+      __syncthreads();
+      if (seg == 0) {
+        double tot = 0.0;
+        for (int g = 0; g < nseg; ++g) tot += part[g * w + c];
+        out[c] = tot;
+      }
+      __syncthreads();
+    } else {
+      for (int c = tid; c < w; c += 256) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc = fma(m[(size_t)j * w + c], y[j], acc);
+        out[c] = acc;
+      }
+      __syncthreads();
+    }
+  };
+
+  for (int e = tid; e < n * (n + 1) / 2; e += 256) Wp[e] = myrec[e];
+  for (int i = tid; i < n; i += 256) {
+    yA[i] = hasA ? zk[i] : 0.0;
+    yB[i] = hasB ? zk[2 * rows + i] : 0.0;
+    zs[i] = myrec[2 * nn + i];
+  }
+  for (int e = tid; e < 2 * w; e += 256) qv[e] = qr[e];
+  for (int e = tid; e < 2 * rows; e += 256) rv[e] = r0[e];
+  __syncthreads();
+  block_t_times(ab1, yB, d1);  // [A_{s+1} | B_{s+1}]' y_{s+1}: enters t, x_{s+1} and u_{s+1}
+  // t = r_a y_A + r_bb y_B = -A_s (y_A / Q_s) - (A_{s+1}' y_{s+1}) / Q_{s+1}: a row of A_s per wavefront and round
+  for (int i = wave; i < n; i += 4) {
+    double acc = 0.0;
+    if (hasA)
+      for (int j = lane; j < n; j += 64) acc = fma(ab[(size_t)i * w + j], yA[j] / qv[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) tv[i] = -acc - (hasB ? d1[i] / qv[w + i] : 0.0);
+  }
+  __syncthreads();
+  // v = W t (a row per wavefront and round), then y_s = z_sep - W'v (a column per thread)
+  for (int i = wave; i < n; i += 4) {
+    double acc = 0.0;
+    for (int k = lane; k <= i; k += 64) acc = fma(Wp[i * (i + 1) / 2 + k], tv[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) ys[i] = acc;  // (v, for the moment)
+  }
+  __syncthreads();
+  double yi = 0.0;
+  if (tid < n) {  // (n <= 64)
+    double acc = 0.0;
+    for (int k = tid; k < n; ++k) acc = fma(Wp[k * (k + 1) / 2 + tid], ys[k], acc);
+    yi = zs[tid] - acc;
+  }
+  __syncthreads();
+  if (tid < n) {
+    ys[tid] = yi;
+    zk[rows + tid] = yi;  // lambda rows of knot s + 1
+  }
+  __syncthreads();
+  block_t_times(ab, ys, d0);  // [A_s | B_s]' y_s  (second pass over the block: L2)
+  // states and inputs of knots s and s + 1 (the arithmetic of backsub_states_generic); thread -> (knot, row)
+  for (int e = tid; e < 2 * rows; e += 256) {
+    const int kk = e / rows, r = e - kk * rows, k = s + kk;
+    if (r < n && k > 0) continue;  // lambda rows of knots >= 1 are the multipliers already
+    const double* ykm = kk ? ys : yA;     // y_{k-1}
+    const double* q = qv + kk * w;
+    const double* rr = rv + kk * rows;
+    const int col = r < n ? r : r - n;    // column of [A_k | B_k] this row meets
+    double dot = 0.0;
+    if (k < N - 1 && !(k == 0 && r >= n && r < 2 * n)) dot = (kk ? d1 : d0)[col];
+    double out;
+    if (r < n) out = fma(-q[r], rr[r], -rr[n + r]) + dot;                                 // knot 0: Q x0 + q + A_0' y_0
+    else if (r < 2 * n) out = (k == 0) ? -rr[r - n] : (rr[r] - dot + ykm[r - n]) / q[r - n];  // x_k
+    else out = (k == N - 1) ? rr[r] : (rr[r] - dot) / q[r - n];                            // u_k
+    zk[(size_t)kk * rows + r] = out;
   }
 }
 

@@ -409,6 +409,19 @@ static void launch_backsub_generic(NdlqrHipCtx* c) {
                      c->AB, c->QR, c->rhs, c->z);
 }
 
+// the same for the runtime-sized separator-only schedule: its level-0 records are compact (W instead of f_a | f_bb),
+// and one launch resolves the level-0 multipliers and the states / inputs of every knot
+static void launch_backsub_reduced_generic(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  ScopedSlot t(c, SLOT_APPLY);
+  for (int l = d.K - 1; l >= 1; --l)
+    hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
+                       c->rec, c->z);
+  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 5 * (size_t)d.n + 4 * (size_t)d.w + 2 * (size_t)d.rows + 256);
+  hipLaunchKernelGGL(ndlqr::backsub_level0_states_generic, dim3(d.N >> 1, d.batch), dim3(256), lds, c->stream, d, c->AB,
+                     c->QR, c->rhs, c->rec, c->z);
+}
+
 static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
   const ndlqr::Dims& d = c->d;
   c->schedule = p.keep ? "generic-reduced-records" : "generic-reduced";
@@ -435,7 +448,7 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
 #undef NDLQR_LAUNCH_SEP2
 #undef NDLQR_LAUNCH_SEP
   }
-  launch_backsub_generic(c);
+  launch_backsub_reduced_generic(c);
   return NDLQR_OK;
 }
 
@@ -449,7 +462,7 @@ static void launch_rhs_reduced_generic(NdlqrHipCtx* c) {
     hipLaunchKernelGGL(ndlqr::rhs_reduced_generic, dim3(d.N >> (l + 1), d.batch), dim3(256), lds, c->stream, d, l, np,
                        c->AB, c->QR, c->rhs, c->red, c->rec, c->wfac);
   }
-  launch_backsub_generic(c);
+  launch_backsub_reduced_generic(c);
 }
 
 template <bool STRICT>
