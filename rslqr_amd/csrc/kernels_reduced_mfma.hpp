@@ -747,16 +747,16 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
       const int c = tid % w, seg = tid / w;
       double acc = 0.0;
       if (seg < nseg) {
-        for (int j0 = seg; j0 < n; j0 += 4 * nseg) {  // four loads in flight
-          double mv[4], yv4[4];
+        for (int j0 = seg; j0 < n; j0 += 8 * nseg) {  // eight loads in flight
+          double mv[8], yv8[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 8; ++u) {
             const int j = j0 + u * nseg, jc = j < n ? j : n - 1;
             mv[u] = m[(size_t)jc * w + c];
-            yv4[u] = j < n ? y[jc] : 0.0;
+            yv8[u] = j < n ? y[jc] : 0.0;
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc = fma(mv[u], yv4[u], acc);
+          for (int u = 0; u < 8; ++u) acc = fma(mv[u], yv8[u], acc);
         }
         part[tid] = acc;
       }
@@ -788,12 +788,24 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   __syncthreads();
   block_t_times(ab1, yB, d1);  // [A_{s+1} | B_{s+1}]' y_{s+1}: enters t, x_{s+1} and u_{s+1}
   // t = r_a y_A + r_bb y_B = -A_s (y_A / Q_s) - (A_{s+1}' y_{s+1}) / Q_{s+1}: a row of A_s per wavefront and round
-  for (int i = wave; i < n; i += 4) {
-    double acc = 0.0;
-    if (hasA)
-      for (int j = lane; j < n; j += 64) acc = fma(ab[(size_t)i * w + j], yA[j] / qv[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) tv[i] = -acc - (hasB ? d1[i] / qv[w + i] : 0.0);
+  for (int i0 = 4 * wave; i0 < n; i0 += 16) {  // (four rows per wavefront and round: four loads in flight)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (hasA) {
+      for (int j = lane; j < n; j += 64) {
+        const double yq = yA[j] / qv[j];
+        double av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = ab[(size_t)(i0 + u < n ? i0 + u : n - 1) * w + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fma(av[u], yq, acc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double a = wave_sum(acc[u]);
+      const int i = i0 + u;
+      if (lane == 0 && i < n) tv[i] = -a - (hasB ? d1[i] / qv[w + i] : 0.0);
+    }
   }
   __syncthreads();
   // v = W t (a row per wavefront and round), then y_s = z_sep - W'v (a column per thread)
