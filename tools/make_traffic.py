@@ -18,7 +18,8 @@ import bench  # noqa: E402  (csrc_sha)
 
 SLOTS = [("bottom", ("bottom_reduced_mc", "bottom_small", "rb_bottom")),
          ("upper", ("reduced_level_mc", "level_small")),
-         ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_states_generic")),
+         ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_states_generic",
+                    "backsub_level0_states_generic")),
          ("leaf", ("leaf_generic",)),
          ("separator", ("separator_generic", "separator_mfma", "separator_reduced_mfma")),
          ("schur_boundary", ("schur_mfma", "schur_generic")),
@@ -41,7 +42,8 @@ def main():
     fetch, write = agg(fpath), agg(wpath)
     K = N.bit_length() - 1
     # solves in the profiled process = launches of the once-per-solve kernel
-    once = [c[0] for k, c in fetch.items() if any(s in k for s in ("bottom_", "rb_bottom", "leaf_generic", "backsub_states_generic"))]
+    once = [c[0] for k, c in fetch.items() if any(s in k for s in ("bottom_", "rb_bottom", "leaf_generic", "backsub_states_generic",
+                                                             "backsub_level0_states_generic"))]
     solves = max(once) if once else 1
     kernels = {}
     for slot, pats in SLOTS:
