@@ -74,7 +74,7 @@ __host__ __device__ inline int reduced_lds_doubles(const int n, const int w) {
   int big = n * reduced_stage_pitch(w);                 // staged [A_s | B_s]
   const int later = n * (n + 1) + 17 * n + n * (n + 1);  // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
   if (later > big) big = later;
-  return w + (w > n ? w : n) + 2 * n + big;  // dq (w), zc (later y of the z column: max(w, n)), q1, b~ (n each)
+  return w + (w > n ? w : n) + 3 * n + big;  // dq (w), zc (later y of the z column: max(w, n)), q1, b~, z_sep (n each)
 }
 
 // lower-triangle tile t -> its block row (block column: t - row (row + 1) / 2)
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   double* dq = sm;           // 1 / [Q_s | R_s]  (state entries of knot 0: zero -- its state is fixed)
   double* zc = dq + wp;      // rhs(s).xu scaled likewise (state entries of knot 0: -x0)
   double* q1 = zc + (wp > n ? wp : n);  // 1 / Q_{s+1}  (zc doubles as the y of the z column: n entries)
-  double* bz = q1 + n;       // b~, later z_sep
-  double* S = bz + n;        // S-bar / L / W
+  double* bz = q1 + n;       // b~
+  double* zsv = bz + n;      // z_sep
+  double* S = zsv + n;       // S-bar / L / W
   double* Wd = S + n * ns;   // NB blocks of 16 x 17: inverses of the diagonal blocks of L
   double* stage = S;         // [A_s | B_s], pitch P, until S-bar is formed
   double* Ra = S;            // r_a (pitch PR) once W is dead
@@ -352,8 +353,6 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     if (sg == 0) zc[i] = acc;  // (zc is dead since the leafS products)
   }
   __syncthreads();
-  double zsep = 0.0;  // lanes with sg == 0: z_sep(i) of the row they reduced
-  int zrow = -1;
   for (int i0 = 8 * wave; i0 < n; i0 += 8 * NW) {  // z_sep = W'y
     const int i = i0 + (lane >> 3), sg = lane & 7;
     double wv[n / 8], yv[n / 8];
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
     acc += __shfl_xor(acc, 4, 64);
     if (sg == 0) {
       if (i < nl) myrec[2 * nnl + i] = acc;
-      zsep = acc; zrow = i;
+      zsv[i] = acc;  // for the vector pushes (phase D)
     }
   }
   // ================================================================================================= phase B
@@ -465,8 +464,6 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
         for (int q = 0; q < 4; ++q) Ra[(16 * kb + 4 * q + lk) * PR + 16 * gt + li] = rfk[m][kb][q];
     }
   }
-  // z_sep for the vector pushes (b~ is dead: the barrier above)
-  if (zrow >= 0) bz[zrow] = zsep;
   __syncthreads();
   SEG(58);
 
@@ -560,7 +557,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
         for (int k0 = 0; k0 < n; k0 += 8) {
           double rv[8], zv[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { rv[u] = R[(k0 + u) * PR + j]; zv[u] = bz[k0 + u]; }
+          for (int u = 0; u < 8; ++u) { rv[u] = R[(k0 + u) * PR + j]; zv[u] = zsv[k0 + u]; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc = fma(rv[u], zv[u], acc);
         }
@@ -706,7 +703,8 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
 // (the multipliers next to it are final: levels >= 1 ran before, backsub_multipliers_generic), then the states
 // and inputs of both knots (the arithmetic of backsub_states_generic) -- [A | B] of the two knots comes from HBM
 // once for both, and level 0's f_a | f_bb never exist in memory.
-//   grid (N / 2, batch), block 256, dynamic LDS = n (n + 1) / 2 + 5 n + 4 (n + m) + 2 (2 n + m) + 256 doubles.
+//   grid (N / 2, batch), block 64 / 128 / 256 (by block size), dynamic LDS = n (n + 1) / 2 + 5 n + 4 (n + m) +
+//   2 (2 n + m) + block doubles.
 static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims d, const double* __restrict__ AB,
                                                                             const double* __restrict__ QR,
                                                                             const double* __restrict__ rhs,
@@ -726,8 +724,8 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   double* d1 = d0 + w;                  // [A_{s+1} | B_{s+1}]' y_{s+1}
   double* qv = d1 + w;                  // [Q | R] of knots s, s + 1
   double* rv = qv + 2 * w;              // raw right-hand sides of knots s, s + 1
-  double* part = rv + 2 * rows;         // partial column sums (256)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* part = rv + 2 * rows;         // partial column sums (one per thread)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   const double* ab = AB + ((size_t)b * N + s) * n * w;
   const double* ab1 = ab + (size_t)n * w;
   const double* qr = QR + ((size_t)b * N + s) * w;
@@ -742,7 +740,7 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   // out[c] = sum_j m[j * w + c] y[j], c < w (a block transposed times a vector): thread (c, seg) sums the rows
   // j = seg, seg + nseg, .. -- consecutive threads read consecutive words of a row of the block
   auto block_t_times = [&](const double* m, const double* y, double* out) {
-    const int nseg = w <= 128 ? 256 / w : 1;
+    const int nseg = 2 * w <= nthr ? nthr / w : 1;
     if (nseg > 1) {
       const int c = tid % w, seg = tid / w;
       double acc = 0.0;
@@ -768,7 +766,7 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
       }
       __syncthreads();
     } else {
-      for (int c = tid; c < w; c += 256) {
+      for (int c = tid; c < w; c += nthr) {
         double acc = 0.0;
         for (int j = 0; j < n; ++j) acc = fma(m[(size_t)j * w + c], y[j], acc);
         out[c] = acc;
@@ -777,18 +775,18 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
     }
   };
 
-  for (int e = tid; e < n * (n + 1) / 2; e += 256) Wp[e] = myrec[e];
-  for (int i = tid; i < n; i += 256) {
+  for (int e = tid; e < n * (n + 1) / 2; e += nthr) Wp[e] = myrec[e];
+  for (int i = tid; i < n; i += nthr) {
     yA[i] = hasA ? zk[i] : 0.0;
     yB[i] = hasB ? zk[2 * rows + i] : 0.0;
     zs[i] = myrec[2 * nn + i];
   }
-  for (int e = tid; e < 2 * w; e += 256) qv[e] = qr[e];
-  for (int e = tid; e < 2 * rows; e += 256) rv[e] = r0[e];
+  for (int e = tid; e < 2 * w; e += nthr) qv[e] = qr[e];
+  for (int e = tid; e < 2 * rows; e += nthr) rv[e] = r0[e];
   __syncthreads();
   block_t_times(ab1, yB, d1);  // [A_{s+1} | B_{s+1}]' y_{s+1}: enters t, x_{s+1} and u_{s+1}
   // t = r_a y_A + r_bb y_B = -A_s (y_A / Q_s) - (A_{s+1}' y_{s+1}) / Q_{s+1}: a row of A_s per wavefront and round
-  for (int i0 = 4 * wave; i0 < n; i0 += 16) {  // (four rows per wavefront and round: four loads in flight)
+  for (int i0 = 4 * wave; i0 < n; i0 += 4 * nwave) {  // (four rows per wavefront and round: four loads in flight)
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     if (hasA) {
       for (int j = lane; j < n; j += 64) {
@@ -809,7 +807,7 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   }
   __syncthreads();
   // v = W t (a row per wavefront and round), then y_s = z_sep - W'v (a column per thread)
-  for (int i = wave; i < n; i += 4) {
+  for (int i = wave; i < n; i += nwave) {
     double acc = 0.0;
     for (int k = lane; k <= i; k += 64) acc = fma(Wp[i * (i + 1) / 2 + k], tv[k], acc);
     acc = wave_sum(acc);
@@ -830,7 +828,7 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   __syncthreads();
   block_t_times(ab, ys, d0);  // [A_s | B_s]' y_s  (second pass over the block: L2)
   // states and inputs of knots s and s + 1 (the arithmetic of backsub_states_generic); thread -> (knot, row)
-  for (int e = tid; e < 2 * rows; e += 256) {
+  for (int e = tid; e < 2 * rows; e += nthr) {
     const int kk = e / rows, r = e - kk * rows, k = s + kk;
     if (r < n && k > 0) continue;  // lambda rows of knots >= 1 are the multipliers already
     const double* ykm = kk ? ys : yA;     // y_{k-1}

@@ -341,7 +341,9 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   p.nb = (d.n + 15) / 16;
   const int npad = 16 * p.nb, wpad = (d.w + 3) / 4 * 4;
   p.pad = npad != d.n || wpad != d.w;  // blocks that do not fill their tiles: zero-padded in LDS (PAD instances)
-  p.threads = p.nb >= 3 ? 512 : 256;
+  // one wavefront per 16x16 block where the weights fit its lanes: many small workgroups fill the chip better than
+  // a four-wavefront workgroup whose phases are mostly serial at this size
+  p.threads = p.nb >= 3 ? 512 : (p.nb == 1 && wpad <= 64 ? 64 : 256);
   if (wpad > p.threads) return p;  // one weight / rhs entry per thread
   p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(npad, wpad);
   if (p.lds > 160 * 1024) return p;
@@ -417,8 +419,9 @@ static void launch_backsub_reduced_generic(NdlqrHipCtx* c) {
   for (int l = d.K - 1; l >= 1; --l)
     hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
                        c->rec, c->z);
-  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 5 * (size_t)d.n + 4 * (size_t)d.w + 2 * (size_t)d.rows + 256);
-  hipLaunchKernelGGL(ndlqr::backsub_level0_states_generic, dim3(d.N >> 1, d.batch), dim3(256), lds, c->stream, d, c->AB,
+  const int thr = d.n <= 16 ? 64 : (d.n <= 32 ? 128 : 256);  // (its y_s step wants n <= threads)
+  const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 5 * (size_t)d.n + 4 * (size_t)d.w + 2 * (size_t)d.rows + thr);
+  hipLaunchKernelGGL(ndlqr::backsub_level0_states_generic, dim3(d.N >> 1, d.batch), dim3(thr), lds, c->stream, d, c->AB,
                      c->QR, c->rhs, c->rec, c->z);
 }
 
@@ -440,7 +443,10 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
     else NDLQR_LAUNCH_SEP2(NB_, NT_, false, false);                         \
   } while (0)
     switch (p.nb) {
-      case 1: NDLQR_LAUNCH_SEP(1, 256); break;
+      case 1:
+        if (p.threads == 64) NDLQR_LAUNCH_SEP(1, 64);
+        else NDLQR_LAUNCH_SEP(1, 256);
+        break;
       case 2: NDLQR_LAUNCH_SEP(2, 256); break;
       case 3: NDLQR_LAUNCH_SEP(3, 512); break;
       default: NDLQR_LAUNCH_SEP(4, 512); break;
