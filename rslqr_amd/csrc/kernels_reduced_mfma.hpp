@@ -47,6 +47,11 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 //   (64,16): two workgroups per CU.
 // LEVEL0: the launch of tree level 0 (couplings from the problem data, pushes are stores). PAD: see below.
 // wfac != nullptr: NDLQR_FLAG_KEEP_RECORDS.
+// NTHR = 64 NB ("two rounds"): every wavefront solves column tile c of r_a AND of r_bb; the pushes run in two rounds on
+// ONE coupling array in LDS (r_a, then r_bb, each fetched again from L2) -- 45 KB instead of 77 KB at (64,16), so
+// that THREE workgroups share a CU. The kernel is bound by the latency chain of a workgroup, not by its
+// matrix-core time: four wavefronts per workgroup cost 4 % of a workgroup's throughput, the third workgroup
+// brings 50 % more of them.
 //
 // Phases (workgroup barriers only between them):
 //   A  stage [A_s | B_s]; leafS tiles on the matrix cores; S-bar = leafS - DL - DR + Q_{s+1}^-1 into LDS; blocked
@@ -70,9 +75,12 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 // blocks, then the inverses of the diagonal blocks (n / 16 blocks of 16 x 17); n = padded block size
 __host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * (n + 1) + 17 * n; }
 
-__host__ __device__ inline int reduced_lds_doubles(const int n, const int w) {
-  int big = n * reduced_stage_pitch(w);                 // staged [A_s | B_s]
-  const int later = n * (n + 1) + 17 * n + n * (n + 1);  // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
+// two_round: one wavefront per tile column (NTHR = 64 NB): r_a and r_bb take turns in ONE array over the dead
+// S-bar / W (no separate r_bb array)
+__host__ __device__ inline int reduced_lds_doubles(const int n, const int w, const bool two_round) {
+  int big = n * reduced_stage_pitch(w);  // staged [A_s | B_s]
+  // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
+  const int later = n * (n + 1) + 17 * n + (two_round ? 0 : n * (n + 1));
   if (later > big) big = later;
   return w + (w > n ? w : n) + 3 * n + big;  // dq (w), zc (later y of the z column: max(w, n)), q1, b~, z_sep (n each)
 }
@@ -84,8 +92,12 @@ __device__ __forceinline__ int tri_row(const int t) {
   return r;
 }
 
+// wavefronts per SIMD the register budget is cut for: what LDS lets share a CU (two-round mode at n = 48, 64: three or
+// four workgroups of NB wavefronts)
+constexpr int reduced_min_waves(const int nb, const int nthr) { return (nthr == 64 * nb && nb >= 3) ? 3 : 4; }
+
 template <int NB, int NTHR, bool LEVEL0, bool PAD>
-__global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
+__global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
                                                                   const double* __restrict__ rhs, double* red,
                                                                   double* __restrict__ rec, int* __restrict__ info,
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   constexpr int MAXS = (NT + NW - 1) / NW;       // S-bar tiles per wavefront
   constexpr int MAXT = (2 * NB + NW - 1) / NW;   // panel column tiles (of r_a, r_bb) per wavefront
   constexpr int PR = n + 1;                      // pitch of r_a, r_bb in the push phase
+  constexpr bool TWO = NW == NB;                 // two-round pushes on one coupling array (see above)
   static_assert(NW >= NB && n / 4 <= 16, "work distribution of the shared phases");
   // PAD: the block does not fill its tiles (nl < n rows / columns, or n + m not a multiple of 4). Everything in
   // global memory keeps the problem's own pitch nl; LDS holds the padded tiles: zero rows / columns of [A | B], r_a,
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   double* Wd = S + n * ns;   // NB blocks of 16 x 17: inverses of the diagonal blocks of L
   double* stage = S;         // [A_s | B_s], pitch P, until S-bar is formed
   double* Ra = S;            // r_a (pitch PR) once W is dead
-  double* Rb = Wd + 17 * n;  // r_bb (pitch PR), written in phase B
+  double* Rb = TWO ? S : Wd + 17 * n;  // r_bb (pitch PR): written in phase B, or (two rounds) staged over r_a
   const int P = reduced_stage_pitch(wp);
   const int tid = threadIdx.x;
   // (the wavefront index as a scalar: everything that depends on it branches uniformly)
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
         for (int q = 0; q < 4; ++q) {
           const bool in = hasB && (!PAD || (16 * kb + 4 * q + lk < nl && 16 * c + li < nl));
           rf[kb][q] = !in ? 0.0 : LEVEL0 ? -rf[kb][q] * q1[16 * kb + 4 * q + lk] : -rf[kb][q];
-          Rb[(16 * kb + 4 * q + lk) * PR + 16 * c + li] = rf[kb][q];  // operand of the push phase
+          if constexpr (!TWO) Rb[(16 * kb + 4 * q + lk) * PR + 16 * c + li] = rf[kb][q];  // operand of the push phase
         }
     }
     // Y = W R: block lower triangular; block (it, kb) of W as A operand (row li, k = 4 q + lk)
@@ -454,14 +467,40 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   SEG(56);
 
   // ================================================================================================= phase C
+  // coupling block from global memory (L2: it was read in phase B) into the coupling array, padded and masked
+  auto stage_coupling = [&](const bool a_side) {
+    constexpr int RS = (n * n + NTHR - 1) / NTHR;
+    const bool have = a_side ? hasA : hasB;
+    double t[RS];
 #pragma unroll
-  for (int m = 0; m < MAXT; ++m) {
-    const int gt = wave + m * NW;
-    if (gt < NB) {
+    for (int u = 0; u < RS; ++u) {
+      const int e = tid + u * NTHR, ec = e < n * n ? e : n * n - 1, hi = ec / n, lo = ec % n;
+      const int hc = hi < nl ? hi : nl - 1, lc = lo < nl ? lo : nl - 1;
+      // level 0: r_a(k, j) = -A_s(k, j) / Q_s(j);  r_bb(k, j) = -A_{s+1}(j, k) / Q_{s+1}(k): walk the rows of A_{s+1}
+      if (a_side) t[u] = LEVEL0 ? ab[(size_t)hc * w + lc] : myslot[2 * nnl + hc * nl + lc];
+      else t[u] = LEVEL0 ? ab1[(size_t)hc * w + lc] : myslot[3 * nnl + hc * nl + lc];
+    }
 #pragma unroll
-      for (int kb = 0; kb < NB; ++kb)
+    for (int u = 0; u < RS; ++u) {
+      const int e = tid + u * NTHR, ec = e < n * n ? e : n * n - 1, hi = ec / n, lo = ec % n;
+      const bool in = have && hi < nl && lo < nl;
+      if (a_side) S[hi * PR + lo] = !in ? 0.0 : LEVEL0 ? -t[u] * dq[lo] : -t[u];
+      else if (LEVEL0) S[lo * PR + hi] = !in ? 0.0 : -t[u] * q1[lo];
+      else S[hi * PR + lo] = !in ? 0.0 : -t[u];
+    }
+  };
+  if constexpr (TWO) {
+    stage_coupling(true);
+  } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Ra[(16 * kb + 4 * q + lk) * PR + 16 * gt + li] = rfk[m][kb][q];
+    for (int m = 0; m < MAXT; ++m) {
+      const int gt = wave + m * NW;
+      if (gt < NB) {
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Ra[(16 * kb + 4 * q + lk) * PR + 16 * gt + li] = rfk[m][kb][q];
+      }
     }
   }
   __syncthreads();
@@ -474,15 +513,22 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
   auto push_tile = [&](const double* Rl, const int rt, const mfma_acc_t (&x)[NB], const bool xa, double* blk,
                        const int orow, const int ocol, mfma_acc_t acc) {
     const double* rl = Rl + lk * PR + 16 * rt + li;
-    double rv[n / 4];
+    constexpr int QH = (n / 4) % 8 == 0 ? 8 : ((n / 4) % 6 == 0 ? 6 : 4);  // operand fragments of 8 (6, 4) k-steps at a time
+    static_assert((n / 4) % QH == 0, "whole rounds");
 #pragma unroll
-    for (int q = 0; q < n / 4; ++q) rv[q] = rl[4 * q * PR];
-    if (xa) {
+    for (int q0 = 0; q0 < n / 4; q0 += QH) {
+      double rv[QH];
 #pragma unroll
-      for (int q = 0; q < n / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q / 4][q % 4], rv[q], acc, 0, 0, 0);
-    } else {
+      for (int q = 0; q < QH; ++q) rv[q] = rl[4 * (q0 + q) * PR];
+      if (xa) {
 #pragma unroll
-      for (int q = 0; q < n / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[q], x[q / 4][q % 4], acc, 0, 0, 0);
+        for (int q = 0; q < QH; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[(q0 + q) / 4][(q0 + q) % 4], rv[q], acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < QH; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[q], x[(q0 + q) / 4][(q0 + q) % 4], acc, 0, 0, 0);
+      }
     }
     if (!PAD || 16 * ocol + li < nl) {
       double* dst = blk + (size_t)(16 * orow + lk) * nl + 16 * ocol + li;
@@ -491,80 +537,86 @@ __global__ __launch_bounds__(NTHR, 4) void separator_reduced_mfma(Dims d, int l,
         if (!PAD || 16 * orow + lk + 4 * gg < nl) dst[(size_t)4 * gg * nl] = acc[gg];
     }
   };
+  // Everything that multiplies with r_a (with_ra) or with r_bb. DR, DL and S-bar are symmetric: only tiles on and
+  // below the diagonal. The coupling tile (a-tile i, bb-tile j) goes to the wavefront of f_a's tile i when j <= i
+  // (as f_a' r_bb = r_a' S-bar^-1 r_bb) and to the one of f_bb's tile j when i < j (as r_a' f_bb).
+  auto pushes = [&](const bool with_ra) {
+    const double* Rl = with_ra ? Ra : Rb;
 #pragma unroll
-  for (int m = 0; m < MAXT; ++m) {
-    const int gt = wave + m * NW;
-    if (gt >= 2 * NB) continue;
-    const int c = gt < NB ? gt : gt - NB;
-    if (gt < NB ? !hasA : !hasB) continue;
-    // the tiles the accumulating pushes start from (DR[A](:, tile c) / DL[B](:, tile c)): requested first, consumed
-    // behind the coupling tiles
-    double* pblk = gt < NB ? slotA + nnl : slotB;
-    mfma_acc_t pacc[NB];
-    {
-      const int jc = 16 * c + li < nl ? 16 * c + li : nl - 1;
+    for (int m = 0; m < MAXT; ++m) {
+      const int gt = wave + m * NW;
+      if (gt >= 2 * NB) continue;
+      const int c = gt < NB ? gt : gt - NB;
+      const bool atile = gt < NB;
+      if (atile ? !hasA : !hasB) continue;
+      if (atile == with_ra) {
+        // DR[A](lower tiles, tile column c) += r_a' f_a(:, c)   /   DL[B](..) += r_bb' f_bb(:, c); the tiles they start
+        // from are requested first
+        double* pblk = atile ? slotA + nnl : slotB;
+        const int jc = 16 * c + li < nl ? 16 * c + li : nl - 1;
+        // (tiles above the diagonal are neither kept nor read; padding: never stored)
+        auto start_tile = [&](const int rt) -> mfma_acc_t {
+          mfma_acc_t a0 = {0.0, 0.0, 0.0, 0.0};
+          if (!LEVEL0 && rt >= c) {
 #pragma unroll
-      for (int rt = 0; rt < NB; ++rt)
+            for (int gg = 0; gg < 4; ++gg) {
+              const int i = 16 * rt + lk + 4 * gg;
+              a0[gg] = pblk[(size_t)(i < nl ? i : nl - 1) * nl + jc];
+            }
+          }
+          return a0;
+        };
+        if constexpr (TWO) {  // (registers are short with two solved tiles per wavefront: tile by tile)
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          const int i = 16 * rt + lk + 4 * gg;
-          // (tiles above the diagonal are neither kept nor read; padding: never stored)
-          pacc[rt][gg] = (LEVEL0 || rt < c) ? 0.0 : pblk[(size_t)(i < nl ? i : nl - 1) * nl + jc];
+          for (int rt = 0; rt < NB; ++rt)
+            if (rt >= c) push_tile(Rl, rt, xk[m], false, pblk, rt, c, start_tile(rt));
+        } else {
+          mfma_acc_t pacc[NB];
+#pragma unroll
+          for (int rt = 0; rt < NB; ++rt) pacc[rt] = start_tile(rt);
+#pragma unroll
+          for (int rt = 0; rt < NB; ++rt)
+            if (rt >= c) push_tile(Rl, rt, xk[m], false, pblk, rt, c, pacc[rt]);
         }
-    }
-    if (gt < NB) {
-      // coupling tiles (a-tile c, bb-tile j), j <= c:  r_a' S-bar^-1 r_bb = f_a' r_bb  (with the NB - c tiles of DR
-      // below: NB + 1 tile products for every wavefront of this half, NB for the other)
-      if (hasB) {
-        for (int j = 0; j <= c; ++j) {
-          if (leftchild)  // CA[B] = (f_a' r_bb)' = r_bb' f_a: rows bb-tile j, columns a-tile c
-            push_tile(Rb, j, xk[m], false, slotB + 2 * nnl, j, c, zero4);
-          else            // CB[A] = f_a' r_bb: rows a-tile c, columns bb-tile j
-            push_tile(Rb, j, xk[m], true, slotA + 3 * nnl, c, j, zero4);
+      } else if (hasA && hasB) {
+        if (atile) {  // with r_bb: coupling tiles (c, j <= c) as f_a' r_bb
+          for (int j = 0; j <= c; ++j) {
+            if (leftchild) push_tile(Rl, j, xk[m], false, slotB + 2 * nnl, j, c, zero4);  // CA[B] = (f_a' r_bb)': rows bb-tile j
+            else push_tile(Rl, j, xk[m], true, slotA + 3 * nnl, c, j, zero4);           // CB[A] = f_a' r_bb: rows a-tile c
+          }
+        } else {      // with r_a: coupling tiles (i < c, c) as r_a' f_bb
+          for (int i = 0; i < c; ++i) {
+            if (leftchild) push_tile(Rl, i, xk[m], true, slotB + 2 * nnl, c, i, zero4);   // CA[B] = f_bb' r_a: rows bb-tile c
+            else push_tile(Rl, i, xk[m], false, slotA + 3 * nnl, i, c, zero4);          // CB[A] = r_a' f_bb: rows a-tile i
+          }
         }
       }
-      // DR[A](tiles on and below the diagonal, tile column c) += r_a' f_a(:, tile c): DR is symmetric and only its
-      // lower tiles are ever read
-#pragma unroll
-      for (int rt = 0; rt < NB; ++rt)
-        if (rt >= c) push_tile(Ra, rt, xk[m], false, pblk, rt, c, pacc[rt]);
-    } else {
-      // coupling tiles (a-tile i, bb-tile c), i < c:  r_a' f_bb
-      if (hasA) {
-        for (int i = 0; i < c; ++i) {
-          if (leftchild)  // CA[B] = (r_a' f_bb)' = f_bb' r_a: rows bb-tile c, columns a-tile i
-            push_tile(Ra, i, xk[m], true, slotB + 2 * nnl, c, i, zero4);
-          else            // CB[A] = r_a' f_bb: rows a-tile i, columns bb-tile c
-            push_tile(Ra, i, xk[m], false, slotA + 3 * nnl, i, c, zero4);
-        }
-      }
-      // DL[B](tiles on and below the diagonal, tile column c) += r_bb' f_bb(:, tile c)
-#pragma unroll
-      for (int rt = 0; rt < NB; ++rt)
-        if (rt >= c) push_tile(Rb, rt, xk[m], false, pblk, rt, c, pacc[rt]);
     }
-  }
-  // vector pushes gR[A] += r_a' z_sep (first wavefront), gL[B] += r_bb' z_sep (last): a column of r per lane
-  if ((wave == 0 && hasA) || (wave == NW - 1 && hasB)) {
-    const bool ga = wave == 0 && hasA;
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 0 ? !ga : !(wave == NW - 1 && hasB)) continue;
-      const double* R = pass == 0 ? Ra : Rb;
-      double* dst = pass == 0 ? slotA + 4 * nnl + nl : slotB + 4 * nnl;
+    // vector pushes gR[A] += r_a' z_sep (first wavefront) / gL[B] += r_bb' z_sep (last): a column of r per lane
+    if (with_ra ? (wave == 0 && hasA) : (wave == NW - 1 && hasB)) {
+      double* dst = with_ra ? slotA + 4 * nnl + nl : slotB + 4 * nnl;
       for (int j0 = 0; j0 < nl; j0 += 64) {
         const int j = j0 + lane < nl ? j0 + lane : nl - 1;
         double acc = LEVEL0 ? 0.0 : dst[j];
-        for (int k0 = 0; k0 < n; k0 += 8) {
+#pragma unroll 1
+        for (int k0 = 0; k0 < n; k0 += 8) {  // (not unrolled: the solved tiles are still live for the second round)
           double rv[8], zv[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { rv[u] = R[(k0 + u) * PR + j]; zv[u] = zsv[k0 + u]; }
+          for (int u = 0; u < 8; ++u) { rv[u] = Rl[(k0 + u) * PR + j]; zv[u] = zsv[k0 + u]; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc = fma(rv[u], zv[u], acc);
         }
         if (j0 + lane < nl) dst[j] = acc;
       }
     }
+  };
+  pushes(true);
+  if constexpr (TWO) {
+    __syncthreads();  // r_a has been read
+    stage_coupling(false);
+    __syncthreads();
   }
+  pushes(false);
   SEG(59);
 }
 

@@ -343,9 +343,11 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   p.pad = npad != d.n || wpad != d.w;  // blocks that do not fill their tiles: zero-padded in LDS (PAD instances)
   // one wavefront per 16x16 block where the weights fit its lanes: many small workgroups fill the chip better than
   // a four-wavefront workgroup whose phases are mostly serial at this size
-  p.threads = p.nb >= 3 ? 512 : (p.nb == 1 && wpad <= 64 ? 64 : 256);
+  // a wavefront per 16-column tile where the weights fit the lanes ("two rounds", kernels_reduced_mfma.hpp: small
+  // workgroups, three or more of them per CU), else twice that
+  p.threads = wpad <= 64 * p.nb ? 64 * p.nb : (p.nb >= 3 ? 512 : 256);
   if (wpad > p.threads) return p;  // one weight / rhs entry per thread
-  p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(npad, wpad);
+  p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(npad, wpad, p.threads == 64 * p.nb);
   if (p.lds > 160 * 1024) return p;
   p.ok = true;
   return p;
@@ -447,9 +449,18 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
         if (p.threads == 64) NDLQR_LAUNCH_SEP(1, 64);
         else NDLQR_LAUNCH_SEP(1, 256);
         break;
-      case 2: NDLQR_LAUNCH_SEP(2, 256); break;
-      case 3: NDLQR_LAUNCH_SEP(3, 512); break;
-      default: NDLQR_LAUNCH_SEP(4, 512); break;
+      case 2:
+        if (p.threads == 128) NDLQR_LAUNCH_SEP(2, 128);
+        else NDLQR_LAUNCH_SEP(2, 256);
+        break;
+      case 3:
+        if (p.threads == 192) NDLQR_LAUNCH_SEP(3, 192);
+        else NDLQR_LAUNCH_SEP(3, 512);
+        break;
+      default:
+        if (p.threads == 256) NDLQR_LAUNCH_SEP(4, 256);
+        else NDLQR_LAUNCH_SEP(4, 512);
+        break;
     }
 #undef NDLQR_LAUNCH_SEP2
 #undef NDLQR_LAUNCH_SEP
