@@ -173,7 +173,9 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
                                          (64, 16, 512, 1),
                                          # blocks that do not fill their tiles: zero-padded in LDS (PAD instances)
                                          (20, 20, 16, 3), (7, 9, 16, 2), (5, 3, 32, 2), (1, 1, 4, 2), (17, 3, 16, 2),
-                                         (33, 5, 8, 2), (50, 10, 64, 2), (63, 1, 16, 2), (64, 15, 16, 1), (3, 1, 2, 2)])
+                                         (33, 5, 8, 2), (50, 10, 64, 2), (63, 1, 16, 2), (64, 15, 16, 1), (3, 1, 2, 2),
+                                         # inputs too wide for one wavefront per tile column: the larger workgroups
+                                         (64, 200, 8, 1), (48, 150, 8, 1), (32, 100, 8, 2), (16, 60, 16, 2)])
 def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch):
     """Every block size up to 64 states without a size-specialised instance takes the separator-only schedule on
     the matrix cores (kernels_reduced_mfma.hpp: one launch per tree level, no factor array), down to a single
