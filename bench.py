@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with:
                   plain-C oracle ("port") timed on this host on a bounded sample (N=1, rank 0).
   pipeline     -- depth of the solve pipeline behind `value` and the same steps strictly stream-ordered.
   transfers    -- H2D of the packed inputs and D2H of the solutions, timed separately (never in `value`).
+  spin_up      -- untimed full solves before the W warm-up steps (one-time work of the first solves, clock ramp).
   modes        -- N=1: strict mode, KEEP_FACT and the rhs-only re-solve on the same workload.
   gather       -- N>1: throughput including the all_gather of every shard's solutions.
 """
@@ -183,6 +184,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spin-up-ms", type=float, default=60.0,
+                    help="untimed full solves before the warm-up steps until the device has been under load this long (0: none)")
     ap.add_argument("--nx", type=int, default=12)
     ap.add_argument("--nu", type=int, default=4)
     ap.add_argument("--horizon", type=int, default=256)
@@ -248,6 +251,19 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Device spin-up, untimed and BEFORE the W warm-up steps: the first solves carry one-time work (capture of the
+    # launch sequence for both buffer sets of the pipeline, lazy allocation of the second set), and the GPU needs
+    # some tens of milliseconds of load to reach its sustained clocks -- W = 5 steps are 3 ms at this workload, and
+    # a 20-step region started right behind them measured 0.745 ms/step where every later one measured 0.65-0.67
+    # (tools/overlap_probe.py style loop). Full solves, reported as `spin_up`.
+    spin_steps, spin_t0 = 0, time.perf_counter()
+    while args.spin_up_ms > 0 and (time.perf_counter() - spin_t0) * 1e3 < args.spin_up_ms and spin_steps < 400:
+        for _ in range(4):
+            bs.solve_async()
+        bs.synchronize()
+        spin_steps += 4
+    spin_ms = (time.perf_counter() - spin_t0) * 1e3
 
     # Timed region: the product path as shipped (launch sequence replayed as a hipGraph).
     elapsed = sharding.timed_region(bs, steps, args.warmup, barrier)
@@ -404,6 +420,9 @@ def main():
                                  "starts when the previous one has finished",
                          "value_depth1": (total_solves / elapsed_ordered) if elapsed_ordered else None,
                          "ms_per_step_depth1": (elapsed_ordered / steps * 1e3) if elapsed_ordered else None},
+            "spin_up": {"steps": spin_steps, "ms": spin_ms,
+                        "note": "untimed full solves before the W warm-up steps: one-time work of the first solves and "
+                                "the clock ramp of the device; --spin-up-ms 0 disables"},
             "transfers": {"h2d_ms": h2d_ms, "h2d_bytes": in_bytes, "d2h_ms": d2h_ms,
                           "d2h_bytes": 8 * batch * bs.nvars,
                           "note": "rank 0, pageable host memory, whole shard; not part of `value`"},
