@@ -24,12 +24,22 @@ Prints ONE JSON line on rank 0 (contract in the task description) with:
   transfers    -- H2D of the packed inputs and D2H of the solutions, timed separately (never in `value`).
   spin_up      -- untimed full solves before the W warm-up steps (one-time work of the first solves, clock ramp).
   modes        -- N=1: strict mode, KEEP_FACT and the rhs-only re-solve on the same workload.
+  configs      -- N=1: the other single-GPU configurations of BASELINE.json, each timed the same way on a bounded
+                  number of steps: lqr_prob_256.json x 1 (latency, error against the fixture's `soln`),
+                  (12,4,1024) x 512 (one GPU's shard of config 4), (64,16,512) x 256 (config 5).
   gather       -- N>1: throughput including the all_gather of every shard's solutions.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks: this
+process -- before it imports torch or touches a GPU in any way -- runs `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child, relays rank 0's JSON line and exits
+with the child's status. A process group whose size differs from --gpus is an error (exit 3), not a warning.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -155,6 +165,164 @@ def cpu_baseline(n, m, N, probs, gpu_solutions):
     return out, worst
 
 
+def launch_ranks(gpus):
+    """--gpus N > 1 outside a launcher: start N fresh rank processes (one per GPU) with torch.distributed.run and
+    exit with their status. Nothing in this process has touched the GPU (no torch import, no HIP call)."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this pool)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("--gpus %d without WORLD_SIZE: launching %d ranks: %s" % (gpus, gpus, " ".join(cmd[1:])))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def roofline_object(prof, steps, schedule, n, m, N, batch, flags, solves_per_s_per_gpu):
+    """The `roofline` object of one workload from its per-kernel HIP-event profile: head = dominant kernel kind
+    (algorithmic bytes / useful flops of the IMPLEMENTED schedule over the measured launch time), `kernels` = the
+    other kinds, `step` = the whole step, `traffic` = PMC-measured HBM bytes of the committed profile of this tree."""
+    used = {k: v for k, v in prof.items() if v[1] > 0}
+    model = rf.model_for(schedule, n, m, N)
+    traffic, traffic_src = committed_traffic(n, m, N, batch, flags)
+    kernels = {}
+    for slot, (ms, launches) in used.items():
+        avg_ms = ms / launches
+        entry = {"avg_launch_ms": avg_ms, "launches_per_step": launches / steps,
+                 "ms_per_step": ms / steps}
+        if model and slot in model:
+            entry.update(rf.kernel_roofline(model[slot], batch, avg_ms))
+            assert 0.0 < entry["frac"] <= 1.0, (slot, entry)
+        entry["traffic"] = traffic.get(slot)
+        kernels[slot] = entry
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    roofline = dict(kernels[dom])
+    roofline["kernel"] = dom
+    roofline["schedule"] = schedule
+    if "frac" not in roofline:
+        # strict / KEEP schedules stream the whole factor array level by level: SURVEY 8(d) model (B)
+        # is what they execute
+        b = rf.model_b_bytes(n, m, N) * batch
+        gbs = b / (sum(k["ms_per_step"] for k in kernels.values()) * 1e-3) / 1e9
+        roofline.update(bound="hbm", achieved=gbs, peak=rf.HBM_PEAK_GBS, unit="GB/s", frac=gbs / rf.HBM_PEAK_GBS,
+                        note="whole step against SURVEY.md 8(d) model (B) level-streaming bytes")
+    roofline["traffic_source"] = traffic_src
+    if model:
+        sb = sum(v["bytes"] for v in model.values()) * batch
+        sf = sum(v["flops"] for v in model.values()) * batch
+        dev_ms = sum(k["ms_per_step"] for k in kernels.values())
+        roofline["step"] = {
+            "algorithmic_bytes": sb, "useful_flops": sf, "kernel_ms": dev_ms,
+            "hbm_frac": sb / (dev_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
+            "fp64_frac": sf / (dev_ms * 1e-3) / 1e12 / rf.FP64_PEAK_TFLOPS,
+            # inputs read once + solution written once (SURVEY 8(d) floor (A)): what a perfectly
+            # fused solver would move -- the step's distance from the HBM roof of the PROBLEM
+            "compulsory_bytes": rf.compulsory_bytes(n, m, N) * batch,
+            "compulsory_hbm_frac": rf.compulsory_bytes(n, m, N) * batch / (dev_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
+            "traffic": sum(kernels[k]["traffic"] * kernels[k]["launches_per_step"] for k in kernels)
+            if all(kernels[k]["traffic"] for k in kernels) else None,
+        }
+    roofline["kernels"] = {k: v for k, v in kernels.items() if k != dom}
+    # the reference's dense schedule priced at this throughput (> peak: the bytes are not moved)
+    roofline["vs_level_streaming_model"] = {
+        "model_b_bytes_per_solve": rf.model_b_bytes(n, m, N),
+        "equivalent_gbs_per_gpu": rf.model_b_bytes(n, m, N) * solves_per_s_per_gpu / 1e9,
+        "model_b_flops_per_solve": rf.model_b_flops(n, m, N)}
+    return roofline
+
+
+def profile_pass(rslqr_amd, bs, flags, steps):
+    """Per-kernel durations: `steps` more solves with a HIP-event pair around every launch on the launch stream
+    (events force eager launches, so they cannot sit inside the graph-replayed region; the kernels and their
+    inputs are identical). Returns ({slot: (ms, launches)}, wall seconds)."""
+    bs.set_flags(flags | rslqr_amd.FLAG_PROFILE)
+    bs.solve()
+    bs.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bs.solve_async()
+    bs.synchronize()
+    wall = time.perf_counter() - t0
+    prof = bs.profile()
+    bs.set_flags(flags)
+    return prof, wall
+
+
+def config_leg(rslqr_amd, n, m, N, batch, device, steps, seed0=1, json_path=None, cpu_sample=0):
+    """One more BASELINE configuration on this GPU, measured like the headline workload on a bounded number of
+    steps: spin-up, `steps` graph-replayed solves between synchronisations, the per-kernel profile pass, the
+    device-side KKT residual of every problem. json_path: the problem of a reference JSON fixture (batch 1)."""
+    t_leg = time.perf_counter()
+    bs = rslqr_amd.BatchSolver(n, m, N, batch, device=device)
+    out = {"workload": "nx=%d nu=%d N=%d batch=%d, fp64, factor+solve per step" % (n, m, N, batch)}
+    try:
+        L = rslqr_amd.lib()
+        soln = None
+        if json_path:
+            import ctypes as C
+            prob = L.ndlqr_ReadLQRProblemJSONFile(json_path.encode())
+            if not prob:
+                return {"error": "cannot read " + json_path}
+            arr = (C.POINTER(rslqr_amd.LQRProblem) * 1)(prob)
+            err = L.ndlqr_InitializeBatch(bs.h, arr, 1)
+            L.ndlqr_FreeLQRProblem(prob)
+            if err:
+                return {"error": "ndlqr_InitializeBatch: %d" % err}
+            soln = np.asarray(json.load(open(json_path))["soln"], dtype=np.float64).reshape(-1)
+            out["data"] = os.path.basename(json_path)
+        else:
+            bs.initialize_synthetic(seed0)
+            out["data"] = "synthetic, seeds %d..%d" % (seed0, seed0 + batch - 1)
+        out["setup_s"] = time.perf_counter() - t_leg
+        if bs.solve() != 0:
+            return {"error": "solve failed: %s" % L.ndlqr_hip_last_error().decode()}
+        t0 = time.perf_counter()  # spin-up: ~50 ms of load, at least two solves per buffer set
+        spin = 0
+        while spin < 4 or ((time.perf_counter() - t0) < 0.05 and spin < 200):
+            bs.solve_async()
+            bs.solve_async()
+            bs.synchronize()
+            spin += 2
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bs.solve_async()
+        bs.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        schedule = bs.schedule()
+        out.update(steps=steps, ms_per_step=ms, solves_per_s=batch / (ms * 1e-3), schedule=schedule,
+                   pipeline_depth=bs.pipeline_depth(), cholesky_failures=bs.cholesky_failures())
+        lat = []
+        for _ in range(min(steps, 20)):  # one solve at a time: launch -> synchronise, host clock and device events
+            t0 = time.perf_counter()
+            bs.solve()
+            lat.append(((time.perf_counter() - t0) * 1e3, bs.solve_ms()))
+        out["one_solve_in_flight_ms"] = {"host_median": sorted(x[0] for x in lat)[len(lat) // 2],
+                                         "device_median": sorted(x[1] for x in lat)[len(lat) // 2]}
+        prof, _ = profile_pass(rslqr_amd, bs, 0, min(steps, 10))
+        roof = roofline_object(prof, min(steps, 10), schedule, n, m, N, batch, 0, batch / (ms * 1e-3))
+        roof.pop("vs_level_streaming_model", None)
+        out["roofline"] = roof
+        res, bn = bs.kkt_residuals()
+        out["kkt_residual_rel_max"] = float((res / np.maximum(1.0, bn)).max())
+        if soln is not None:
+            x = bs.solution(0)
+            out["err_vs_fixture_soln_l2"] = float(np.linalg.norm(x - soln))  # the reference's bar: < 1e-6
+            out["soln_norm"] = float(np.linalg.norm(soln))
+        if cpu_sample:
+            probs = [rslqr_amd.generate_synthetic(n, m, N, seed0 + p) for p in range(cpu_sample)]
+            base, worst = cpu_baseline(n, m, N, probs, [bs.solution(p) for p in range(cpu_sample)])
+            out["cpu_baseline"] = base
+            out["parity_rel_err_vs_cpu"] = worst
+            out["speedup_vs_cpu"] = out["solves_per_s"] / base["value"]
+        out["leg_s"] = time.perf_counter() - t_leg
+        return out
+    finally:
+        bs.close()
+
+
 def time_mode(rslqr_amd, n, m, N, batch, device, seed0, flags, steps, rhs_only=False):
     """ms per step of one more mode of the same workload (own solver, same synthetic problems)."""
     bs = rslqr_amd.BatchSolver(n, m, N, batch, device=device, flags=flags)
@@ -195,7 +363,15 @@ def main():
     ap.add_argument("--no-modes", action="store_true", help="skip the strict / KEEP / rhs-only legs")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the solution-gather leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU sample (0 = auto)")
+    ap.add_argument("--no-configs", action="store_true", help="N=1: skip the legs of the other BASELINE configurations")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)  # does not return
+    if os.environ.get("NDLQR_BENCH_LAUNCH_ONLY"):  # test hook (tests/test_sharding_gloo.py): the launch alone, no GPU
+        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")),
+                          "gpus": args.gpus}), flush=True)
+        sys.exit(0 if int(os.environ.get("WORLD_SIZE", "1")) == args.gpus else 3)
 
     import torch
     import torch.distributed as dist
@@ -220,7 +396,10 @@ def main():
             dist.init_process_group(backend)
     ranks_seen = dist.get_world_size() if distributed else 1
     if ranks_seen != args.gpus:
-        log("WARNING: --gpus %d but the process group has %d ranks" % (args.gpus, ranks_seen))
+        log("ERROR: --gpus %d but the process group has %d ranks" % (args.gpus, ranks_seen))
+        if distributed:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     import rslqr_amd
     n, m, N, batch = args.nx, args.nu, args.horizon, args.batch
@@ -282,16 +461,7 @@ def main():
     # Per-kernel durations for the roofline object: the SAME K steps once more with a HIP-event
     # pair around every launch on the launch stream. (Events force eager launches, so they cannot
     # sit inside the graph-replayed region above; the kernels and their inputs are identical.)
-    bs.set_flags(args.flags | rslqr_amd.FLAG_PROFILE)
-    bs.solve()
-    bs.profile_reset()
-    tp0 = time.perf_counter()
-    for _ in range(steps):
-        bs.solve_async()
-    bs.synchronize()
-    elapsed_profiled = time.perf_counter() - tp0
-    prof = bs.profile()
-    bs.set_flags(args.flags)
+    prof, elapsed_profiled = profile_pass(rslqr_amd, bs, args.flags, steps)
 
     # per-solve device times (HIP events around the replayed launch sequence, one solve at a time):
     # median and minimum next to the mean of the timed region
@@ -348,53 +518,8 @@ def main():
     if rank == 0:
         total_solves = batch * world * steps
         value = total_solves / elapsed_max
-        used = {k: v for k, v in prof.items() if v[1] > 0}
-        model = rf.model_for(schedule, n, m, N)
-        traffic, traffic_src = committed_traffic(n, m, N, batch, args.flags)
-        kernels = {}
-        for slot, (ms, launches) in used.items():
-            avg_ms = ms / launches
-            entry = {"avg_launch_ms": avg_ms, "launches_per_step": launches / steps,
-                     "ms_per_step": ms / steps}
-            if model and slot in model:
-                entry.update(rf.kernel_roofline(model[slot], batch, avg_ms))
-                assert 0.0 < entry["frac"] <= 1.0, (slot, entry)
-            entry["traffic"] = traffic.get(slot)
-            kernels[slot] = entry
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         step_ms = elapsed_max / steps * 1e3
-        roofline = dict(kernels[dom])
-        roofline["kernel"] = dom
-        roofline["schedule"] = schedule
-        if "frac" not in roofline:
-            # strict / KEEP schedules stream the whole factor array level by level: SURVEY 8(d) model (B)
-            # is what they execute
-            b = rf.model_b_bytes(n, m, N) * batch
-            gbs = b / (sum(k["ms_per_step"] for k in kernels.values()) * 1e-3) / 1e9
-            roofline.update(bound="hbm", achieved=gbs, peak=rf.HBM_PEAK_GBS, unit="GB/s", frac=gbs / rf.HBM_PEAK_GBS,
-                            note="whole step against SURVEY.md 8(d) model (B) level-streaming bytes")
-        roofline["traffic_source"] = traffic_src
-        if model:
-            sb = sum(v["bytes"] for v in model.values()) * batch
-            sf = sum(v["flops"] for v in model.values()) * batch
-            dev_ms = sum(k["ms_per_step"] for k in kernels.values())
-            roofline["step"] = {
-                "algorithmic_bytes": sb, "useful_flops": sf, "kernel_ms": dev_ms,
-                "hbm_frac": sb / (dev_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
-                "fp64_frac": sf / (dev_ms * 1e-3) / 1e12 / rf.FP64_PEAK_TFLOPS,
-                # inputs read once + solution written once (SURVEY 8(d) floor (A)): what a perfectly
-                # fused solver would move -- the step's distance from the HBM roof of the PROBLEM
-                "compulsory_bytes": rf.compulsory_bytes(n, m, N) * batch,
-                "compulsory_hbm_frac": rf.compulsory_bytes(n, m, N) * batch / (dev_ms * 1e-3) / 1e9 / rf.HBM_PEAK_GBS,
-                "traffic": sum(kernels[k]["traffic"] * kernels[k]["launches_per_step"] for k in kernels)
-                if all(kernels[k]["traffic"] for k in kernels) else None,
-            }
-        roofline["kernels"] = {k: v for k, v in kernels.items() if k != dom}
-        # the reference's dense schedule priced at this throughput (> peak: the bytes are not moved)
-        roofline["vs_level_streaming_model"] = {
-            "model_b_bytes_per_solve": rf.model_b_bytes(n, m, N),
-            "equivalent_gbs_per_gpu": rf.model_b_bytes(n, m, N) * value / world / 1e9,
-            "model_b_flops_per_solve": rf.model_b_flops(n, m, N)}
+        roofline = roofline_object(prof, steps, schedule, n, m, N, batch, args.flags, value / world)
         result = {
             "metric": "LQR solves/sec (nx=%d,nu=%d,N=%d,batch=%d per GPU)" % (n, m, N, batch),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": steps,
@@ -460,6 +585,21 @@ def main():
             result["cpu_baseline"] = base
             result["parity_rel_err_vs_cpu"] = worst
             result["speedup_vs_cpu"] = value / base["value"]
+        headline = (n, m, N, batch, args.flags) == (12, 4, 256, 1024, 0)
+        if world == 1 and headline and not args.no_configs:
+            # the other single-GPU configurations of BASELINE.json, driver-timed in the same run (bounded legs)
+            bs.close()
+            fixture = os.path.join(ROOT, "tests", "golden", "lqr_prob_256.json")
+            result["configs"] = {}
+            log("configs leg: lqr_prob_256.json x 1")
+            result["configs"]["config2: lqr_prob_256.json (6,3,256) x 1"] = \
+                config_leg(rslqr_amd, 6, 3, 256, 1, local_rank, 50, json_path=fixture)
+            log("configs leg: (12,4,1024) x 512")
+            result["configs"]["config4 shard: (12,4,1024) x 512 (one GPU of the 8 x 512 = 4096 job)"] = \
+                config_leg(rslqr_amd, 12, 4, 1024, 512, local_rank, 20)
+            log("configs leg: (64,16,512) x 256")
+            result["configs"]["config5: (64,16,512) x 256"] = \
+                config_leg(rslqr_amd, 64, 16, 512, 256, local_rank, 10, cpu_sample=0 if args.no_cpu else 3)
         print(json.dumps(result), flush=True)
 
     bs.close()

@@ -98,7 +98,7 @@ def build(force=False, verbose=False):
     if force or _newer(LIB, objs):
         if verbose:
             print("link", os.path.basename(LIB))
-        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"])
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"])
     return LIB
 
 

@@ -11,6 +11,9 @@
  * reference's C.state = A', C.input = B' stored column-major, src/solver.c:149-152), the rhs is
  * negated as in src/solver.c:188-190.
  */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -162,28 +165,72 @@ int ndlqr_InitializeBatchFlatDevice(NdLqrBatchSolver* bs, const double* dA, cons
   return ndlqr_hip_pack_flat_device(bs->ctx, dA, dB, dQ, dR, dq, dr, dd, dx0);
 }
 
-int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0) {
-  if (!bs) return NDLQR_ERR_INVALID;
+/* Synthetic problems of one staging chunk are generated and packed side by side on host threads
+ * (one splitmix64 stream per problem, so the result does not depend on the thread count): the
+ * (64,16,512) x 256 family is 37 s of Box-Muller draws on one core. */
+typedef struct {
+  NdLqrBatchSolver* bs;
+  uint64_t seed0;
+  int p0, count, tid, nthreads, err;
+} SynthJob;
+
+static void* synth_worker(void* arg) {
+  SynthJob* job = (SynthJob*)arg;
+  NdLqrBatchSolver* bs = job->bs;
   const size_t n = (size_t)bs->n, m = (size_t)bs->m, N = (size_t)bs->N;
   double* buf = (double*)malloc(sizeof(double) * (N * (n * n + n * m + 3 * n + 2 * m) + n));
-  if (!buf) return NDLQR_ERR_INVALID;
+  if (!buf) { job->err = NDLQR_ERR_INVALID; return NULL; }
   double* A = buf; double* B = A + N * n * n; double* Q = B + N * n * m; double* R = Q + N * n;
   double* q = R + N * m; double* r = q + N * n; double* d = r + N * m; double* x0 = d + N * n;
-  int slot = 0, p0 = 0, err = NDLQR_OK;
-  for (int p = 0; p < bs->batch && !err; ++p) {
-    ndlqr_GenerateSyntheticFlat(bs->n, bs->m, bs->N, seed0 + (uint64_t)p, A, B, Q, R, q, r, d, x0);
+  for (int slot = job->tid; slot < job->count; slot += job->nthreads) {
+    ndlqr_GenerateSyntheticFlat(bs->n, bs->m, bs->N, job->seed0 + (uint64_t)(job->p0 + slot), A, B, Q, R, q, r, d, x0);
     for (size_t k = 0; k < N; ++k) {
       pack_knot(bs, slot, (int)k, A + k * n * n, B + k * n * m, Q + k * n, R + k * m);
       pack_rhs(bs, slot, (int)k, k == 0 ? x0 : d + (k - 1) * n, q + k * n, r + k * m);
     }
-    if (++slot == bs->chunk || p == bs->batch - 1) {
-      err = flush(bs, p0, slot);
-      p0 += slot;
-      slot = 0;
-    }
   }
   free(buf);
-  return err;
+  return NULL;
+}
+
+static int host_threads(void) {
+  const char* env = getenv("NDLQR_HOST_THREADS");
+  if (env && atoi(env) > 0) return atoi(env);
+  cpu_set_t set;
+  int t = 1;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) t = CPU_COUNT(&set);
+  return t > 16 ? 16 : (t < 1 ? 1 : t);
+}
+
+int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0) {
+  if (!bs) return NDLQR_ERR_INVALID;
+  enum { MAXT = 64 };
+  int nthreads = host_threads();
+  if (nthreads > MAXT) nthreads = MAXT;
+  for (int p0 = 0; p0 < bs->batch; p0 += bs->chunk) {
+    const int count = bs->batch - p0 < bs->chunk ? bs->batch - p0 : bs->chunk;
+    const int nt = count < nthreads ? count : nthreads;
+    pthread_t th[MAXT];
+    SynthJob job[MAXT];
+    int started = 0;
+    for (int t = 0; t < nt; ++t) {
+      job[t] = (SynthJob){bs, seed0, p0, count, t, nt, NDLQR_OK};
+      if (t > 0 && pthread_create(&th[t], NULL, synth_worker, &job[t]) == 0) ++started;
+      else if (t > 0) { job[t].tid = -1; }
+    }
+    /* (a thread that could not be started: its share is done here, after this thread's own) */
+    synth_worker(&job[0]);
+    int err = job[0].err;
+    for (int t = 1; t < nt; ++t) {
+      if (job[t].tid < 0) { job[t].tid = t; synth_worker(&job[t]); }
+      else pthread_join(th[t], NULL);
+      if (job[t].err) err = job[t].err;
+    }
+    (void)started;
+    if (!err) err = flush(bs, p0, count);
+    if (err) return err;
+  }
+  return NDLQR_OK;
 }
 
 /* Single-problem path used by ndlqr_Solve: inputs come from the solver's host mirrors

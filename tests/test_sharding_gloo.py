@@ -88,3 +88,47 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     single = _solve_shard(0, 1, world * per_rank, n, m, N)  # global problems 0..5, seeds 1..6
     assert np.array_equal(allsol, single)
     assert np.array_equal(np.load(tmp_path / "max.npy"), [2.0, 5.0])
+
+
+def _run_bench(args, env_extra, timeout):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    root = os.path.dirname(HERE)
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [json.loads(l) for l in proc.stdout.splitlines() if l.startswith("{")]
+    return proc, lines
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (N > 1, no launcher around it) starts N rank processes itself before anything
+    touches a GPU, and a process group of another size than --gpus is an error. (Launch alone: the ranks stop
+    before the solver is created -- NDLQR_BENCH_LAUNCH_ONLY -- so this runs without a GPU.)"""
+    proc, lines = _run_bench(["--gpus", "2", "--steps", "3"], {"NDLQR_BENCH_LAUNCH_ONLY": "1"}, 300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert sorted((l["rank"], l["world"], l["gpus"]) for l in lines) == [(0, 2, 2), (1, 2, 2)]
+    # a launcher that made 2 ranks while the command line says --gpus 4: every rank exits 3
+    proc, lines = _run_bench(["--gpus", "4"], {"NDLQR_BENCH_LAUNCH_ONLY": "1", "WORLD_SIZE": "2", "RANK": "0"}, 120)
+    assert proc.returncode == 3
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's own N = 2 path end to end on the one GPU of the test box: two rank processes (launched by
+    bench.py itself), both on device 0, gloo instead of RCCL (one GPU cannot host two RCCL ranks); the real
+    BatchSolver, the shared timed regions, the gather leg."""
+    proc, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--no-cpu", "--no-modes",
+                              "--spin-up-ms", "5"],
+                             {"NDLQR_BENCH_SAME_DEVICE": "1", "NDLQR_BENCH_BACKEND": "gloo"}, 600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert len(lines) == 1, lines  # rank 0 alone prints
+    res = lines[0]
+    assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2
+    assert res["scaling"] == "weak" and res["value"] > 0
+    assert res["gather"]["every_rank_found_its_shard_intact"] is True
+    assert res["config"]["kkt_residual_rel_max"] <= 1e-9 and res["config"]["cholesky_failures"] == 0
