@@ -165,6 +165,32 @@ def cpu_baseline(n, m, N, probs, gpu_solutions):
     return out, worst
 
 
+def riccati_column():
+    """the reference's serial Riccati comparison solver (src/riccati_solve.c:7-150, compiled into
+    oracle/_ref) next to the reference's ndlqr_Solve, on the two JSON fixtures of the reference (its own comparison,
+    test/sample_problem_test.c:127-177; off-fixture it diverges on long random horizons -- SURVEY.md App. C).
+    One thread: Riccati is serial."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import support
+    if not support.have_reference():
+        return None
+    ref = support.Reference()
+    out = {"kind": "reference", "cores": 1, "note": "reference ndlqr_SolveRiccati vs reference ndlqr_Solve (1 thread), "
+           "JSON fixtures only"}
+    for fname in ("lqr_prob.json", "lqr_prob_256.json"):
+        prob, soln = support.load_json_problem(os.path.join(support.GOLDEN, fname))
+        x, ms = ref.riccati(prob, reps=20)
+        flat = [np.ascontiguousarray(a[None]) for a in prob.arrays()]
+        args = [a.ctypes.data_as(support.dp) for a in flat]
+        ref.L.ref_bench(prob.n, prob.m, prob.N, 1, 2, *args, 1)
+        nd_ms = ref.L.ref_bench(prob.n, prob.m, prob.N, 1, 10, *args, 1) / 10
+        out["%s (%d,%d,%d)" % (fname, prob.n, prob.m, prob.N)] = {
+            "riccati_ms_per_solve": ms, "riccati_solves_per_s": 1e3 / ms,
+            "riccati_err_vs_fixture_soln_l2": float(np.linalg.norm(x - soln)),
+            "rslqr_1thread_ms_per_solve": nd_ms, "rslqr_1thread_solves_per_s": 1e3 / nd_ms}
+    return out
+
+
 def launch_ranks(gpus):
     """--gpus N > 1 outside a launcher: start N fresh rank processes (one per GPU) with torch.distributed.run and
     exit with their status. Nothing in this process has touched the GPU (no torch import, no HIP call)."""
@@ -582,6 +608,9 @@ def main():
             probs = [rslqr_amd.generate_synthetic(n, m, N, seed0 + p) for p in range(count)]
             gpu_sol = [local_sol[p] for p in range(count)]
             base, worst = cpu_baseline(n, m, N, probs, gpu_sol)
+            ric = riccati_column()
+            if ric:
+                base["riccati"] = ric
             result["cpu_baseline"] = base
             result["parity_rel_err_vs_cpu"] = worst
             result["speedup_vs_cpu"] = value / base["value"]

@@ -49,6 +49,14 @@ static void free_problem(LQRProblem* p) {
   free(p->lqrdata); free(p->x0); free(p);
 }
 
+/* (exported for ref_riccati_driver.c) */
+LQRProblem* ref_make_problem(int n, int m, int N, const double* A, const double* B, const double* Q,
+                             const double* R, const double* q, const double* r, const double* d,
+                             const double* x0) {
+  return make_problem(n, m, N, A, B, Q, R, q, r, d, x0);
+}
+void ref_free_problem(LQRProblem* p) { free_problem(p); }
+
 /* New + Initialize; returns the reference's own NdLqrSolver*. */
 void* ref_new_solver(int n, int m, int N, const double* A, const double* B, const double* Q,
                      const double* R, const double* q, const double* r, const double* d,

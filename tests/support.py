@@ -219,6 +219,19 @@ class Reference:
     def solver(self, prob):
         return RefSolver(self, prob)
 
+    def riccati(self, prob, reps=1):
+        """The reference's serial Riccati comparison solver (src/riccati_solve.c:7-150) on one problem:
+        (solution [nvars] in the reference's [lambda x u] order, mean ms per solve). Fixtures only -- it
+        diverges on random long horizons."""
+        fn = self.L.ref_riccati_bench
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_int] * 4 + [dp] * 8 + [dp, C.POINTER(C.c_int)]
+        soln = np.zeros(prob.nvars)
+        nv = C.c_int(0)
+        ms = fn(prob.n, prob.m, prob.N, reps, *prob.cargs(), _p(soln), C.byref(nv))
+        assert ms >= 0 and nv.value == prob.nvars, (ms, nv.value, prob.nvars)
+        return soln, ms
+
 
 class RefSolver:
     def __init__(self, ref, prob):

@@ -85,3 +85,19 @@ def test_full_solve_bit_identical(oracle, ref, ndlqr, threads):
     assert np.array_equal(z, rs.soln()) and np.array_equal(fact, rs.fact())
     res, bnorm = oracle.kkt_residual(prob, z[: prob.nvars])
     assert res <= 1e-9 * max(1.0, bnorm)
+
+
+@pytest.mark.parametrize("fname", ["lqr_prob.json", "lqr_prob_256.json"])
+def test_reference_riccati_on_the_fixtures(fname):
+    """the reference's serial Riccati solver (src/riccati_solve.c:26-150), compiled into
+    oracle/_ref, is the second CPU column of bench.py. On the two JSON fixtures it reproduces the stored
+    solution (the reference's own check: test/riccati_solver_test.c:332-370, test/sample_problem_test.c:150-151)."""
+    from support import GOLDEN, load_json_problem
+    import os
+    prob, soln = load_json_problem(os.path.join(GOLDEN, fname))
+    x, ms = Reference().riccati(prob, reps=3)
+    assert ms > 0
+    assert np.linalg.norm(x - soln) < 1e-6
+    z = Reference().solver(prob)
+    z.solve(1)
+    assert np.linalg.norm(x - z.soln()[: prob.nvars]) < 1e-6  # "same answer" as rsLQR (sample_problem_test.c:151)
