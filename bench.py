@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with:
                   plain-C oracle ("port") timed on this host on a bounded sample (N=1, rank 0).
   pipeline     -- depth of the solve pipeline behind `value` and the same steps strictly stream-ordered.
   transfers    -- H2D of the packed inputs and D2H of the solutions, timed separately (never in `value`).
+  end_to_end   -- the MPC step of a drop-in caller: right-hand side up, factor + solve, solutions down, two in flight.
   spin_up      -- untimed full solves before the W warm-up steps (one-time work of the first solves, clock ramp).
   modes        -- N=1: strict mode, KEEP_FACT and the rhs-only re-solve on the same workload.
   configs      -- N=1: the other single-GPU configurations of BASELINE.json, each timed the same way on a bounded
@@ -189,6 +190,77 @@ def riccati_column():
             "riccati_err_vs_fixture_soln_l2": float(np.linalg.norm(x - soln)),
             "rslqr_1thread_ms_per_solve": nd_ms, "rslqr_1thread_solves_per_s": 1e3 / nd_ms}
     return out
+
+
+def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
+    """`transfers`: H2D of the packed inputs and D2H of the solutions, pageable and pinned host memory, whole shard,
+    each timed on its own. `end_to_end`: the MPC step a drop-in caller runs -- new right-hand side up, factor + solve,
+    solutions down (ndlqr_BatchStepAsync), two steps in flight on the two buffer sets of the pipeline, pinned host
+    arrays -- timed over `steps` steps; never part of `value`."""
+    w, rows = n + m, 2 * n + m
+    in_bytes = 8 * batch * N * (n * w + w + rows)
+    out = {"h2d_bytes": in_bytes, "d2h_bytes": 8 * batch * bs.nvars}
+    # D2H of the solutions
+    t0 = time.perf_counter()
+    sol = bs.solutions()
+    out["d2h_ms_pageable_first_touch"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    bs.solutions(out=sol)
+    out["d2h_ms_pageable"] = (time.perf_counter() - t0) * 1e3
+    pin = rslqr_amd.pinned_empty((batch, bs.nvars))
+    bs.solutions(out=pin)
+    t0 = time.perf_counter()
+    bs.solutions(out=pin)
+    out["d2h_ms"] = (time.perf_counter() - t0) * 1e3
+    out["d2h_gbs"] = out["d2h_bytes"] / out["d2h_ms"] / 1e6
+    out["d2h_equal"] = bool(np.array_equal(pin, sol))
+    # end to end: the same problems' own right-hand sides, so the result must equal the resident solution
+    q, r, d, x0 = (rslqr_amd.pinned_empty(s) for s in ((batch, N, n), (batch, N, m), (batch, N, n), (batch, n)))
+    for p in range(batch):
+        g = rslqr_amd.generate_synthetic(n, m, N, seed0 + p)
+        q[p], r[p], d[p], x0[p] = g["q"], g["r"], g["d"], g["x0"]
+    outs = [rslqr_amd.pinned_empty((batch, bs.nvars)) for _ in range(2)]
+
+    def run(k):
+        for i in range(k):
+            if bs.step_async(q, r, d, x0, outs[i & 1]) != 0:
+                raise RuntimeError("ndlqr_BatchStepAsync failed")
+            if i >= 1:
+                bs.synchronize_previous()
+        bs.synchronize()
+
+    run(4)
+    t0 = time.perf_counter()
+    run(steps)
+    e2e = (time.perf_counter() - t0) / steps
+    end_to_end = {"steps": steps, "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e,
+                  "h2d_bytes_per_step": 8 * batch * (N * rows + n), "d2h_bytes_per_step": 8 * batch * bs.nvars,
+                  "equals_resident_solution": bool(np.array_equal(outs[(steps - 1) & 1], sol)),
+                  "note": "ndlqr_BatchStepAsync: q, r, d, x0 up (pinned), pack kernel, factor + solve, pack kernel, "
+                          "solutions down (pinned); two steps in flight; rank 0; not part of `value`"}
+    # H2D of the packed inputs (a fresh solver: the upload replaces the inputs)
+    h2d = {}
+    if in_bytes <= (8 << 30):
+        tmp = rslqr_amd.BatchSolver(n, m, N, batch)
+        try:
+            for kind in ("pageable", "pinned"):
+                mk = (lambda s: np.ones(s)) if kind == "pageable" else (lambda s: rslqr_amd.pinned_empty(s))
+                hAB, hQR, hrhs = mk((batch, N, n * w)), mk((batch, N, w)), mk((batch, N, rows))
+                if kind == "pinned":
+                    hAB[...], hQR[...], hrhs[...] = 1.0, 1.0, 1.0
+                tmp.upload_packed(hAB, hQR, hrhs)
+                t0 = time.perf_counter()
+                tmp.upload_packed(hAB, hQR, hrhs)
+                h2d[kind] = (time.perf_counter() - t0) * 1e3
+                del hAB, hQR, hrhs
+        finally:
+            tmp.close()
+        out["h2d_ms_pageable"] = h2d["pageable"]
+        out["h2d_ms"] = h2d["pinned"]
+        out["h2d_gbs"] = in_bytes / h2d["pinned"] / 1e6
+    out["note"] = ("rank 0, whole shard; h2d_ms / d2h_ms: pinned host memory (ndlqr_HostAlloc), *_pageable: malloc'ed; "
+                   "not part of `value`")
+    return out, end_to_end, sol
 
 
 def launch_ranks(gpus):
@@ -389,6 +461,7 @@ def main():
     ap.add_argument("--no-modes", action="store_true", help="skip the strict / KEEP / rhs-only legs")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the solution-gather leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU sample (0 = auto)")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the transfer / end-to-end legs")
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the legs of the other BASELINE configurations")
     args = ap.parse_args()
 
@@ -436,18 +509,6 @@ def main():
     bs = rslqr_amd.BatchSolver(n, m, N, batch, device=local_rank, flags=args.flags)
     seed0 = sharding.shard_seed0(rank, batch)  # global problem g has seed 1 + g
 
-    # ---- H2D of the packed inputs, timed on its own (pageable host memory, whole batch, before the
-    #      real problems go up): SURVEY.md 8(d) asks for the transfers next to, never inside, `value`
-    w, rows = n + m, 2 * n + m
-    in_bytes = 8 * batch * N * (n * w + w + rows)
-    h2d_ms = None
-    if rank == 0 and in_bytes <= (8 << 30):
-        hAB, hQR, hrhs = np.ones((batch, N, n * w)), np.ones((batch, N, w)), np.ones((batch, N, rows))
-        bs.upload_packed(hAB, hQR, hrhs)
-        t0 = time.perf_counter()
-        bs.upload_packed(hAB, hQR, hrhs)
-        h2d_ms = (time.perf_counter() - t0) * 1e3
-        del hAB, hQR, hrhs
     log("rank %d: generating + uploading %d synthetic problems" % (rank, batch))
     bs.initialize_synthetic(seed0)
     log("rank %d: warm-up" % rank)
@@ -503,10 +564,12 @@ def main():
     kres, kbn = bs.kkt_residuals()
     kkt_worst = float((kres / np.maximum(1.0, kbn)).max())
 
-    # ---- D2H of the solutions, timed on its own
-    t0 = time.perf_counter()
-    local_sol = bs.solutions()
-    d2h_ms = (time.perf_counter() - t0) * 1e3
+    # ---- transfers and the end-to-end MPC step, timed on their own (rank 0; the other ranks just download)
+    if rank == 0 and not args.no_transfers:
+        log("transfer / end-to-end legs")
+        transfers, end_to_end, local_sol = transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, min(steps, 50))
+    else:
+        transfers, end_to_end, local_sol = None, None, bs.solutions()
 
     # ---- N>1: the same steps with every shard's solutions gathered after each
     gather = None
@@ -574,9 +637,8 @@ def main():
             "spin_up": {"steps": spin_steps, "ms": spin_ms,
                         "note": "untimed full solves before the W warm-up steps: one-time work of the first solves and "
                                 "the clock ramp of the device; --spin-up-ms 0 disables"},
-            "transfers": {"h2d_ms": h2d_ms, "h2d_bytes": in_bytes, "d2h_ms": d2h_ms,
-                          "d2h_bytes": 8 * batch * bs.nvars,
-                          "note": "rank 0, pageable host memory, whole shard; not part of `value`"},
+            "transfers": transfers,
+            "end_to_end": end_to_end,
         }
         if gather:
             g_el, g_bad = red[3], red[4]

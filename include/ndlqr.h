@@ -17,7 +17,9 @@
 #define NDLQR_H_
 
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h> /* (the reference's nested_dissection.h:15 pulls it in; callers rely on that: test/parallel_test.c:120) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -84,6 +86,20 @@ void MatrixSymmetricMultiply(Matrix* Asym, Matrix* B, Matrix* C, double alpha, d
 void MatrixCopyDiagonal(Matrix* dest, Matrix* src);
 enum MatrixLinearAlgebraLibrary MatrixGetLinearAlgebraLibrary(void);
 void MatrixPrintLinearAlgebraLibrary(void);
+/* The names of the reference's internal backend (src/linalg_custom.h:44-159; its tests call them directly,
+ * test/linalg_custom_test.c:11-208). Same argument meaning and return codes, same device kernels as the
+ * Matrix* functions above. */
+static const int clap_kCholeskySuccess = 0;
+static const int clap_kCholeskyFail = -1;
+int clap_MatrixAddition(Matrix* A, Matrix* B, double alpha);                 /* B += alpha A */
+int clap_MatrixScale(Matrix* A, double alpha);                               /* A *= alpha */
+int clap_MatrixMultiply(Matrix* A, Matrix* B, Matrix* C, bool tA, bool tB, double alpha, double beta);
+int clap_MatrixTransposeMultiply(Matrix* A, Matrix* B, Matrix* C);           /* C = A' B */
+int clap_SymmetricMatrixMultiply(Matrix* Asym, Matrix* B, Matrix* C, double alpha, double beta);
+int clap_AddDiagonal(Matrix* A, double alpha);                               /* A += alpha I */
+int clap_CholeskyFactorize(Matrix* A);                                       /* lower, in place; -1: pivot <= 0 */
+int clap_CholeskySolve(Matrix* L, Matrix* b);                                /* b <- (L L')^-1 b */
+int clap_LowerTriBackSub(Matrix* L, Matrix* b, bool istransposed);           /* b <- L^-1 b or L^-T b */
 
 /* ------------------------------------------------------------------ utils.h / linalg_utils.h */
 bool IsPowerOfTwo(int x);
@@ -351,6 +367,18 @@ int ndlqr_BatchSetRhsFlat(NdLqrBatchSolver* bs, const double* q, const double* r
 int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs);
 int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs); /* enqueue on the solver's stream */
 int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
+/* One MPC step, asynchronous: new q, r, d, x0 (flat host layout as above) up, factor + solve against the resident
+ * A, B, Q, R, the solutions [batch][nvars] down into `soln` (the array ndlqr_CopyBatchSolutions fills). Consecutive
+ * steps alternate between the two buffer sets of the solve pipeline, so the transfers of one step run beside the
+ * kernels of the other; `soln` of a step is complete after ndlqr_BatchSynchronize, or -- one step behind --
+ * ndlqr_BatchSynchronizePrevious. Host arrays from ndlqr_HostAlloc (pinned) keep the copies asynchronous;
+ * pageable memory works but blocks. What the reference does per MPC iteration with ndlqr_ResetSolver +
+ * ndlqr_InitializeWithLQRProblem + ndlqr_Solve + ndlqr_CopySolution (src/solve.h:20-32). */
+int ndlqr_BatchStepAsync(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
+                         const double* x0, double* soln);
+int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs);
+void* ndlqr_HostAlloc(size_t bytes); /* pinned host memory (NULL: no device / no memory) */
+void ndlqr_HostFree(void* p);
 int ndlqr_BatchNumVars(const NdLqrBatchSolver* bs);
 int ndlqr_BatchSize(const NdLqrBatchSolver* bs);
 int ndlqr_CopyBatchSolution(NdLqrBatchSolver* bs, int p, double* soln);    /* nvars doubles */

@@ -83,6 +83,23 @@ int ndlqr_hip_upload_rhs(NdlqrHipCtx* ctx, int p0, int count, const double* rhs)
 int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* ctx);
 double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
 
+/* One MPC step, asynchronous: a new right-hand side up (flat host arrays in the reference's layout: q, d
+ * [batch][N][n], r [batch][N][m], x0 [batch][n] -- what ndlqr_InitializeWithLQRProblem reads from the problem,
+ * src/solver.c:141-190), packed and negated by a kernel, factor + solve, the solutions [batch][nvars] (the layout of
+ * ndlqr_hip_download_solutions, src/solve.c:192-201) down into `soln`. Everything is ordered on the stream of the
+ * step's buffer set, so with the two-deep pipeline the copies of one step run beside the kernels of the other. Give
+ * pinned host memory (ndlqr_hip_host_alloc): copies from / to pageable memory are staged by the runtime and block.
+ * `soln` of a step is complete after ndlqr_hip_synchronize (every step) or, one step behind,
+ * ndlqr_hip_synchronize_previous (the step before the most recent one). The step replaces the right-hand side of
+ * ITS buffer set only; ndlqr_hip_upload_inputs / _upload_rhs / _pack_flat_device set it for both again. */
+int ndlqr_hip_step_async(NdlqrHipCtx* ctx, const double* q, const double* r, const double* d, const double* x0,
+                         double* soln);
+int ndlqr_hip_synchronize_previous(NdlqrHipCtx* ctx);
+/* Pinned host memory for the transfer functions (hipHostMalloc): copies from / to it are asynchronous and run at the
+ * rate of the host link. NULL when no device / no memory. */
+void* ndlqr_hip_host_alloc(size_t bytes);
+void ndlqr_hip_host_free(void* p);
+
 /* D2H. soln: count*nvars doubles, nvars = (2n+m)N - m (src/solve.c:192-201).
  * fact: one problem, converted to the reference's NdData layout, N*K*(2n+m)*n doubles. */
 int ndlqr_hip_download_solutions(NdlqrHipCtx* ctx, int p0, int count, double* soln);
@@ -116,6 +133,9 @@ int ndlqr_hip_gemm(int tA, int tB, int m, int n, int k, double alpha, const doub
                    const double* B, int ldb, double beta, double* C, int ldc);
 int ndlqr_hip_potrf_lower(int n, double* A, int lda);
 int ndlqr_hip_potrs_lower(int n, int nrhs, const double* L, int ldl, double* B, int ldb);
+/* one triangular substitution alone: L x = b (transposed = 0) or L' x = b (clap_LowerTriBackSub,
+ * src/linalg_custom.c:113-132) */
+int ndlqr_hip_trsv_lower(int n, int nrhs, const double* L, int ldl, double* B, int ldb, int transposed);
 
 #ifdef __cplusplus
 }

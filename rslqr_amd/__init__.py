@@ -23,4 +23,5 @@ from .api import (  # noqa: F401
     generate_synthetic,
     lib,
     library_path,
+    pinned_empty,
 )

@@ -221,6 +221,10 @@ def lib():
     proto("ndlqr_BatchSetRhsFlat", ci, vp, dp, dp, dp, dp)
     proto("ndlqr_SolveBatchRhsOnly", ci, vp)
     proto("ndlqr_SolveBatchAsync", ci, vp)
+    proto("ndlqr_BatchStepAsync", ci, vp, dp, dp, dp, dp, dp)
+    proto("ndlqr_BatchSynchronizePrevious", ci, vp)
+    proto("ndlqr_HostAlloc", vp, C.c_size_t)
+    proto("ndlqr_HostFree", None, vp)
     proto("ndlqr_BatchSynchronize", ci, vp)
     proto("ndlqr_BatchNumVars", ci, vp)
     proto("ndlqr_BatchSize", ci, vp)
@@ -250,6 +254,21 @@ def lib():
     proto("ndlqr_hip_potrs_lower", ci, ci, ci, dp, ci, dp, ci)
     _LIB = L
     return L
+
+
+def pinned_empty(shape):
+    """float64 numpy array in pinned host memory (ndlqr_HostAlloc): H2D / D2H copies from / to it are
+    asynchronous and run at the rate of the host link. Freed when the array is garbage-collected."""
+    import weakref
+    count = int(np.prod(shape))
+    L = lib()
+    ptr = L.ndlqr_HostAlloc(max(count, 1) * 8)
+    if not ptr:
+        raise MemoryError("ndlqr_HostAlloc(%d bytes) failed" % (count * 8))
+    buf = (C.c_double * max(count, 1)).from_address(ptr)
+    arr = np.ctypeslib.as_array(buf)[:count].reshape(shape)
+    weakref.finalize(buf, L.ndlqr_HostFree, C.c_void_p(ptr))
+    return arr
 
 
 def device_count():
@@ -342,6 +361,20 @@ class BatchSolver:
     def solve_async(self):
         return self.L.ndlqr_SolveBatchAsync(self.h)
 
+    def step_async(self, q, r, d, x0, soln):
+        """ndlqr_BatchStepAsync: new right-hand side up, factor + solve, solutions down into `soln` ([batch, nvars]),
+        asynchronously. The arrays must stay alive and untouched until the step has been synchronised (use
+        pinned_empty() arrays; pageable ones make the call block)."""
+        for a in (q, r, d, x0, soln):
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+        n, m, N, bt = self.n, self.m, self.N, self.batch
+        assert q.size == bt * N * n and d.size == bt * N * n and r.size == bt * N * m and x0.size == bt * n
+        assert soln.size == bt * self.nvars
+        return self.L.ndlqr_BatchStepAsync(self.h, _ptr(q), _ptr(r), _ptr(d), _ptr(x0), _ptr(soln))
+
+    def synchronize_previous(self):
+        return self.L.ndlqr_BatchSynchronizePrevious(self.h)
+
     def synchronize(self):
         return self.L.ndlqr_BatchSynchronize(self.h)
 
@@ -364,8 +397,11 @@ class BatchSolver:
             raise RuntimeError("ndlqr_BatchKktResiduals failed: %d" % err)
         return res, bn
 
-    def solutions(self):
-        out = np.zeros((self.batch, self.nvars))
+    def solutions(self, out=None):
+        """[batch, nvars] solutions of the latest solve; `out`: destination (e.g. a pinned_empty array)."""
+        if out is None:
+            out = np.zeros((self.batch, self.nvars))
+        assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.size == self.batch * self.nvars
         got = self.L.ndlqr_CopyBatchSolutions(self.h, _ptr(out))
         if got != self.nvars:
             raise RuntimeError("ndlqr_CopyBatchSolutions failed: %d" % got)

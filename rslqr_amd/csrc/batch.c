@@ -293,6 +293,16 @@ int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs) {
 int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs) {
   return bs ? ndlqr_hip_synchronize(bs->ctx) : NDLQR_ERR_INVALID;
 }
+int ndlqr_BatchStepAsync(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
+                         const double* x0, double* soln) {
+  return bs ? ndlqr_hip_step_async(bs->ctx, q, r, d, x0, soln) : NDLQR_ERR_INVALID;
+}
+int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs) {
+  return bs ? ndlqr_hip_synchronize_previous(bs->ctx) : NDLQR_ERR_INVALID;
+}
+void* ndlqr_HostAlloc(size_t bytes) { return ndlqr_hip_host_alloc(bytes); }
+void ndlqr_HostFree(void* p) { ndlqr_hip_host_free(p); }
+
 int ndlqr_SolveBatch(NdLqrBatchSolver* bs) {
   if (!bs) return NDLQR_ERR_INVALID;
   int err = ndlqr_hip_solve_async(bs->ctx);

@@ -45,6 +45,8 @@ struct NdlqrAltSlot {
   size_t red_bytes = 0;
   double* ytop = nullptr;
   double* z = nullptr;
+  double* rhs = nullptr;      // this set's copy of the right-hand side (ndlqr_hip_step_async replaces it per step)
+  double* xfer = nullptr;     // transfer staging in HBM: flat q | r | d | x0 going up, packed [batch][nvars] coming down
   int* tree_cnt = nullptr;
   int* h_fail = nullptr;
   hipStream_t stream = nullptr;
@@ -88,12 +90,15 @@ struct NdlqrHipCtx {
   const char* schedule;  // name of the launch sequence the last solve used (ndlqr_hip_schedule)
   int* h_fail;      // pinned host word: the batch-wide failure count, copied behind the last kernel of a solve
   double* kkt_out;  // [2 batch] scratch of ndlqr_hip_kkt_residual (allocated on first use)
+  double* xfer;     // transfer staging of the current buffer set (see NdlqrAltSlot::xfer; allocated on first use)
+  double* h_stage[2];  // pinned bounce buffers of the downloads into pageable host memory (allocated on first use)
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
   bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)
   const char* graph_schedule;  // and its name
   int sep_threads;    // NDLQR_SEP_THREADS: workgroup size of the matrix-core separator (0 = by block size)
   hipEvent_t ev_start, ev_stop;
+  hipEvent_t ev_inputs;  // orders the other buffer set's stream behind a device-side replacement of the inputs
   bool timing_pending;
   double last_ms;
   int last_failures;

@@ -342,6 +342,24 @@ static __global__ void pack_flat_generic(Dims d, const double* __restrict__ A, c
   }
 }
 
+// The right-hand side alone from flat arrays (q, d [batch][N][n], r [batch][N][m], x0 [batch][n]) that live in HBM:
+// knot k = [-(x0 | d_{k-1}); -q_k; -r_k], the last knot's input slot 0 (src/solver.c:141-190). grid (N, batch).
+static __global__ void pack_rhs_flat_generic(Dims d, const double* __restrict__ q, const double* __restrict__ r,
+                                             const double* __restrict__ dd, const double* __restrict__ x0,
+                                             double* __restrict__ rhs) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int n = d.n, m = d.m, rows = d.rows, N = d.N;
+  const size_t pk = (size_t)b * N + k;
+  double* z = rhs + pk * rows;
+  for (int e = threadIdx.x; e < rows; e += blockDim.x) {
+    double v;
+    if (e < n) v = k == 0 ? -x0[(size_t)b * n + e] : -dd[(pk - 1) * n + e];
+    else if (e < 2 * n) v = -q[pk * n + (e - n)];
+    else v = k < N - 1 ? -r[pk * m + (e - 2 * n)] : 0.0;
+    z[e] = v;
+  }
+}
+
 // Solutions [batch][N][2n+m] (the unused trailing u_N slot included) -> [batch][nvars] packed, the
 // layout of ndlqr_CopyBatchSolutions, in device memory. grid (N, batch).
 static __global__ void pack_solutions_generic(Dims d, const double* __restrict__ z, double* __restrict__ dst) {
@@ -639,21 +657,24 @@ static __global__ void dense_potrf(int n, double* A, int lda, int* info) {
   }
 }
 
-// L L' x = b (linalg_custom.c:113-138); one thread per right-hand side.
-static __global__ void dense_potrs(int n, int nrhs, const double* L, int ldl, double* B, int ldb) {
+// L L' x = b (linalg_custom.c:113-138); one thread per right-hand side. which = 1: the forward substitution
+// alone (L x = b), 2: the transposed one alone (L' x = b) -- clap_LowerTriBackSub.
+static __global__ void dense_potrs(int n, int nrhs, const double* L, int ldl, double* B, int ldb, int which) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nrhs) return;
   double* x = B + (size_t)ldb * c;
-  for (int j = 0; j < n; ++j) {
-    const double xj = x[j] / L[j + (size_t)ldl * j];
-    x[j] = xj;
-    for (int i = j + 1; i < n; ++i) x[i] = x[i] - L[i + (size_t)ldl * j] * xj;
-  }
-  for (int j = n - 1; j >= 0; --j) {
-    const double xj = x[j] / L[j + (size_t)ldl * j];
-    x[j] = xj;
-    for (int i = 0; i < j; ++i) x[i] = x[i] - L[j + (size_t)ldl * i] * xj;
-  }
+  if (which != 2)
+    for (int j = 0; j < n; ++j) {
+      const double xj = x[j] / L[j + (size_t)ldl * j];
+      x[j] = xj;
+      for (int i = j + 1; i < n; ++i) x[i] = x[i] - L[i + (size_t)ldl * j] * xj;
+    }
+  if (which != 1)
+    for (int j = n - 1; j >= 0; --j) {
+      const double xj = x[j] / L[j + (size_t)ldl * j];
+      x[j] = xj;
+      for (int i = 0; i < j; ++i) x[i] = x[i] - L[j + (size_t)ldl * i] * xj;
+    }
 }
 
 }  // namespace ndlqr

@@ -97,3 +97,57 @@ void MatrixCopyDiagonal(Matrix* dest, Matrix* src) {
   memset(dest->data, 0, sizeof(double) * (size_t)dest->rows * dest->cols);
   for (int i = 0; i < len && i < n && i < dest->cols; ++i) dest->data[i + n * i] = src->data[i];
 }
+
+/* ---- the reference's internal-backend names (src/linalg_custom.c:6-138): thin aliases over the same
+ *      device kernels, so that test/linalg_custom_test.c runs against this library unchanged ---- */
+int clap_MatrixAddition(Matrix* A, Matrix* B, double alpha) { return MatrixAddition(A, B, alpha); }
+
+int clap_MatrixScale(Matrix* A, double alpha) {
+  if (!A) return -1;
+  /* A <- 0 * (A * 1) + alpha * A as a (count x 1) product: the arithmetic stays on the device */
+  const int count = MatrixNumElements(A);
+  double one = 1.0;
+  return ndlqr_hip_gemm(0, 0, count, 1, 1, 0.0, A->data, count, &one, 1, alpha, A->data, count);
+}
+
+int clap_MatrixMultiply(Matrix* A, Matrix* B, Matrix* C, bool tA, bool tB, double alpha, double beta) {
+  if (!A || !B || !C) return -1;
+  const int m = tA ? A->cols : A->rows;
+  const int k = tA ? A->rows : A->cols;
+  const int n = tB ? B->rows : B->cols;
+  return ndlqr_hip_gemm(tA, tB, m, n, k, alpha, A->data, A->rows, B->data, B->rows, beta, C->data, C->rows);
+}
+
+int clap_MatrixTransposeMultiply(Matrix* A, Matrix* B, Matrix* C) {
+  return clap_MatrixMultiply(A, B, C, true, false, 1.0, 0.0);
+}
+
+int clap_SymmetricMatrixMultiply(Matrix* Asym, Matrix* B, Matrix* C, double alpha, double beta) {
+  if (!Asym || !B || !C) return -1;
+  MatrixSymmetricMultiply(Asym, B, C, alpha, beta);
+  return 0;
+}
+
+int clap_AddDiagonal(Matrix* A, double alpha) {
+  if (!A) return -1;
+  /* diag(A) += alpha: the n diagonal entries as a strided (1 x n) row, C <- alpha * 1 * ones + C */
+  const int n = A->rows;
+  Matrix ones = NewMatrix(1, n);
+  MatrixSetConst(&ones, 1.0);
+  double one = 1.0;
+  const int err = ndlqr_hip_gemm(0, 0, 1, n, 1, alpha, &one, 1, ones.data, 1, 1.0, A->data, n + 1);
+  FreeMatrix(&ones);
+  return err;
+}
+
+int clap_CholeskyFactorize(Matrix* A) {
+  const int out = MatrixCholeskyFactorize(A);
+  return out == 0 ? clap_kCholeskySuccess : (out == -1 ? clap_kCholeskyFail : out);
+}
+
+int clap_CholeskySolve(Matrix* L, Matrix* b) { return MatrixCholeskySolve(L, b); }
+
+int clap_LowerTriBackSub(Matrix* L, Matrix* b, bool istransposed) {
+  if (!L || !b) return -1;
+  return ndlqr_hip_trsv_lower(b->rows, b->cols, L->data, L->rows, b->data, b->rows, istransposed ? 1 : 0);
+}

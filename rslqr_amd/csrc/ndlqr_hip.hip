@@ -6,6 +6,7 @@
 // Written for wave64 / gfx950 only; built with -ffp-contract=off so that every fused
 // multiply-add in the kernels is an explicit fma() (fast mode) or an explicit mul + add
 // (NDLQR_FLAG_STRICT_FP, which reproduces the reference's default CPU build bit for bit).
+#include <mutex>
 #include <utility>
 
 #include "hip_context.hpp"
@@ -84,7 +85,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
   c->pipeline = getenv("NDLQR_PIPELINE") ? atoi(getenv("NDLQR_PIPELINE")) : 2;
   c->solve_count = 0; c->in_alt = false; c->z_latest = nullptr; c->stream_latest = nullptr; c->h_fail_other = nullptr;
-  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false; c->graph_schedule = "none";
+  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->xfer = nullptr; c->h_stage[0] = c->h_stage[1] = nullptr; c->ev_inputs = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false; c->graph_schedule = "none";
 
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->rowbcast = getenv("NDLQR_ROWBCAST") ? (atoi(getenv("NDLQR_ROWBCAST")) != 0 ? 1 : 0) : -1;  // -1: by block size
@@ -96,6 +97,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) == hipSuccess &&
             hipMalloc(&c->AB, bytes_AB(d)) == hipSuccess && hipMalloc(&c->QR, bytes_QR(d)) == hipSuccess &&
             hipMalloc(&c->rhs, bytes_z(d)) == hipSuccess && hipMalloc(&c->z, bytes_z(d)) == hipSuccess &&
             hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
@@ -139,7 +141,9 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
-  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->wfac);
+  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->wfac); (void)hipFree(c->xfer);
+  for (double* h : c->h_stage) if (h) (void)hipHostFree(h);
+  if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -153,6 +157,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
 static void swap_slot(NdlqrHipCtx* c) {
   NdlqrAltSlot& a = c->alt;
   std::swap(c->rec, a.rec); std::swap(c->red, a.red); std::swap(c->red_bytes, a.red_bytes); std::swap(c->ytop, a.ytop); std::swap(c->z, a.z);
+  std::swap(c->rhs, a.rhs); std::swap(c->xfer, a.xfer);
   std::swap(c->tree_cnt, a.tree_cnt); std::swap(c->h_fail, a.h_fail); std::swap(c->stream, a.stream);
   std::swap(c->graph_exec, a.graph_exec); std::swap(c->graph_flags, a.graph_flags);
   std::swap(c->graph_stream, a.graph_stream); std::swap(c->graph_rec_complete, a.graph_rec_complete);
@@ -167,6 +172,7 @@ static void free_alt(NdlqrHipCtx* c) {
   if (a.stream) (void)hipStreamSynchronize(a.stream);
   if (a.graph_exec) (void)hipGraphExecDestroy(a.graph_exec);
   (void)hipFree(a.rec); (void)hipFree(a.red); (void)hipFree(a.ytop); (void)hipFree(a.z); (void)hipFree(a.tree_cnt);
+  (void)hipFree(a.rhs); (void)hipFree(a.xfer);
   if (a.h_fail) (void)hipHostFree(a.h_fail);
   if (a.ev_start) (void)hipEventDestroy(a.ev_start);
   if (a.ev_stop) (void)hipEventDestroy(a.ev_stop);
@@ -185,7 +191,12 @@ static bool ensure_alt(NdlqrHipCtx* c) {
   bool ok = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&a.ev_start) == hipSuccess && hipEventCreate(&a.ev_stop) == hipSuccess &&
             hipMalloc(&a.rec, bytes_rec(d)) == hipSuccess && hipMalloc(&a.z, bytes_z(d)) == hipSuccess &&
+            hipMalloc(&a.rhs, bytes_z(d)) == hipSuccess &&
             hipHostMalloc((void**)&a.h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  // this set's own copy of the right-hand side (a step of ndlqr_hip_step_async replaces the right-hand side of
+  // ITS buffer set only; whatever replaces the inputs of the context writes both copies: mirror_rhs)
+  ok = ok && hipStreamSynchronize(c->stream) == hipSuccess &&
+       hipMemcpyAsync(a.rhs, c->rhs, bytes_z(d), hipMemcpyDeviceToDevice, a.stream) == hipSuccess;
   if (ok && c->tree_cnt)  // size-specialised shapes (the runtime-sized schedule's slots: ensure_red_generic)
     ok = hipMalloc(&a.red, red_bytes) == hipSuccess && hipMemsetAsync(a.red, 0, red_bytes, a.stream) == hipSuccess &&
          ((a.red_bytes = red_bytes), true) &&
@@ -217,6 +228,8 @@ int ndlqr_hip_set_pipeline_depth(NdlqrHipCtx* c, int depth) {
   if (c->in_alt) {  // keep the latest solution where the single-slot code expects it
     swap_slot(c);
     if (c->alt.z && c->z_latest == c->alt.z) {
+      // (and the right-hand side it belongs to: after ndlqr_hip_step_async the two sets hold different ones)
+      HIP_TRY(hipMemcpy(c->rhs, c->alt.rhs, bytes_z(c->d), hipMemcpyDeviceToDevice));
       HIP_TRY(hipMemcpy(c->z, c->alt.z, bytes_z(c->d), hipMemcpyDeviceToDevice));
       HIP_TRY(hipDeviceSynchronize());  // (a device-to-device copy on the null stream need not be finished on return;
                                         //  the solver's streams do not wait for the null stream)
@@ -276,6 +289,21 @@ int ndlqr_hip_set_stream(NdlqrHipCtx* c, void* hip_stream) {
 }
 void* ndlqr_hip_get_stream(NdlqrHipCtx* c) { return c ? (void*)c->stream : nullptr; }
 
+// The right-hand side exists once per buffer set of the pipeline: after `count` doubles at `offset` of the current
+// set's copy have been (re)written on the current stream, the other set's copy follows (same stream: the caller
+// synchronises it or orders the other stream behind it with other_stream_waits).
+static hipError_t mirror_rhs(NdlqrHipCtx* c, size_t offset, size_t count) {
+  if (!c->alt.rhs) return hipSuccess;
+  return hipMemcpyAsync(c->alt.rhs + offset, c->rhs + offset, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream);
+}
+
+// the other buffer set's stream waits for everything enqueued on the current one so far
+static hipError_t other_stream_waits(NdlqrHipCtx* c) {
+  if (!c->alt.stream) return hipSuccess;
+  const hipError_t e = hipEventRecord(c->ev_inputs, c->stream);
+  return e != hipSuccess ? e : hipStreamWaitEvent(c->alt.stream, c->ev_inputs, 0);
+}
+
 int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB, const double* QR,
                             const double* rhs) {
   if (!c || !AB || !QR || !rhs || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
@@ -286,6 +314,7 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   HIP_TRY(hipMemcpyAsync(c->AB + p0 * sAB, AB, sizeof(double) * sAB * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->QR + p0 * sQR, QR, sizeof(double) * sQR * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(mirror_rhs(c, p0 * sz, sz * count));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host staging buffers are reused by the caller
   c->fact_valid = false;  // new A, B, Q, R: a cached factorisation no longer matches the inputs
   c->rec_complete = false;
@@ -301,6 +330,8 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->d, A, B, Q, R,
                      q, r, d, x0, c->AB, c->QR, c->rhs);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(mirror_rhs(c, 0, (size_t)c->d.batch * c->d.N * c->d.rows));
+  HIP_TRY(other_stream_waits(c));  // the next solve may run on the other buffer set's stream
   c->fact_valid = false;  // new A, B, Q, R: neither a cached factor array nor cached records match
   c->rec_complete = false;
   return NDLQR_OK;
@@ -661,8 +692,9 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   return err;
 }
 
-int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
-  if (!c) return NDLQR_ERR_INVALID;
+// first half of a solve: allocations, recovery from a failed solve, choice of the buffer set (the context's
+// buffer / stream fields hold it on return). *pipelined_out: this solve runs on the two-deep pipeline.
+static int prepare_solve(NdlqrHipCtx* c, bool* pipelined_out) {
   HIP_TRY(hipSetDevice(c->device));
   if (solve_needs_F(c)) {  // before any capture starts: allocation is not a stream operation
     const int ferr = ndlqr_hip_ensure_F(c);
@@ -698,7 +730,12 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   if (want_alt != c->in_alt) swap_slot(c);
   ++c->solve_count;
   c->state_dirty = true;  // until this solve is known to have been enqueued completely
-  HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  if (pipelined_out) *pipelined_out = pipelined;
+  return NDLQR_OK;
+}
+
+// second half: the launch sequence (replayed as a hipGraph) on the current buffer set's stream
+static int launch_solve(NdlqrHipCtx* c) {
   int err = NDLQR_OK;
   if (c->flags & NDLQR_FLAG_PROFILE) {
     err = enqueue_solve(c);  // per-kernel events need eager launches
@@ -728,15 +765,88 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   }
   if (err) return err;
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
-  c->timing_pending = true;
-  c->state_dirty = false;
   c->z_latest = c->z;
   c->stream_latest = c->stream;
   // a complete factor array is on the device with KEEP, and on the strict runtime-sized path
   c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 ||
                   ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
   return NDLQR_OK;
+}
+
+int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
+  if (!c) return NDLQR_ERR_INVALID;
+  int err = prepare_solve(c, nullptr);
+  if (err) return err;
+  HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  err = launch_solve(c);
+  if (err) return err;
+  HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+  c->timing_pending = true;
+  c->state_dirty = false;
+  return NDLQR_OK;
+}
+
+// transfer staging of the current buffer set: max(flat right-hand side, packed solutions) doubles
+static int ensure_xfer(NdlqrHipCtx* c) {
+  if (c->xfer) return NDLQR_OK;
+  const ndlqr::Dims& d = c->d;
+  HIP_TRY(hipMalloc(&c->xfer, sizeof(double) * ((size_t)d.batch * d.N * d.rows + (size_t)d.batch * d.n)));
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const double* dd, const double* x0,
+                         double* soln) {
+  if (!c || !q || !r || !dd || !x0 || !soln) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  bool pipelined = false;
+  int err = prepare_solve(c, &pipelined);
+  if (err) return err;
+  err = ensure_xfer(c);  // (before anything is captured: allocation is not a stream operation)
+  if (err) return err;
+  // everything of this step is ordered on the stream of its buffer set: the copies of one step overlap the kernels of
+  // the other set's step. Without the pipeline (factor array / records kept, caller-owned stream, depth 1) the steps
+  // are simply stream-ordered.
+  (void)pipelined;
+  hipStream_t st = c->stream;
+  HIP_TRY(hipEventRecord(c->ev_start, st));
+  const size_t nq = (size_t)d.batch * d.N * d.n, nr = (size_t)d.batch * d.N * d.m, nx = (size_t)d.batch * d.n;
+  double* fq = c->xfer; double* fr = fq + nq; double* fd = fr + nr; double* fx = fd + nq;
+  HIP_TRY(hipMemcpyAsync(fq, q, sizeof(double) * nq, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(fr, r, sizeof(double) * nr, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(fd, dd, sizeof(double) * nq, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(fx, x0, sizeof(double) * nx, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ndlqr::pack_rhs_flat_generic, dim3(d.N, d.batch), dim3(64), 0, st, d, fq, fr, fd, fx, c->rhs);
+  HIP_TRY(hipGetLastError());
+  err = launch_solve(c);
+  if (err) return err;
+  // the flat right-hand side has been consumed by the pack kernel: the staging now takes the packed solutions
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, d, c->z, c->xfer);
+  HIP_TRY(hipGetLastError());
+  const size_t nvars = (size_t)d.rows * d.N - d.m;
+  HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * nvars * d.batch, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(c->ev_stop, st));
+  c->timing_pending = true;
+  c->state_dirty = false;
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_synchronize_previous(NdlqrHipCtx* c) {
+  if (!c) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->alt.stream) HIP_TRY(hipStreamSynchronize(c->alt.stream));  // (the set that is not current holds the older step)
+  return NDLQR_OK;
+}
+
+void* ndlqr_hip_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void ndlqr_hip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
@@ -746,6 +856,7 @@ int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
   HIP_TRY(sync_all(c));
   const size_t sz = (size_t)d.N * d.rows;
   HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(mirror_rhs(c, p0 * sz, sz * count));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return NDLQR_OK;
 }
@@ -868,16 +979,65 @@ int ndlqr_hip_profile_reset(NdlqrHipCtx* c) {
 
 // ------------------------------------------------------------------------------ downloads
 
+// is `p` pinned (hipHostMalloc / hipHostRegister) host memory?
+static bool host_ptr_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary malloc'ed pointer is "invalid value" to older runtimes
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// Solutions of problems [p0, p0 + count) as [count][nvars]: a pack kernel gathers them into the transfer staging
+// (the device layout carries the unused trailing input slot of every problem, src/solver.c:64), then ONE contiguous
+// copy brings them down -- straight into `soln` when that is pinned memory (ndlqr_hip_host_alloc), through two
+// pinned 8 MB bounce buffers otherwise (the copy of chunk i overlaps the host memcpy of chunk i-1). The strided
+// hipMemcpy2D into pageable memory this replaces ran at 5.4 GB/s.
 int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln) {
   if (!c || !soln || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
+  const int xerr = ensure_xfer(c);
+  if (xerr) return xerr;
   const double* zl = c->z_latest ? c->z_latest : c->z;
   const size_t nvars = (size_t)d.rows * d.N - d.m, pitch = (size_t)d.rows * d.N;
-  HIP_TRY(hipMemcpy2DAsync(soln, sizeof(double) * nvars, zl + p0 * pitch, sizeof(double) * pitch,
-                           sizeof(double) * nvars, (size_t)count, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  hipStream_t st = c->stream;
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, count), dim3(64), 0, st, d, zl + p0 * pitch, c->xfer);
+  HIP_TRY(hipGetLastError());
+  const size_t total = nvars * count;
+  if (host_ptr_is_pinned(soln)) {
+    HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NDLQR_OK;
+  }
+  const size_t chunk = (8u << 20) / sizeof(double);
+  if (total <= chunk / 8) {  // small: one synchronous copy (the runtime stages it)
+    HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NDLQR_OK;
+  }
+  for (int i = 0; i < 2; ++i)
+    if (!c->h_stage[i]) HIP_TRY(hipHostMalloc((void**)&c->h_stage[i], sizeof(double) * chunk, hipHostMallocDefault));
+  hipEvent_t done[2] = {take_event(c), take_event(c)};
+  const size_t nchunks = (total + chunk - 1) / chunk;
+  hipError_t e = hipSuccess;
+  for (size_t i = 0; i <= nchunks && e == hipSuccess; ++i) {
+    if (i < nchunks) {  // (buffer i & 1 held chunk i - 2, which the previous iteration copied out)
+      const size_t off = i * chunk, len = total - off < chunk ? total - off : chunk;
+      e = hipMemcpyAsync(c->h_stage[i & 1], c->xfer + off, sizeof(double) * len, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipEventRecord(done[i & 1], st);
+    }
+    if (i > 0 && e == hipSuccess) {
+      const size_t off = (i - 1) * chunk, len = total - off < chunk ? total - off : chunk;
+      e = hipEventSynchronize(done[(i - 1) & 1]);
+      if (e == hipSuccess) memcpy(soln + off, c->h_stage[(i - 1) & 1], sizeof(double) * len);
+    }
+  }
+  c->event_pool.push_back(done[0]);
+  c->event_pool.push_back(done[1]);
+  if (e != hipSuccess) return fail("ndlqr_hip_download_solutions", e);
   return NDLQR_OK;
 }
 
@@ -957,10 +1117,45 @@ int ndlqr_hip_download_factors(NdlqrHipCtx* c, int p, double* fact) {
 
 // ------------------------------------------------------------------------------ dense helpers
 
+// Host matrices in, host matrices out (the reference's Matrix* layer, src/linalg.c:55-190). One call = one
+// packed H2D copy of the operands, one kernel, one D2H copy of the result, all on the stream of a pooled
+// scratch (a device buffer + a pinned staging buffer, grown on demand): no allocation and no blocking
+// null-stream copy per call, and calls from different host threads (the reference's tests call these from
+// an OpenMP team, test/parallel_test.c:30-239) run side by side on different scratches.
 namespace {
-struct DevBuf {
-  double* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+struct DenseScratch {
+  double* dev = nullptr;
+  double* host = nullptr;
+  size_t cap = 0;  // doubles
+  hipStream_t stream = nullptr;
+};
+std::mutex g_dense_mu;
+std::vector<DenseScratch*> g_dense_pool;  // idle scratches; never freed (bounded by the peak concurrency)
+
+struct DenseLease {
+  DenseScratch* s = nullptr;
+  DenseLease() {
+    std::lock_guard<std::mutex> lock(g_dense_mu);
+    if (!g_dense_pool.empty()) { s = g_dense_pool.back(); g_dense_pool.pop_back(); }
+    else s = new DenseScratch();
+  }
+  ~DenseLease() {
+    std::lock_guard<std::mutex> lock(g_dense_mu);
+    g_dense_pool.push_back(s);
+  }
+  int ensure(size_t doubles) {
+    if (!s->stream) HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    if (doubles <= s->cap) return NDLQR_OK;
+    size_t cap = s->cap ? s->cap : 4096;
+    while (cap < doubles) cap *= 2;
+    if (s->dev) { (void)hipFree(s->dev); s->dev = nullptr; }
+    if (s->host) { (void)hipHostFree(s->host); s->host = nullptr; }
+    s->cap = 0;
+    HIP_TRY(hipMalloc(&s->dev, sizeof(double) * cap));
+    HIP_TRY(hipHostMalloc((void**)&s->host, sizeof(double) * cap, hipHostMallocDefault));
+    s->cap = cap;
+    return NDLQR_OK;
+  }
 };
 }  // namespace
 
@@ -977,50 +1172,82 @@ static int dense_ready() {
 int ndlqr_hip_gemm(int tA, int tB, int m, int n, int k, double alpha, const double* A, int lda,
                    const double* B, int ldb, double beta, double* C, int ldc) {
   if (dense_ready()) return NDLQR_ERR_NO_DEVICE;
-  const int Ac = tA ? m : k, Bc = tB ? k : n;
-  DevBuf dA, dB, dC;
-  const size_t bA = sizeof(double) * (size_t)lda * Ac, bB = sizeof(double) * (size_t)ldb * Bc,
-               bC = sizeof(double) * (size_t)ldc * n;
-  HIP_TRY(hipMalloc(&dA.p, bA)); HIP_TRY(hipMalloc(&dB.p, bB)); HIP_TRY(hipMalloc(&dC.p, bC));
-  HIP_TRY(hipMemcpy(dA.p, A, bA, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dB.p, B, bB, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dC.p, C, bC, hipMemcpyHostToDevice));
+  if (m <= 0 || n <= 0 || k < 0 || !A || !B || !C) return NDLQR_ERR_INVALID;
+  // stored shapes: A is (Ar x Ac) with leading dimension lda, ...; the last column ends after its rows
+  const int Ar = tA ? k : m, Ac = tA ? m : k, Br = tB ? n : k, Bc = tB ? k : n;
+  if (k > 0 && (lda < Ar || ldb < Br)) return NDLQR_ERR_INVALID;
+  if (ldc < m) return NDLQR_ERR_INVALID;
+  const size_t nA = k > 0 ? (size_t)lda * (Ac - 1) + Ar : 0, nB = k > 0 ? (size_t)ldb * (Bc - 1) + Br : 0,
+               nC = (size_t)ldc * (n - 1) + m;
+  DenseLease L;
+  const int err = L.ensure(nA + nB + nC);
+  if (err) return err;
+  DenseScratch* s = L.s;
+  memcpy(s->host, A, sizeof(double) * nA);
+  memcpy(s->host + nA, B, sizeof(double) * nB);
+  memcpy(s->host + nA + nB, C, sizeof(double) * nC);
+  HIP_TRY(hipMemcpyAsync(s->dev, s->host, sizeof(double) * (nA + nB + nC), hipMemcpyHostToDevice, s->stream));
   const int total = m * n;
-  hipLaunchKernelGGL(ndlqr::dense_gemm, dim3((total + 255) / 256), dim3(256), 0, 0, tA, tB, m, n, k,
-                     alpha, dA.p, lda, dB.p, ldb, beta, dC.p, ldc);
+  hipLaunchKernelGGL(ndlqr::dense_gemm, dim3((total + 255) / 256), dim3(256), 0, s->stream, tA, tB, m, n, k, alpha,
+                     s->dev, lda, s->dev + nA, ldb, beta, s->dev + nA + nB, ldc);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(C, dC.p, bC, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(s->host + nA + nB, s->dev + nA + nB, sizeof(double) * nC, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  memcpy(C, s->host + nA + nB, sizeof(double) * nC);
   return NDLQR_OK;
 }
 
 int ndlqr_hip_potrf_lower(int n, double* A, int lda) {
   if (dense_ready()) return NDLQR_ERR_NO_DEVICE;
-  DevBuf dA, dI;  // dI: one int, held as a double-sized buffer
-  const size_t bA = sizeof(double) * (size_t)lda * n;
-  HIP_TRY(hipMalloc(&dA.p, bA));
-  HIP_TRY(hipMalloc(&dI.p, sizeof(double)));
-  int* dinfo = reinterpret_cast<int*>(dI.p);
-  HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
-  HIP_TRY(hipMemcpy(dA.p, A, bA, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(ndlqr::dense_potrf, dim3(1), dim3(256), 0, 0, n, dA.p, lda, dinfo);
+  if (n <= 0 || !A) return NDLQR_ERR_INVALID;
+  if (lda < n) return NDLQR_ERR_INVALID;
+  const size_t nA = (size_t)lda * (n - 1) + n;
+  DenseLease L;
+  const int err = L.ensure(nA + 1);  // + one slot for the failure word
+  if (err) return err;
+  DenseScratch* s = L.s;
+  memcpy(s->host, A, sizeof(double) * nA);
+  s->host[nA] = 0.0;  // (all-zero bits: the int the kernel writes into starts at 0)
+  HIP_TRY(hipMemcpyAsync(s->dev, s->host, sizeof(double) * (nA + 1), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(ndlqr::dense_potrf, dim3(1), dim3(256), 0, s->stream, n, s->dev, lda,
+                     reinterpret_cast<int*>(s->dev + nA));
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->host, s->dev, sizeof(double) * (nA + 1), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  memcpy(A, s->host, sizeof(double) * nA);
   int info = 0;
-  HIP_TRY(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(A, dA.p, bA, hipMemcpyDeviceToHost));
+  memcpy(&info, s->host + nA, sizeof(int));
   return info ? -1 : 0;
 }
 
-int ndlqr_hip_potrs_lower(int n, int nrhs, const double* L, int ldl, double* B, int ldb) {
+// which: 0 = L L' x = b (both substitutions), 1 = L x = b, 2 = L' x = b
+static int dense_tri_solve(int which, int n, int nrhs, const double* Lm, int ldl, double* B, int ldb) {
   if (dense_ready()) return NDLQR_ERR_NO_DEVICE;
-  DevBuf dL, dB;
-  const size_t bL = sizeof(double) * (size_t)ldl * n, bB = sizeof(double) * (size_t)ldb * nrhs;
-  HIP_TRY(hipMalloc(&dL.p, bL)); HIP_TRY(hipMalloc(&dB.p, bB));
-  HIP_TRY(hipMemcpy(dL.p, L, bL, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dB.p, B, bB, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(ndlqr::dense_potrs, dim3((nrhs + 63) / 64), dim3(64), 0, 0, n, nrhs, dL.p, ldl, dB.p, ldb);
+  if (n <= 0 || nrhs <= 0 || !Lm || !B) return NDLQR_ERR_INVALID;
+  if (ldl < n || ldb < n) return NDLQR_ERR_INVALID;
+  const size_t nL = (size_t)ldl * (n - 1) + n, nB = (size_t)ldb * (nrhs - 1) + n;
+  DenseLease L;
+  const int err = L.ensure(nL + nB);
+  if (err) return err;
+  DenseScratch* s = L.s;
+  memcpy(s->host, Lm, sizeof(double) * nL);
+  memcpy(s->host + nL, B, sizeof(double) * nB);
+  HIP_TRY(hipMemcpyAsync(s->dev, s->host, sizeof(double) * (nL + nB), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(ndlqr::dense_potrs, dim3((nrhs + 63) / 64), dim3(64), 0, s->stream, n, nrhs, s->dev, ldl,
+                     s->dev + nL, ldb, which);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(B, dB.p, bB, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(s->host + nL, s->dev + nL, sizeof(double) * nB, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  memcpy(B, s->host + nL, sizeof(double) * nB);
   return NDLQR_OK;
+}
+
+int ndlqr_hip_potrs_lower(int n, int nrhs, const double* L, int ldl, double* B, int ldb) {
+  return dense_tri_solve(0, n, nrhs, L, ldl, B, ldb);
+}
+
+int ndlqr_hip_trsv_lower(int n, int nrhs, const double* L, int ldl, double* B, int ldb, int transposed) {
+  return dense_tri_solve(transposed ? 2 : 1, n, nrhs, L, ldl, B, ldb);
 }
 
 // developer hook (tools/debug_compare.py; not part of include/*.h): raw copy of an internal array,

@@ -658,3 +658,78 @@ print("DEVICE_PACKING_OK")
 """ % root
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DEVICE_PACKING_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("n,m,N,batch,flags", [(12, 4, 64, 300, 0), (6, 3, 32, 5, 0), (20, 6, 16, 40, 0),
+                                                 (12, 4, 64, 300, 16), (7, 2, 8, 3, 0)])
+def test_step_async_transfers_and_solves(ndlqr, oracle, n, m, N, batch, flags):
+    """ndlqr_BatchStepAsync (the MPC step: new q, r, d, x0 up, factor + solve, solutions down; what the reference
+    does per iteration with Reset + Initialize + Solve + CopySolution, src/solve.h:20-32): a stream of steps with a
+    different right-hand side each, two in flight, pinned host arrays; every step's solutions against the oracle's
+    solve of that problem; the pageable-memory form; the plain download functions afterwards."""
+    gens = [ndlqr.generate_synthetic(n, m, N, 500 + p) for p in range(batch)]
+    flat = {k: np.stack([g[k] for g in gens]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")}
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=flags)
+    bs.initialize_flat(*[flat[k] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    rng = np.random.default_rng(7)
+    nsteps = 5
+    ins, outs = [], []
+    for s in range(nsteps):
+        arrs = {}
+        for k in ("q", "r", "d", "x0"):
+            a = ndlqr.pinned_empty(flat[k].shape)
+            a[...] = flat[k] + 0.25 * (s + 1) * rng.standard_normal(flat[k].shape)
+            arrs[k] = a
+        ins.append(arrs)
+        outs.append(ndlqr.pinned_empty((batch, bs.nvars)))
+        outs[-1][...] = np.nan
+    for s in range(nsteps):
+        assert bs.step_async(ins[s]["q"], ins[s]["r"], ins[s]["d"], ins[s]["x0"], outs[s]) == 0
+        if s >= 1:
+            assert bs.synchronize_previous() == 0
+            assert np.isfinite(outs[s - 1]).all()  # the older step is complete while the newer one is in flight
+    assert bs.synchronize() == 0
+    assert bs.cholesky_failures() == 0
+    for s in range(nsteps):
+        for p in sorted({0, batch // 2, batch - 1}):
+            prob = Problem(n, m, N, flat["A"][p], flat["B"][p], flat["Q"][p], flat["R"][p], ins[s]["q"][p],
+                           ins[s]["r"][p], ins[s]["d"][p], ins[s]["x0"][p])
+            ref = oracle.solve(prob, 1)[0][: prob.nvars]
+            assert np.linalg.norm(outs[s][p] - ref) / np.linalg.norm(ref) <= REL_TOL, (s, p)
+    # the solution resident on the device is the last step's: both download paths (pageable: staged, pinned: direct)
+    last = outs[-1].copy()
+    assert np.array_equal(bs.solutions(), last)
+    pinned = ndlqr.pinned_empty((batch, bs.nvars))
+    assert np.array_equal(bs.solutions(out=pinned), last)
+    assert np.array_equal(bs.solution(batch - 1), last[batch - 1])
+    res, bn = bs.kkt_residuals()  # against the right-hand side of the step it belongs to
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    # pageable arrays: the call blocks but is correct
+    out = np.zeros((batch, bs.nvars))
+    assert bs.step_async(ins[0]["q"].copy(), ins[0]["r"].copy(), ins[0]["d"].copy(), ins[0]["x0"].copy(), out) == 0
+    assert bs.synchronize() == 0
+    assert np.array_equal(out, outs[0])
+    # a new right-hand side for every following solve replaces both buffer sets' copies
+    bs.set_rhs_flat(flat["q"], flat["r"], flat["d"], flat["x0"])
+    assert bs.solve_async() == 0 and bs.solve_async() == 0 and bs.synchronize() == 0
+    prob = Problem(n, m, N, *[flat[k][0] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    ref = oracle.solve(prob, 1)[0][: prob.nvars]
+    assert np.linalg.norm(bs.solution(0) - ref) / np.linalg.norm(ref) <= REL_TOL
+    bs.close()
+
+
+def test_large_download_through_bounce_buffers(ndlqr):
+    """ndlqr_CopyBatchSolutions into pageable memory goes through two pinned 8 MB bounce buffers in chunks: a
+    download larger than several chunks equals the pinned (single-copy) one and the per-problem one."""
+    n, m, N, batch = 12, 4, 256, 600  # 600 x 7164 doubles = 34 MB: five chunks
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_synthetic(77)
+    assert bs.solve() == 0
+    pageable = bs.solutions()
+    pinned = bs.solutions(out=ndlqr.pinned_empty((batch, bs.nvars)))
+    assert np.array_equal(pageable, pinned)
+    for p in (0, 311, batch - 1):
+        assert np.array_equal(bs.solution(p), pageable[p])
+    res, bn = bs.kkt_residuals()
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    bs.close()
