@@ -221,23 +221,29 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         q[p], r[p], d[p], x0[p] = g["q"], g["r"], g["d"], g["x0"]
     outs = [rslqr_amd.pinned_empty((batch, bs.nvars)) for _ in range(2)]
 
-    def run(k):
+    def run(k, full):
         for i in range(k):
-            if bs.step_async(q, r, d, x0, outs[i & 1]) != 0:
+            err = bs.step_async(q, r, d, x0, outs[i & 1]) if full else bs.step_async(None, None, None, x0, outs[i & 1])
+            if err != 0:
                 raise RuntimeError("ndlqr_BatchStepAsync failed")
             if i >= 1:
                 bs.synchronize_previous()
         bs.synchronize()
 
-    run(4)
-    t0 = time.perf_counter()
-    run(steps)
-    e2e = (time.perf_counter() - t0) / steps
-    end_to_end = {"steps": steps, "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e,
-                  "h2d_bytes_per_step": 8 * batch * (N * rows + n), "d2h_bytes_per_step": 8 * batch * bs.nvars,
-                  "equals_resident_solution": bool(np.array_equal(outs[(steps - 1) & 1], sol)),
-                  "note": "ndlqr_BatchStepAsync: q, r, d, x0 up (pinned), pack kernel, factor + solve, pack kernel, "
-                          "solutions down (pinned); two steps in flight; rank 0; not part of `value`"}
+    end_to_end = {"steps": steps, "d2h_bytes_per_step": 8 * batch * bs.nvars,
+                  "note": "ndlqr_BatchStepAsync, pinned host arrays, two steps in flight, rank 0; not part of `value`. "
+                          "full_rhs: q, r, d, x0 read over the host link by the pack kernel, factor + solve, pack kernel, "
+                          "solutions down; x0_only: the same with x0 alone replaced (the usual MPC iteration)"}
+    for name, full in (("full_rhs", True), ("x0_only", False)):
+        run(4, full)
+        t0 = time.perf_counter()
+        run(steps, full)
+        e2e = (time.perf_counter() - t0) / steps
+        end_to_end[name] = {"ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e,
+                            "h2d_bytes_per_step": 8 * batch * ((N * rows if full else 0) + n),
+                            "equals_resident_solution": bool(np.array_equal(outs[(steps - 1) & 1], sol))}
+    end_to_end["ms_per_step"] = end_to_end["full_rhs"]["ms_per_step"]
+    end_to_end["solves_per_s"] = end_to_end["full_rhs"]["solves_per_s"]
     # H2D of the packed inputs (a fresh solver: the upload replaces the inputs)
     h2d = {}
     if in_bytes <= (8 << 30):
@@ -462,9 +468,27 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the solution-gather leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="problems in the CPU sample (0 = auto)")
     ap.add_argument("--no-transfers", action="store_true", help="skip the transfer / end-to-end legs")
+    ap.add_argument("--transfer-leg", action="store_true", help=argparse.SUPPRESS)  # internal: child process of the N=1 run
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the legs of the other BASELINE configurations")
     args = ap.parse_args()
 
+    if args.transfer_leg:
+        # Child of the N = 1 run (below): the transfer / end-to-end legs in a process of their own that never imports
+        # torch. torch 2.10+rocm7.0 brings its own HIP runtime (torch/lib/libamdhip64.so, 7.0), which every library
+        # loaded after it then uses; on it copies and kernels of two streams overlap far less than on the system's
+        # ROCm 7.2 runtime that a plain C caller of the library gets (x0-only step 1.72 vs 1.19 ms,
+        # tools/e2e_probe.py --with-torch). The parent is idle while this runs.
+        import rslqr_amd
+        n, m, N, batch = args.nx, args.nu, args.horizon, args.batch
+        bs = rslqr_amd.BatchSolver(n, m, N, batch, device=0, flags=args.flags)
+        bs.initialize_synthetic(1)
+        for _ in range(8):
+            bs.solve_async()
+        bs.synchronize()
+        transfers, end_to_end, _ = transfer_legs(rslqr_amd, bs, n, m, N, batch, 1, min(args.steps, 50))
+        bs.close()
+        print(json.dumps({"transfers": transfers, "end_to_end": end_to_end}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)  # does not return
     if os.environ.get("NDLQR_BENCH_LAUNCH_ONLY"):  # test hook (tests/test_sharding_gloo.py): the launch alone, no GPU
@@ -564,12 +588,25 @@ def main():
     kres, kbn = bs.kkt_residuals()
     kkt_worst = float((kres / np.maximum(1.0, kbn)).max())
 
-    # ---- transfers and the end-to-end MPC step, timed on their own (rank 0; the other ranks just download)
-    if rank == 0 and not args.no_transfers:
-        log("transfer / end-to-end legs")
-        transfers, end_to_end, local_sol = transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, min(steps, 50))
-    else:
-        transfers, end_to_end, local_sol = None, None, bs.solutions()
+    # ---- transfers and the end-to-end MPC step, timed on their own: N = 1 only, in a child process without torch
+    #      (see --transfer-leg above); the GPU is otherwise idle meanwhile
+    local_sol = bs.solutions()
+    transfers, end_to_end = None, None
+    if world == 1 and not args.no_transfers:
+        log("transfer / end-to-end legs (child process on the system HIP runtime)")
+        cmd = [sys.executable, os.path.abspath(__file__), "--transfer-leg", "--steps", str(steps), "--nx", str(n),
+               "--nu", str(m), "--horizon", str(N), "--batch", str(batch), "--flags", str(args.flags)]
+        try:
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+            if proc.returncode == 0 and lines:
+                leg = json.loads(lines[-1])
+                transfers, end_to_end = leg["transfers"], leg["end_to_end"]
+                transfers["runtime"] = end_to_end["runtime"] = "child process without torch: system ROCm HIP runtime"
+            else:
+                log("transfer leg failed (rc %d): %s" % (proc.returncode, proc.stderr[-500:]))
+        except subprocess.TimeoutExpired:
+            log("transfer leg timed out")
 
     # ---- N>1: the same steps with every shard's solutions gathered after each
     gather = None

@@ -368,7 +368,9 @@ int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs);
 int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs); /* enqueue on the solver's stream */
 int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
 /* One MPC step, asynchronous: new q, r, d, x0 (flat host layout as above) up, factor + solve against the resident
- * A, B, Q, R, the solutions [batch][nvars] down into `soln` (the array ndlqr_CopyBatchSolutions fills). Consecutive
+ * A, B, Q, R, the solutions [batch][nvars] down into `soln` (the array ndlqr_CopyBatchSolutions fills); q, r, d may each
+ * be NULL (kept as ndlqr_InitializeBatch* / ndlqr_BatchSetRhsFlat left them: an MPC iteration often replaces x0 alone;
+ * do not mix with steps that pass them -- those replace them in one of the two buffer sets only). Consecutive
  * steps alternate between the two buffer sets of the solve pipeline, so the transfers of one step run beside the
  * kernels of the other; `soln` of a step is complete after ndlqr_BatchSynchronize, or -- one step behind --
  * ndlqr_BatchSynchronizePrevious. Host arrays from ndlqr_HostAlloc (pinned) keep the copies asynchronous;

@@ -86,7 +86,10 @@ double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
 /* One MPC step, asynchronous: a new right-hand side up (flat host arrays in the reference's layout: q, d
  * [batch][N][n], r [batch][N][m], x0 [batch][n] -- what ndlqr_InitializeWithLQRProblem reads from the problem,
  * src/solver.c:141-190), packed and negated by a kernel, factor + solve, the solutions [batch][nvars] (the layout of
- * ndlqr_hip_download_solutions, src/solve.c:192-201) down into `soln`. Everything is ordered on the stream of the
+ * ndlqr_hip_download_solutions, src/solve.c:192-201) down into `soln`. q, r, d may each be NULL: that part of the
+ * right-hand side stays as it is IN THE STEP'S BUFFER SET (an MPC iteration often replaces x0 alone; the two sets
+ * alternate, and ndlqr_hip_upload_inputs / _upload_rhs / _pack_flat_device write both, so set q, r, d with one of those
+ * and then step with x0 alone). Everything is ordered on the stream of the
  * step's buffer set, so with the two-deep pipeline the copies of one step run beside the kernels of the other. Give
  * pinned host memory (ndlqr_hip_host_alloc): copies from / to pageable memory are staged by the runtime and block.
  * `soln` of a step is complete after ndlqr_hip_synchronize (every step) or, one step behind,

@@ -365,12 +365,12 @@ class BatchSolver:
         """ndlqr_BatchStepAsync: new right-hand side up, factor + solve, solutions down into `soln` ([batch, nvars]),
         asynchronously. The arrays must stay alive and untouched until the step has been synchronised (use
         pinned_empty() arrays; pageable ones make the call block)."""
-        for a in (q, r, d, x0, soln):
-            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
         n, m, N, bt = self.n, self.m, self.N, self.batch
-        assert q.size == bt * N * n and d.size == bt * N * n and r.size == bt * N * m and x0.size == bt * n
-        assert soln.size == bt * self.nvars
-        return self.L.ndlqr_BatchStepAsync(self.h, _ptr(q), _ptr(r), _ptr(d), _ptr(x0), _ptr(soln))
+        for a, size in ((q, bt * N * n), (r, bt * N * m), (d, bt * N * n), (x0, bt * n), (soln, bt * self.nvars)):
+            assert a is None or (a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.size == size)
+        assert x0 is not None and soln is not None  # q, r, d may be None: unchanged
+        ptr = lambda a: None if a is None else _ptr(a)
+        return self.L.ndlqr_BatchStepAsync(self.h, ptr(q), ptr(r), ptr(d), ptr(x0), ptr(soln))
 
     def synchronize_previous(self):
         return self.L.ndlqr_BatchSynchronizePrevious(self.h)

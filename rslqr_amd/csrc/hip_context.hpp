@@ -98,6 +98,8 @@ struct NdlqrHipCtx {
   const char* graph_schedule;  // and its name
   int sep_threads;    // NDLQR_SEP_THREADS: workgroup size of the matrix-core separator (0 = by block size)
   hipEvent_t ev_start, ev_stop;
+  hipEvent_t ev_step[2];  // end of the steps of ndlqr_hip_step_async, alternating (ndlqr_hip_synchronize_previous)
+  unsigned step_count;
   hipEvent_t ev_inputs;  // orders the other buffer set's stream behind a device-side replacement of the inputs
   bool timing_pending;
   double last_ms;

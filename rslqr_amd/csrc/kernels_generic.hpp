@@ -360,6 +360,55 @@ static __global__ void pack_rhs_flat_generic(Dims d, const double* __restrict__ 
   }
 }
 
+// The same as a STREAMING kernel: few workgroups (the launch is resident at once, so that kernels of the other buffer
+// set's stream run beside it), grid-stride, four independent loads in flight per thread -- made to read q, r, d, x0
+// straight from PINNED HOST memory over the host link (no staging copy; a copy engine transfer in both directions on
+// one stream serialises the two-deep step pipeline on this platform, tools/ubench/copy_overlap.hip). Any of q / r / d
+// may be null: that part of the right-hand side stays as it is (an MPC iteration often replaces x0 alone).
+__device__ __forceinline__ void pack_rhs_one(const Dims& d, const int which, const size_t g, const double v,
+                                             double* __restrict__ rhs) {
+  const size_t n = d.n, m = d.m, rows = d.rows, N = d.N;
+  if (which == 0) {         // q
+    const size_t pk = g / n, e = g - pk * n;
+    rhs[pk * rows + n + e] = -v;
+  } else if (which == 1) {  // r (the last knot's input slot stays 0)
+    const size_t pk = g / m, e = g - pk * m;
+    rhs[pk * rows + 2 * n + e] = (pk % N) < N - 1 ? -v : 0.0;
+  } else if (which == 2) {  // d_k is the lambda block of knot k + 1
+    const size_t pk = g / n, e = g - pk * n;
+    if ((pk % N) < N - 1) rhs[(pk + 1) * rows + e] = -v;
+  } else {                  // x0: the lambda block of knot 0
+    const size_t b = g / n, e = g - b * n;
+    rhs[b * N * rows + e] = -v;
+  }
+}
+
+static __global__ __launch_bounds__(256) void pack_rhs_stream_generic(Dims d, const double* __restrict__ q,
+                                                                      const double* __restrict__ r,
+                                                                      const double* __restrict__ dd,
+                                                                      const double* __restrict__ x0,
+                                                                      double* __restrict__ rhs) {
+  const size_t nq = (size_t)d.batch * d.N * d.n, nr = (size_t)d.batch * d.N * d.m, nx = (size_t)d.batch * d.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double* src[4] = {q, r, dd, x0};
+  const size_t cnt[4] = {nq, nr, nq, nx};
+#pragma unroll
+  for (int which = 0; which < 4; ++which) {
+    const double* p = src[which];
+    if (!p) continue;
+    const size_t n = cnt[which];
+    size_t i = t0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+      const double a = p[i], b = p[i + stride], c = p[i + 2 * stride], e = p[i + 3 * stride];
+      pack_rhs_one(d, which, i, a, rhs);
+      pack_rhs_one(d, which, i + stride, b, rhs);
+      pack_rhs_one(d, which, i + 2 * stride, c, rhs);
+      pack_rhs_one(d, which, i + 3 * stride, e, rhs);
+    }
+    for (; i < n; i += stride) pack_rhs_one(d, which, i, p[i], rhs);
+  }
+}
+
 // Solutions [batch][N][2n+m] (the unused trailing u_N slot included) -> [batch][nvars] packed, the
 // layout of ndlqr_CopyBatchSolutions, in device memory. grid (N, batch).
 static __global__ void pack_solutions_generic(Dims d, const double* __restrict__ z, double* __restrict__ dst) {

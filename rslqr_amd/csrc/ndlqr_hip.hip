@@ -85,7 +85,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
   c->pipeline = getenv("NDLQR_PIPELINE") ? atoi(getenv("NDLQR_PIPELINE")) : 2;
   c->solve_count = 0; c->in_alt = false; c->z_latest = nullptr; c->stream_latest = nullptr; c->h_fail_other = nullptr;
-  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->xfer = nullptr; c->h_stage[0] = c->h_stage[1] = nullptr; c->ev_inputs = nullptr; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false; c->graph_schedule = "none";
+  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->xfer = nullptr; c->h_stage[0] = c->h_stage[1] = nullptr; c->ev_inputs = nullptr; c->ev_step[0] = c->ev_step[1] = nullptr; c->step_count = 0; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false; c->graph_schedule = "none";
 
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->rowbcast = getenv("NDLQR_ROWBCAST") ? (atoi(getenv("NDLQR_ROWBCAST")) != 0 ? 1 : 0) : -1;  // -1: by block size
@@ -98,6 +98,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_step[0], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_step[1], hipEventDisableTiming) == hipSuccess &&
             hipMalloc(&c->AB, bytes_AB(d)) == hipSuccess && hipMalloc(&c->QR, bytes_QR(d)) == hipSuccess &&
             hipMalloc(&c->rhs, bytes_z(d)) == hipSuccess && hipMalloc(&c->z, bytes_z(d)) == hipSuccess &&
             hipMalloc(&c->rec, bytes_rec(d)) == hipSuccess &&
@@ -144,6 +146,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->wfac); (void)hipFree(c->xfer);
   for (double* h : c->h_stage) if (h) (void)hipHostFree(h);
   if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
+  for (hipEvent_t ev : c->ev_step) if (ev) (void)hipEventDestroy(ev);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -188,7 +191,14 @@ static bool ensure_alt(NdlqrHipCtx* c) {
   const size_t slot_doubles = (4 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
   const size_t red_bytes = sizeof(double) * (size_t)d.batch * (d.N / 4) * slot_doubles;
   const size_t cnt_bytes = sizeof(int) * (size_t)d.batch * (d.N / 4);
-  bool ok = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess &&
+  // The second set's stream gets another priority than the first's: streams of one priority share a few hardware
+  // queues round-robin with every other stream of the process, and two streams on ONE hardware queue run strictly one
+  // after the other (measured: the step pipeline lost all its overlap in a process that had created other streams
+  // before, tools/e2e_probe.py --other-solvers; with its own priority level it keeps it).
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const int alt_prio = getenv("NDLQR_ALT_PRIORITY") ? atoi(getenv("NDLQR_ALT_PRIORITY")) : prio_greatest;
+  bool ok = hipStreamCreateWithPriority(&a.stream, hipStreamNonBlocking, alt_prio) == hipSuccess &&
             hipEventCreate(&a.ev_start) == hipSuccess && hipEventCreate(&a.ev_stop) == hipSuccess &&
             hipMalloc(&a.rec, bytes_rec(d)) == hipSuccess && hipMalloc(&a.z, bytes_z(d)) == hipSuccess &&
             hipMalloc(&a.rhs, bytes_z(d)) == hipSuccess &&
@@ -794,46 +804,68 @@ static int ensure_xfer(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
+// device-side address of `p` when it is pinned host memory (hipHostMalloc / hipHostRegister), else null
+static const double* pinned_device_view(const double* p) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (a.type != hipMemoryTypeHost) return nullptr;
+  void* dv = nullptr;
+  if (hipHostGetDevicePointer(&dv, const_cast<double*>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return static_cast<const double*>(dv);
+}
+
 int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const double* dd, const double* x0,
                          double* soln) {
-  if (!c || !q || !r || !dd || !x0 || !soln) return NDLQR_ERR_INVALID;
+  if (!c || !x0 || !soln) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
-  bool pipelined = false;
-  int err = prepare_solve(c, &pipelined);
+  int err = prepare_solve(c, nullptr);
   if (err) return err;
   err = ensure_xfer(c);  // (before anything is captured: allocation is not a stream operation)
   if (err) return err;
-  // everything of this step is ordered on the stream of its buffer set: the copies of one step overlap the kernels of
-  // the other set's step. Without the pipeline (factor array / records kept, caller-owned stream, depth 1) the steps
-  // are simply stream-ordered.
-  (void)pipelined;
+  // Everything of this step is ordered on the stream of its buffer set. Right-hand side: a streaming kernel reads
+  // pinned host arrays over the host link directly; pageable ones go through the staging first (the runtime stages
+  // those copies itself and blocks). Solutions: pack kernel, then ONE copy-engine transfer. With the two-deep
+  // pipeline the transfers of one step run beside the kernels of the other set's step; otherwise (factor array /
+  // records kept, caller-owned stream, depth 1) the steps are simply stream-ordered.
   hipStream_t st = c->stream;
   HIP_TRY(hipEventRecord(c->ev_start, st));
   const size_t nq = (size_t)d.batch * d.N * d.n, nr = (size_t)d.batch * d.N * d.m, nx = (size_t)d.batch * d.n;
-  double* fq = c->xfer; double* fr = fq + nq; double* fd = fr + nr; double* fx = fd + nq;
-  HIP_TRY(hipMemcpyAsync(fq, q, sizeof(double) * nq, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(fr, r, sizeof(double) * nr, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(fd, dd, sizeof(double) * nq, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(fx, x0, sizeof(double) * nx, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(ndlqr::pack_rhs_flat_generic, dim3(d.N, d.batch), dim3(64), 0, st, d, fq, fr, fd, fx, c->rhs);
+  const double* src[4] = {q, r, dd, x0};
+  const size_t cnt[4] = {nq, nr, nq, nx};
+  const double* view[4];
+  double* stage = c->xfer;
+  for (int k = 0; k < 4; ++k) {
+    view[k] = pinned_device_view(src[k]);
+    if (src[k] && !view[k]) {
+      HIP_TRY(hipMemcpyAsync(stage, src[k], sizeof(double) * cnt[k], hipMemcpyHostToDevice, st));
+      view[k] = stage;
+    }
+    stage += cnt[k];
+  }
+  hipLaunchKernelGGL(ndlqr::pack_rhs_stream_generic, dim3(512), dim3(256), 0, st, d, view[0], view[1], view[2], view[3],
+                     c->rhs);
   HIP_TRY(hipGetLastError());
   err = launch_solve(c);
   if (err) return err;
-  // the flat right-hand side has been consumed by the pack kernel: the staging now takes the packed solutions
+  // (the staging has been consumed by the pack kernel: it now takes the packed solutions)
   hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, d, c->z, c->xfer);
   HIP_TRY(hipGetLastError());
   const size_t nvars = (size_t)d.rows * d.N - d.m;
   HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * nvars * d.batch, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(c->ev_stop, st));
+  HIP_TRY(hipEventRecord(c->ev_step[c->step_count & 1u], st));
+  ++c->step_count;
   c->timing_pending = true;
   c->state_dirty = false;
   return NDLQR_OK;
 }
 
+// the step before the most recent one is complete (its `soln` may be read) -- whichever stream it ran on
 int ndlqr_hip_synchronize_previous(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
-  if (c->alt.stream) HIP_TRY(hipStreamSynchronize(c->alt.stream));  // (the set that is not current holds the older step)
+  if (c->step_count >= 2) HIP_TRY(hipEventSynchronize(c->ev_step[c->step_count & 1u]));  // step_count - 2
   return NDLQR_OK;
 }
 

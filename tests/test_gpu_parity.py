@@ -715,6 +715,18 @@ def test_step_async_transfers_and_solves(ndlqr, oracle, n, m, N, batch, flags):
     prob = Problem(n, m, N, *[flat[k][0] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
     ref = oracle.solve(prob, 1)[0][: prob.nvars]
     assert np.linalg.norm(bs.solution(0) - ref) / np.linalg.norm(ref) <= REL_TOL
+    # MPC steps that replace x0 alone (q, r, d: what set_rhs_flat left in both buffer sets), two in flight
+    xs = [ndlqr.pinned_empty(flat["x0"].shape) for _ in range(3)]
+    for s, x in enumerate(xs):
+        x[...] = flat["x0"] + (s + 1.0)
+        assert bs.step_async(None, None, None, x, outs[s]) == 0
+    assert bs.synchronize() == 0
+    for s, x in enumerate(xs):
+        p = batch - 1
+        prob = Problem(n, m, N, flat["A"][p], flat["B"][p], flat["Q"][p], flat["R"][p], flat["q"][p], flat["r"][p],
+                       flat["d"][p], x[p])
+        ref = oracle.solve(prob, 1)[0][: prob.nvars]
+        assert np.linalg.norm(outs[s][p] - ref) / np.linalg.norm(ref) <= REL_TOL, s
     bs.close()
 
 
