@@ -65,12 +65,51 @@ template <int NX> __device__ __forceinline__ constexpr bool rows_none_v(int g) {
 // c: [S-bar | b~] tile (column NX = rhs). ra / rb: B-operand fragments of r_a / r_bb, i.e.
 // ra[q] = r_a(4 q + lk, li) (any finite value outside the block). On return X0 = [f_a | z_sep],
 // X1 = [f_bb] in accumulator layout. hook(R0, R1, X0, X1) sees the panel fragments and the solution.
+// Second half of the core: everything behind the Cholesky. Wm: W = L^-1 in LDS (row pitch McScratch::WP, zero outside
+// the leading NX x NX block). c: the separator's [S-bar | b~] tile (only its rhs column NX is read here).
+template <int NX, class Hook>
+__device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
+                                               const double (&rb)[(NX + 3) / 4], const double* Wm, acc4_t& X0,
+                                               acc4_t& X1, Hook hook, double* sinv_store) {
+  constexpr int KS = (NX + 3) / 4, WP = McScratch<NX>::WP;
+  int lane_o = lane;  // (opaque: the lane predicates of one core are recomputed, not kept in scalar registers)
+  asm volatile("" : "+v"(lane_o));
+  const int li = lane_o & 15, lk = lane_o >> 4;
+  // S-bar^-1 = W'W as one tile; being symmetric, its accumulator components are at once its
+  // A-operand fragments: X = S-bar^-1 [r_a | b~ | r_bb] needs no further data movement
+  double wt[KS], b0[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    wt[q] = Wm[(4 * q + lk) * WP + li];  // W(k, li): A operand of W'(i, k) and B operand of W(k, j)
+    // columns beyond the blocks carry finite don't-cares: they only reach tile elements nobody reads
+    b0[q] = li == NX ? c[q] : ra[q];
+  }
+  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+  acc4_t Si = zero;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) Si = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], wt[q], Si, 0, 0, 0);
+  if (sinv_store) {  // compact level-0 record: S-bar^-1, lower triangle packed (entry (r, c), c <= r, at r (r + 1) / 2 + c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = lk + 4 * g;
+      if (!rows_none_v<NX>(g) && r < NX && li <= r) sinv_store[r * (r + 1) / 2 + li] = Si[g];
+    }
+  }
+  X0 = zero; X1 = zero;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], b0[q], X0, 0, 0, 0);
+    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], rb[q], X1, 0, 0, 0);
+  }
+  hook(b0, rb, X0, X1);
+}
+
 template <int NX, class Hook>
 __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
                                                 const double (&rb)[(NX + 3) / 4], McScratch<NX>& m,
                                                 double* lstore, acc4_t& X0, acc4_t& X1, Hook hook,
                                                 double* sinv_store = nullptr) {
-  constexpr int KS = (NX + 3) / 4, SP = McScratch<NX>::SP, WP = McScratch<NX>::WP;
+  constexpr int SP = McScratch<NX>::SP, WP = McScratch<NX>::WP;
   // the lane id is made opaque here so that the lane predicates of one core are recomputed (one
   // v_cmp) instead of being kept in scalar registers across the whole kernel (spills)
   int lane = lane_in;
@@ -109,36 +148,69 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
   }
   if (lstore && lane < NX) store_row<NX>(lstore + li * NX, acc);
   wave_lds_sync();
-  // S-bar^-1 = W'W as one tile; being symmetric, its accumulator components are at once its
-  // A-operand fragments: X = S-bar^-1 [r_a | b~ | r_bb] needs no further data movement
-  double wt[KS], b0[KS];
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    wt[q] = m.W[(4 * q + lk) * WP + li];  // W(k, li): A operand of W'(i, k) and B operand of W(k, j)
-    // columns beyond the blocks carry finite don't-cares: they only reach tile elements nobody reads
-    b0[q] = li == NX ? c[q] : ra[q];
-  }
-  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-  acc4_t Si = zero;
-#pragma unroll
-  for (int q = 0; q < KS; ++q) Si = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], wt[q], Si, 0, 0, 0);
   SEG(31);
-  if (sinv_store) {  // compact level-0 record: S-bar^-1, lower triangle packed (entry (r, c), c <= r, at r (r + 1) / 2 + c)
+  factor_tail_mc<NX>(lane, c, ra, rb, m.W, X0, X1, hook, sinv_store);
+  SEG(33);
+  return bad;
+}
+
+// The Cholesky + inverse of TWO independent separators in one pass: DPP rows 0-1 (lanes 0..31) work on tile cA,
+// rows 2-3 on cB -- the row-broadcast recurrence (rb_chol_inv) is per 16-lane row, and with one separator all four
+// rows repeat the same work. bottom_reduced_mc eliminates its two level-0 separators this way: two passes per
+// four-knot group instead of three (132 DPP FMAs, 12 pivots and their hazard fences per wavefront less).
+// LDS: buf[0, 288) S-bar tile A, [288, 576) tile B, [576, 848) W_A; W_B lies over tile A (read before it is written).
+// Returns per lane: the separator of this lane's DPP row had a non-positive pivot.
+template <int NX>
+struct McPairLayout {
+  static constexpr int SP = McScratch<NX>::SP, WP = McScratch<NX>::WP;
+  static constexpr int SCR_A = 0, SCR_B = 16 * SP, W_A = 32 * SP, W_B = 0, SIZE = 32 * SP + 16 * WP;
+  static_assert(16 * WP <= 16 * SP, "W_B fits over the S-bar tile of A");
+};
+template <int NX>
+__device__ __forceinline__ bool chol_pair_mc(const int lane_in, const acc4_t& cA, const acc4_t& cB, double* buf,
+                                             double* lstoreA, double* lstoreB) {
+  using P = McPairLayout<NX>;
+  constexpr int SP = P::SP, WP = P::WP;
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  const int li = lane & 15, lk = lane >> 4;
+  const int ri = li < NX ? li : NX - 1;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int r = lk + 4 * g;
-      if (!rows_none_v<NX>(g) && r < NX && li <= r) sinv_store[r * (r + 1) / 2 + li] = Si[g];
+  for (int g = 0; g < 4; ++g) {
+    buf[P::SCR_A + (lk + 4 * g) * SP + li] = cA[g];
+    buf[P::SCR_B + (lk + 4 * g) * SP + li] = cB[g];
+  }
+  wave_lds_sync();
+  const double* mine = buf + (lk < 2 ? P::SCR_A : P::SCR_B) + ri * SP;
+  double acc[NX], w[NX];
+  if constexpr (NX % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < NX; j += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(&mine[j]);
+      acc[j] = t.x; acc[j + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = mine[j];
+  }
+  const bool bad = rb_chol_inv<NX>(li, acc, w);
+  wave_lds_sync();  // (every lane has its row of S-bar: W_B may overwrite tile A)
+  {  // DPP row 0 stores W_A, row 2 W_B (column = lane of the row); rows 1 and 3 zero the pad column of theirs;
+     // unconditional stores (see factor_solve_mc)
+    double* wdst = buf + (lk < 2 ? P::W_A : P::W_B) + ((lk & 1) ? 16 : li);
+    const bool owner = (lk & 1) == 0;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) wdst[r * WP] = owner ? w[r] : 0.0;
+    // rows NX..15 of both: zero (the tiles that lay here were not)
+#pragma unroll
+    for (int e0 = 0; e0 < (16 - NX) * WP; e0 += 32) {
+      const int e = e0 + (lane & 31);
+      if (e < (16 - NX) * WP) buf[(lk < 2 ? P::W_A : P::W_B) + NX * WP + e] = 0.0;
     }
   }
-  X0 = zero; X1 = zero;
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], b0[q], X0, 0, 0, 0);
-    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], rb[q], X1, 0, 0, 0);
-  }
-  SEG(32);
-  hook(b0, rb, X0, X1);
-  SEG(33);
+  if (lstoreA && lane < NX) store_row<NX>(lstoreA + li * NX, acc);
+  if (lstoreB && lane >= 32 && lane < 32 + NX) store_row<NX>(lstoreB + li * NX, acc);
+  wave_lds_sync();
   return bad;
 }
 
@@ -332,7 +404,9 @@ struct alignas(16) ReducedLds {
   static constexpr int W = NX + NU, ROWS = 2 * NX + NU, WP = (W % 2 == 0) ? W + 2 : W;
   static constexpr int SLOT = RedSlot<NX>::SIZE, NSC = (int)(sizeof(McScratch<NX>) / 8);
   static constexpr int NB0 = 4 * NX * WP, NB1 = SLOT + NX * WP;
-  static constexpr int NBUF = (NB0 > NB1 ? NB0 : NB1) > NSC ? (NB0 > NB1 ? NB0 : NB1) : NSC;
+  static constexpr int NB2 = McPairLayout<NX>::SIZE;  // the paired Cholesky of the bottom levels
+  static constexpr int NB01 = (NB0 > NB1 ? NB0 : NB1) > NSC ? (NB0 > NB1 ? NB0 : NB1) : NSC;
+  static constexpr int NBUF = NB01 > NB2 ? NB01 : NB2;
   double buf[NBUF];
   double rq[4 * W];
   double rh[4 * ROWS];
@@ -583,41 +657,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
     rb2[q] = hasB ? -b2 * s3 : 0.0;
   }
   wave_lds_sync();  // last read of the staged [A | B]
-  m.init(lane);
   SEG(21);
 
   acc4_t X0, X1, unused;
   double* myrec = rec + ((size_t)b * N + k0) * REC;
 
-  // ---- s0 = k0 (level 0, left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
-  acc4_t park_a, ca_t;
-  if (factor_solve_mc<NX>(lane, c_s0, ra0, rb0, m, store_l ? Fblk(F, d, b, 0, k0 + 1) : nullptr, X0, X1,
-                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-                            acc4_t g11;
-                            gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
-                          }, compact0 ? myrec : nullptr) &&
-      lane == 0)
+  // ---- Cholesky + inverse of the two level-0 separators s0 = k0 and s2 = k0 + 2 in ONE pass (DPP rows 0-1 / 2-3)
+  using Pair = McPairLayout<NX>;
+  if (chol_pair_mc<NX>(lane, c_s0, c_s2, lds.buf, store_l ? Fblk(F, d, b, 0, k0 + 1) : nullptr,
+                       store_l ? Fblk(F, d, b, 0, k0 + 3) : nullptr) &&
+      (lane == 0 || lane == 32))
     flag_failure(info, d, b);
+  SEG(30);
+
+  // ---- s0 (left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
+  acc4_t park_a, ca_t;
+  factor_tail_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, X0, X1,
+                     [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+                       acc4_t g11;
+                       gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
+#pragma unroll
+                       for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
+                     }, compact0 ? myrec : nullptr);
   SEG(34);  // re-arms the clock after the core's own marks
   if (!compact0) store_record_mc<NX>(myrec, lane, hasA, true, X0, X1);
   SEG(35);
 
-  // ---- s2 = k0 + 2 (level 0, right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
+  // ---- s2 (right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
   acc4_t park_b11, cb_t;
-  if (factor_solve_mc<NX>(lane, c_s2, ra2, rb2, m, store_l ? Fblk(F, d, b, 0, k0 + 3) : nullptr, X0, X1,
-                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-                            acc4_t g00;
-                            gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
+  factor_tail_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, X0, X1,
+                     [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+                       acc4_t g00;
+                       gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
-                          }, compact0 ? myrec + 2 * REC : nullptr) &&
-      lane == 0)
-    flag_failure(info, d, b);
+                       for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
+                     }, compact0 ? myrec + 2 * REC : nullptr);
   SEG(34);
   if (!compact0) store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
   SEG(35);
+  m.init(lane);  // the scratch of t: the pair's tiles lay over the zero rows of its W
 
   // ---- t = k0 + 1 (level 1): r_a = -CA[t] = -Y_bb'Y_a of s0, r_bb = -CB[t] = -Y_a'Y_bb of s2;
   //      pushes of the whole group to the separators k0 - 1 (A) and k0 + 3 (B)

@@ -21,7 +21,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("gpurun_out/${tag}_sq_*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][:60]
+        k = row["Kernel_Name"].split("(")[0][:60] + "  grid " + row.get("Grid_Size", "?")  # (per tree level)
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open("gpurun_out/${tag}_sq_summary.txt", "w") as out:
     for k, cs in acc.items():
