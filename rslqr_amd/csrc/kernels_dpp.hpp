@@ -64,31 +64,49 @@ __device__ __forceinline__ void dpp_fence(double (&x)[N]) {
 
 // ------------------------------------------------------------------------------------- Cholesky + inverse
 // Lane i: row i of S-bar in acc. On return acc = row i of the Cholesky factor L (entries above the
-// diagonal: leftovers), w = COLUMN i of W = L^-1 (w[k] = W(k, i), zero for k < i). Left-looking, fused
-// with the forward substitution of the unit vectors; step j takes row j of L from lane j inside the
-// FMAs. Returns true when a pivot was not positive (NaNs propagate to the last pivot).
+// diagonal: leftovers), w = COLUMN i of W = L^-1 (w[k] = W(k, i), zero for k < i). Fused with the forward
+// substitution of the unit vectors. Returns true when a pivot was not positive (NaNs propagate to the last pivot).
+//
+// RIGHT-looking, software-pipelined (round 3): once column j is scaled, every later column c takes its update
+//     acc[c] -= L(c, j) L(i, j)      w[c] -= L(c, j) W(j, i)          (L(c, j): lane c's acc[j], inside the FMA)
+// independently of the others, and the next pivot only waits for the update of column j + 1. So the pivot chain of
+// step j + 1 (broadcast, v_rsq_f64, Newton step: ~10 dependent instructions) is started right behind that one
+// update and runs under the remaining 2 (NX - j - 2) updates of step j. The left-looking form it replaces had, per
+// step, a chain of j dependent FMAs in front of the pivot chain: the kernels that use this are bound by the
+// dependent-instruction latency of a wavefront at 3-4 wavefronts per SIMD, not by issue slots. Every element still
+// receives the same products in the same order (k ascending): results are bit-identical to the left-looking form.
 template <int NX>
 __device__ __forceinline__ bool rb_chol_inv(const int i, double (&acc)[NX], double (&w)[NX]) {
   bool bad = false;
-  sfor<NX>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    double v = acc[j], sacc = (j == i) ? 1.0 : 0.0;
-    sfor<j>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      fnmac_bc<j>(v, acc[k], acc[k]);   // v    -= L(j, k) L(i, k)
-      fnmac_bc<j>(sacc, acc[k], w[k]);  // sacc -= L(j, k) W(k, i)
-    });
-    dpp_fence(v);  // v was written by the instruction before last
-    const double pivot = row_bc<j>(v);
-    // 1 / sqrt(pivot): hardware estimate + one Newton step (a few ulp; see factor_solve_mc)
+#pragma unroll
+  for (int k = 0; k < NX; ++k) w[k] = (k == i) ? 1.0 : 0.0;
+  // 1 / sqrt(pivot): hardware estimate + one Newton step (a few ulp; see factor_solve_mc)
+  auto rsqrt_newton = [](const double pivot) {
     const double y0 = __builtin_amdgcn_rsq(pivot);
     const double e = fma(-pivot * y0, y0, 1.0);
-    const double rinv = fma(y0 * e, 0.5, y0);
+    return fma(y0 * e, 0.5, y0);
+  };
+  dpp_fence(acc[0]);
+  double rinv = rsqrt_newton(row_bc<0>(acc[0]));
+  sfor<NX>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     if constexpr (j == NX - 1) bad = !((rinv > 0.0) & (rinv < 1.0e300));
-    acc[j] = v * rinv;
-    w[j] = sacc * rinv;
+    acc[j] = acc[j] * rinv;  // L(i, j)
+    w[j] = w[j] * rinv;      // W(j, i)
     asm volatile("" : "+v"(w[j]));
-    dpp_fence(acc[j]);  // both are broadcast from this lane by the steps that follow
+    dpp_fence(acc[j]);  // broadcast from other lanes by everything that follows
+    if constexpr (j + 1 < NX) {
+      fnmac_bc<j + 1>(acc[j + 1], acc[j], acc[j]);
+      fnmac_bc<j + 1>(w[j + 1], acc[j], w[j]);
+      dpp_fence(acc[j + 1]);  // complete: the pivot of the next step
+      const double rnext = rsqrt_newton(row_bc<j + 1>(acc[j + 1]));
+      sfor<NX - j - 2>([&](auto cc) {
+        constexpr int c = j + 2 + decltype(cc)::value;
+        fnmac_bc<c>(acc[c], acc[j], acc[j]);  // acc[c] -= L(c, j) L(i, j)
+        fnmac_bc<c>(w[c], acc[j], w[j]);      // w[c]   -= L(c, j) W(j, i)
+      });
+      rinv = rnext;
+    }
   });
   return bad;
 }
