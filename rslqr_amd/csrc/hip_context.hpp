@@ -92,7 +92,6 @@ struct NdlqrHipCtx {
   double* kkt_out;  // [2 batch] scratch of ndlqr_hip_kkt_residual (allocated on first use)
   double* xfer;     // transfer staging of the current buffer set (see NdlqrAltSlot::xfer; allocated on first use)
   double* h_stage[2];  // pinned bounce buffers of the downloads into pageable host memory (allocated on first use)
-  bool no_pair;       // NDLQR_NO_PAIR=1: upper levels one separator per wavefront (A/B timing of reduced_level_pair_mc)
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
   bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)

@@ -539,148 +539,6 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
   SEG(12);
 }
 
-// ---- two adjacent separators of an upper level per wavefront: ONE round of loads for both, ONE pass of the
-//      row-broadcast Cholesky + inverse for both (DPP rows 0-1 / 2-3, chol_pair_mc), then the matrix-core tails one
-//      after the other. Same arithmetic per separator as reduced_separator_mc; 21 % fewer vector instructions per
-//      separator and two separators' loads in flight per wavefront. Level-per-launch schedule only (plain
-//      read-modify-write pushes: one writer per accumulator block and launch).
-struct AddPlainLate { __device__ __forceinline__ void operator()(double* p, double v, double) const { *p = *p + v; } };
-
-template <int NX, int NU>
-struct alignas(16) ReducedPairLds {
-  static constexpr int W = NX + NU, WP = ReducedLds<NX, NU>::WP, SLOT = RedSlot<NX>::SIZE;
-  static constexpr int PER = (SLOT + NX * WP + 1) / 2 * 2;  // slot | [A_s | B_s] of one separator, 16-byte granules
-  static constexpr int NQ = W + NX, NR = NX + W + 2 * NX;
-  static constexpr int NBUF = 2 * PER > McPairLayout<NX>::SIZE ? 2 * PER : McPairLayout<NX>::SIZE;
-  double buf[NBUF];
-  double rq[2][(NQ + 1) / 2 * 2];
-  double zs[2][(NR + 1) / 2 * 2];
-};
-
-template <int NX, int NU>
-__device__ __forceinline__ void reduced_pair_mc(const Dims& d, const int l, const int base0, const int b,
-                                                const int lane, const double* __restrict__ AB,
-                                                const double* __restrict__ QR, const double* __restrict__ rhs,
-                                                double* red, double* __restrict__ rec, double* F,
-                                                int* __restrict__ info, const int store_l,
-                                                ReducedPairLds<NX, NU>& lds) {
-  using L = ReducedPairLds<NX, NU>;
-  constexpr int W = NX + NU, NN = NX * NX, KSN = (NX + 3) / 4, WP = L::WP, SLOT = L::SLOT, PER = L::PER;
-  const int N = d.N, T = 2 << l;
-  const int li = lane & 15, lk = lane >> 4;
-  const int ri = li < NX ? li : NX - 1;
-  // ---- one round of coalesced loads for both separators (knots s, s + 1 of a level >= 2 are never the first or
-  //      the last knot), every load issued before the first LDS store
-  {
-    constexpr int NS = SLOT / 2, IS = (NS + 63) / 64, NA = NX * W, IA = (NA + 63) / 64;
-    constexpr int NQ = L::NQ, IQ = (NQ + 63) / 64, NR = L::NR, IR = (NR + 63) / 64;
-    double2 ts[2][IS];
-    double ta[2][IA], tq[2][IQ], tr[2][IR];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      const int s = base0 + x * T + (T >> 1) - 1;
-      const double* sl = red_slot<NX>(red, d, b, s).p;
-      const double* abm = AB + ((size_t)b * N + s) * NX * W;
-      const double* qr = QR + ((size_t)b * N + s) * W;
-      const double* r0 = rhs + ((size_t)b * N + s) * (2 * NX + NU);
-#pragma unroll
-      for (int it = 0; it < IS; ++it) {
-        const int e = lane + 64 * it;
-        ts[x][it] = reinterpret_cast<const double2*>(sl)[e < NS ? e : NS - 1];
-      }
-#pragma unroll
-      for (int it = 0; it < IA; ++it) { const int e = lane + 64 * it; ta[x][it] = abm[e < NA ? e : NA - 1]; }
-#pragma unroll
-      for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; tq[x][it] = qr[e < NQ ? e : NQ - 1]; }
-#pragma unroll
-      for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; tr[x][it] = r0[e < NR ? e : NR - 1]; }
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {  // unconditional stores on the clamped indices (see reduced_separator_mc)
-      double* slot = lds.buf + x * PER;
-      double* abs_ = slot + SLOT;
-#pragma unroll
-      for (int it = 0; it < IS; ++it) {
-        const int e = lane + 64 * it;
-        reinterpret_cast<double2*>(slot)[e < NS ? e : NS - 1] = ts[x][it];
-      }
-#pragma unroll
-      for (int it = 0; it < IA; ++it) {
-        const int e = lane + 64 * it, ec = e < NA ? e : NA - 1, row = ec / W, c = ec - row * W;
-        abs_[row * WP + c] = ta[x][it];
-      }
-#pragma unroll
-      for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; lds.rq[x][e < NQ ? e : NQ - 1] = 1.0 / tq[x][it]; }
-#pragma unroll
-      for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; lds.zs[x][e < NR ? e : NR - 1] = tr[x][it]; }
-    }
-  }
-  wave_lds_sync();
-
-  // ---- [S-bar | b~] = leaf tile - DL - DR | - gL - gR and the coupling fragments r_a = -CA, r_bb = -CB of both
-  double ra[2][KSN], rb[2][KSN];
-  acc4_t c0[2];
-  bool hasA[2], hasB[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const int base = base0 + x * T;
-    hasA[x] = base > 0; hasB[x] = base + T < N;
-    const double* slot = lds.buf + x * PER;
-    const double *DL = slot, *DR = slot + NN, *CA = slot + 2 * NN, *CB = slot + 3 * NN;
-    const double *gL = slot + 4 * NN, *gR = slot + 4 * NN + NX;
-#pragma unroll
-    for (int q = 0; q < KSN; ++q) {
-      const int kq = 4 * q + lk, i = kq < NX ? kq : NX - 1;
-      const double ca = CA[i * NX + ri], cb = CB[i * NX + ri];
-      ra[x][q] = hasA[x] ? -ca : 0.0;
-      rb[x][q] = hasB[x] ? -cb : 0.0;
-    }
-    c0[x] = leaf_tile_mc<NX, NU, WP>(lane, false, slot + SLOT, lds.rq[x], lds.rq[x] + W, lds.zs[x], lds.zs[x] + NX + W,
-                                     [&](int g) {
-                                       const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
-                                       const double dd = DL[ic * NX + ri] + DR[ic * NX + ri], gg = gL[ic] + gR[ic];
-                                       return -(li == NX ? gg : dd);
-                                     });
-  }
-  wave_lds_sync();  // last read of the staged operands: the scratch of the paired Cholesky lies over them
-
-  const int sA = base0 + (T >> 1) - 1, sB = sA + T;
-  if (chol_pair_mc<NX>(lane, c0[0], c0[1], lds.buf, store_l ? Fblk(F, d, b, l, sA + 1) : nullptr,
-                       store_l ? Fblk(F, d, b, l, sB + 1) : nullptr) &&
-      (lane == 0 || lane == 32))
-    flag_failure(info, d, b);
-  using Pair = McPairLayout<NX>;
-  PushOld<NX> pnone;
-  pnone.zero();
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const int base = base0 + x * T, s = x ? sB : sA;
-    const bool leftchild = x == 0;  // (base0 is a multiple of 2 T: the first of the pair is its parent's left child)
-    const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA[x] ? base - 1 : s);
-    const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB[x] ? base + T - 1 : s);
-    acc4_t X0, X1, unused;
-    factor_tail_mc<NX>(lane, c0[x], ra[x], rb[x], lds.buf + (x ? Pair::W_B : Pair::W_A), X0, X1,
-                       [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-                         acc4_t g00, g01, g11;
-                         gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
-                         const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-                         push_mc<NX>(lane, hasA[x], hasB[x], leftchild, sa, sb, g00, g01, g11, zero, zero, zero,
-                                     AddPlainLate(), StorePlain(), pnone);
-                       }, nullptr);
-    store_record_mc<NX>(rec + ((size_t)b * N + s) * (2 * NN + NX), lane, hasA[x], hasB[x], X0, X1);
-  }
-}
-
-//   grid (N >> (l+2), batch), block 64; 2 <= l <= K - 2 (at least two separators on the level).
-template <int NX, int NU>
-__global__ __launch_bounds__(64) void reduced_level_pair_mc(
-    Dims d, int l, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
-    double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l) {
-  __shared__ ReducedPairLds<NX, NU> lds;
-  reduced_pair_mc<NX, NU>(d, l, blockIdx.x * (4 << l), blockIdx.y, threadIdx.x, AB, QR, rhs, red, rec, F, info, store_l,
-                          lds);
-}
-
 //   grid (N >> (l+1), batch), block 64; l >= 2.
 template <int NX, int NU>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void reduced_level_mc(

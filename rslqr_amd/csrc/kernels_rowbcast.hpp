@@ -499,22 +499,35 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
   {
     const double* abm = AB + ((size_t)b * N + first) * NX * W;
     const double* rc0 = recs + ((size_t)b * N + first) * REC;
-    constexpr int NA = KPB * NX * W, IA = (NA + 255) / 256;                  // [A | B]: scalar words (W may be odd)
-    constexpr int N0 = 4 * R0, I0 = (N0 + 255) / 256, N1 = 3 * REC, I1 = (N1 + 255) / 256;
+    // 16-byte loads wherever the pieces are 16-byte granules: the eight knots' [A | B] always (8 NX W doubles from
+    // a tile boundary), the records when NX is even (REC and R0 even)
+    constexpr int NA = KPB * NX * W / 2, IA = (NA + 255) / 256;                // [A | B] in 16-byte words
+    constexpr bool WIDE = NX % 2 == 0 && R0 % 2 == 0;
+    constexpr int G = WIDE ? 2 : 1;                                             // doubles per record load
+    constexpr int N0 = 4 * R0 / G, I0 = (N0 + 255) / 256, N1 = 3 * REC / G, I1 = (N1 + 255) / 256;
     constexpr int NQ = KPB * W, NR = KPB * ROWS;
     static_assert(NQ <= 256 && NR <= 256, "one load per thread for the vectors");
-    double ta[IA], t0[I0], t1[I1];
+    static_assert((KPB * NX * W) % 2 == 0, "eight knots of [A | B] are whole 16-byte words");
+    double2 ta[IA];
+    double t0[I0][G], t1[I1][G];
 #pragma unroll
-    for (int it = 0; it < IA; ++it) { const int e = t + 256 * it; ta[it] = abm[e < NA ? e : NA - 1]; }
+    for (int it = 0; it < IA; ++it) {
+      const int e = t + 256 * it;
+      ta[it] = reinterpret_cast<const double2*>(abm)[e < NA ? e : NA - 1];
+    }
 #pragma unroll
     for (int it = 0; it < I0; ++it) {
-      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / R0, w_ = ec - j * R0;
-      t0[it] = rc0[(size_t)(2 * j) * REC + w_];
+      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / (R0 / G), w_ = ec - j * (R0 / G);
+      const double* src = rc0 + (size_t)(2 * j) * REC + G * w_;
+      if constexpr (WIDE) { const double2 v = *reinterpret_cast<const double2*>(src); t0[it][0] = v.x; t0[it][1] = v.y; }
+      else t0[it][0] = *src;
     }
 #pragma unroll
     for (int it = 0; it < I1; ++it) {
-      const int e = t + 256 * it, ec = e < N1 ? e : N1 - 1, j = ec / REC, w_ = ec - j * REC;
-      t1[it] = rc0[(size_t)(2 * j + 1) * REC + w_];
+      const int e = t + 256 * it, ec = e < N1 ? e : N1 - 1, j = ec / (REC / G), w_ = ec - j * (REC / G);
+      const double* src = rc0 + (size_t)(2 * j + 1) * REC + G * w_;
+      if constexpr (WIDE) { const double2 v = *reinterpret_cast<const double2*>(src); t1[it][0] = v.x; t1[it][1] = v.y; }
+      else t1[it][0] = *src;
     }
     const double tq = QR[((size_t)b * N + first) * W + (t < NQ ? t : NQ - 1)];
     const double tr = rhs[((size_t)b * N + first) * ROWS + (t < NR ? t : NR - 1)];
@@ -525,19 +538,25 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
     }
 #pragma unroll
     for (int it = 0; it < IA; ++it) {
-      const int e = t + 256 * it, ec = e < NA ? e : NA - 1, kn = ec / (NX * W), w_ = ec - kn * NX * W;
-      const int row = w_ / W, c = w_ - row * W;
-      lds.ab[kn][row * WP + c] = ta[it];
+      const int e = t + 256 * it, ec = e < NA ? e : NA - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // (the two doubles of a word may sit in different rows when W is odd)
+        const int ed = 2 * ec + h, kn = ed / (NX * W), w_ = ed - kn * NX * W;
+        const int row = w_ / W, c = w_ - row * W;
+        lds.ab[kn][row * WP + c] = h ? ta[it].y : ta[it].x;
+      }
     }
 #pragma unroll
     for (int it = 0; it < I0; ++it) {
-      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / R0, w_ = ec - j * R0;
-      lds.rec0[j][w_] = t0[it];
+      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / (R0 / G), w_ = ec - j * (R0 / G);
+#pragma unroll
+      for (int h = 0; h < G; ++h) lds.rec0[j][G * w_ + h] = t0[it][h];
     }
 #pragma unroll
     for (int it = 0; it < I1; ++it) {
-      const int e = t + 256 * it, ec = e < N1 ? e : N1 - 1, j = ec / REC, w_ = ec - j * REC;
-      lds.rec1[j][w_] = t1[it];
+      const int e = t + 256 * it, ec = e < N1 ? e : N1 - 1, j = ec / (REC / G), w_ = ec - j * (REC / G);
+#pragma unroll
+      for (int h = 0; h < G; ++h) lds.rec1[j][G * w_ + h] = t1[it][h];
     }
     (&lds.qs[0][0])[t < NQ ? t : NQ - 1] = 1.0 / tq;
     (&lds.rs[0][0])[t < NR ? t : NR - 1] = tr;

@@ -100,13 +100,8 @@ static int launch_small(NdlqrHipCtx* c) {
       }
       for (int l = 2; l < d.K && !tree; ++l) {
         ScopedSlot t(c, SLOT_UPPER);
-        // two adjacent separators per wavefront (one Cholesky pass for both) wherever the level has two
-        if (l < d.K - 1 && !c->no_pair)
-          hipLaunchKernelGGL((ndlqr::reduced_level_pair_mc<NX, NU>), dim3(d.N >> (l + 2), d.batch), dim3(64), 0,
-                             c->stream, d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
-        else
-          hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
-                             d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+        hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
+                           d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
       }
       ScopedSlot t(c, SLOT_APPLY);
       if (compact) {
