@@ -59,7 +59,12 @@ struct NdlqrAltSlot {
 };
 
 struct NdlqrHipCtx {
-  ndlqr::Dims d;
+  ndlqr::Dims d;   // block sizes of the DEVICE layout (every kernel works on these)
+  ndlqr::Dims du;  // the caller's block sizes: the same, or smaller when the problem runs zero-padded into the next
+                   // size-specialised instance ("padded shapes", ndlqr_hip_create); only the boundary functions see it
+  bool padded;
+  double* pad_stage;      // HBM staging of caller-layout inputs / outputs of a padded shape (grown on demand)
+  size_t pad_stage_cap;   // doubles
   int device;
   unsigned flags;
   hipStream_t stream;

@@ -315,49 +315,70 @@ __global__ void schur_generic(Dims d, int l, double* F, double* z, int boundary,
 // B [N][n*m] column-major, Q,q,d [N][n], R,r [N][m], x0 [n] per problem): transposes A, B into the
 // row-major [A | B] input, copies the diagonals and builds the negated right-hand side.
 // grid (N, batch), any block size.
-static __global__ void pack_flat_generic(Dims d, const double* __restrict__ A, const double* __restrict__ B,
+// du: the caller's dimensions (layout of the flat arrays), d: the device layout -- the same, or a larger block size
+// that the problem is zero-padded into (ndlqr_hip.hip, "padded shapes": the pad entries are set once and never touched).
+static __global__ void pack_flat_generic(Dims du, Dims d, const double* __restrict__ A, const double* __restrict__ B,
                                   const double* __restrict__ Q, const double* __restrict__ R,
                                   const double* __restrict__ q, const double* __restrict__ r,
                                   const double* __restrict__ dd, const double* __restrict__ x0,
                                   double* __restrict__ AB, double* __restrict__ QR, double* __restrict__ rhs) {
   const int k = blockIdx.x, b = blockIdx.y;
-  const int n = d.n, m = d.m, w = d.w, rows = d.rows, N = d.N;
+  const int n = du.n, m = du.m, N = du.N;
   const size_t pk = (size_t)b * N + k;
   const double* Ak = A + pk * n * n;
   const double* Bk = B + pk * n * m;
-  double* ab = AB + pk * n * w;
-  for (int e = threadIdx.x; e < n * w; e += blockDim.x) {
-    const int i = e / w, j = e - i * w;
-    ab[e] = j < n ? Ak[i + n * j] : Bk[i + n * (j - n)];
+  double* ab = AB + pk * d.n * d.w;
+  for (int e = threadIdx.x; e < n * du.w; e += blockDim.x) {
+    const int i = e / du.w, j = e - i * du.w;
+    ab[i * d.w + (j < n ? j : d.n + (j - n))] = j < n ? Ak[i + n * j] : Bk[i + n * (j - n)];
   }
-  double* qr = QR + pk * w;
-  for (int e = threadIdx.x; e < w; e += blockDim.x) qr[e] = e < n ? Q[pk * n + e] : R[pk * m + (e - n)];
-  double* z = rhs + pk * rows;
-  for (int e = threadIdx.x; e < rows; e += blockDim.x) {
+  double* qr = QR + pk * d.w;
+  for (int e = threadIdx.x; e < du.w; e += blockDim.x)
+    qr[e < n ? e : d.n + (e - n)] = e < n ? Q[pk * n + e] : R[pk * m + (e - n)];
+  double* z = rhs + pk * d.rows;
+  for (int e = threadIdx.x; e < du.rows; e += blockDim.x) {
     double v;
     if (e < n) v = k == 0 ? -x0[(size_t)b * n + e] : -dd[(pk - 1) * n + e];
     else if (e < 2 * n) v = -q[pk * n + (e - n)];
     else v = k < N - 1 ? -r[pk * m + (e - 2 * n)] : 0.0;
-    z[e] = v;
+    z[e < n ? e : (e < 2 * n ? d.n + (e - n) : 2 * d.n + (e - 2 * n))] = v;
   }
 }
 
-// The right-hand side alone from flat arrays (q, d [batch][N][n], r [batch][N][m], x0 [batch][n]) that live in HBM:
-// knot k = [-(x0 | d_{k-1}); -q_k; -r_k], the last knot's input slot 0 (src/solver.c:141-190). grid (N, batch).
-static __global__ void pack_rhs_flat_generic(Dims d, const double* __restrict__ q, const double* __restrict__ r,
-                                             const double* __restrict__ dd, const double* __restrict__ x0,
-                                             double* __restrict__ rhs) {
-  const int k = blockIdx.x, b = blockIdx.y;
-  const int n = d.n, m = d.m, rows = d.rows, N = d.N;
-  const size_t pk = (size_t)b * N + k;
-  double* z = rhs + pk * rows;
-  for (int e = threadIdx.x; e < rows; e += blockDim.x) {
-    double v;
-    if (e < n) v = k == 0 ? -x0[(size_t)b * n + e] : -dd[(pk - 1) * n + e];
-    else if (e < 2 * n) v = -q[pk * n + (e - n)];
-    else v = k < N - 1 ? -r[pk * m + (e - 2 * n)] : 0.0;
-    z[e] = v;
+// Padded shapes: everything of the device inputs that is not a real entry, once, at context creation: zero
+// couplings, unit weights (dummy states / inputs with Q = R = 1), zero right-hand side -- the dummies solve to exactly
+// zero, S-bar gains a unit diagonal block, nothing else changes. grid (N, batch).
+static __global__ void pad_fill_generic(Dims d, double* __restrict__ AB, double* __restrict__ QR, double* __restrict__ rhs) {
+  const size_t pk = (size_t)blockIdx.y * d.N + blockIdx.x;
+  for (int e = threadIdx.x; e < d.n * d.w; e += blockDim.x) AB[pk * d.n * d.w + e] = 0.0;
+  for (int e = threadIdx.x; e < d.w; e += blockDim.x) QR[pk * d.w + e] = 1.0;
+  for (int e = threadIdx.x; e < d.rows; e += blockDim.x) rhs[pk * d.rows + e] = 0.0;
+}
+
+// Packed inputs in the CALLER's block size (the host layout of ndlqr_hip_upload_inputs, staged in HBM) into the padded
+// device arrays of problems [p0, p0 + count). Null sAB: the right-hand side alone. grid (N, count).
+static __global__ void pad_inputs_generic(Dims du, Dims d, const int p0, const double* __restrict__ sAB,
+                                          const double* __restrict__ sQR, const double* __restrict__ srhs,
+                                          double* __restrict__ AB, double* __restrict__ QR, double* __restrict__ rhs) {
+  const size_t sk = (size_t)blockIdx.y * du.N + blockIdx.x, pk = ((size_t)p0 + blockIdx.y) * d.N + blockIdx.x;
+  const int n = du.n;
+  if (sAB) {
+    for (int e = threadIdx.x; e < n * du.w; e += blockDim.x) {
+      const int i = e / du.w, j = e - i * du.w;
+      AB[pk * d.n * d.w + i * d.w + (j < n ? j : d.n + (j - n))] = sAB[sk * n * du.w + e];
+    }
+    for (int e = threadIdx.x; e < du.w; e += blockDim.x) QR[pk * d.w + (e < n ? e : d.n + (e - n))] = sQR[sk * du.w + e];
   }
+  for (int e = threadIdx.x; e < du.rows; e += blockDim.x)
+    rhs[pk * d.rows + (e < n ? e : (e < 2 * n ? d.n + (e - n) : 2 * d.n + (e - 2 * n)))] = srhs[sk * du.rows + e];
+}
+
+// One problem's solution blocks [N][2 n + m] (caller's block size, the u slot of the last knot included) out of
+// the padded device array. grid (N).
+static __global__ void unpad_blocks_generic(Dims du, Dims d, const double* __restrict__ z, double* __restrict__ dst) {
+  const int k = blockIdx.x, n = du.n;
+  for (int e = threadIdx.x; e < du.rows; e += blockDim.x)
+    dst[(size_t)k * du.rows + e] = z[(size_t)k * d.rows + (e < n ? e : (e < 2 * n ? d.n + (e - n) : 2 * d.n + (e - 2 * n)))];
 }
 
 // The same as a STREAMING kernel: few workgroups (the launch is resident at once, so that kernels of the other buffer
@@ -365,15 +386,15 @@ static __global__ void pack_rhs_flat_generic(Dims d, const double* __restrict__ 
 // straight from PINNED HOST memory over the host link (no staging copy; a copy engine transfer in both directions on
 // one stream serialises the two-deep step pipeline on this platform, tools/ubench/copy_overlap.hip). Any of q / r / d
 // may be null: that part of the right-hand side stays as it is (an MPC iteration often replaces x0 alone).
-__device__ __forceinline__ void pack_rhs_one(const Dims& d, const int which, const size_t g, const double v,
-                                             double* __restrict__ rhs) {
-  const size_t n = d.n, m = d.m, rows = d.rows, N = d.N;
+__device__ __forceinline__ void pack_rhs_one(const Dims& du, const Dims& d, const int which, const size_t g,
+                                             const double v, double* __restrict__ rhs) {
+  const size_t n = du.n, m = du.m, rows = d.rows, N = du.N, np = d.n;  // rows, np: the (possibly padded) device layout
   if (which == 0) {         // q
     const size_t pk = g / n, e = g - pk * n;
-    rhs[pk * rows + n + e] = -v;
+    rhs[pk * rows + np + e] = -v;
   } else if (which == 1) {  // r (the last knot's input slot stays 0)
     const size_t pk = g / m, e = g - pk * m;
-    rhs[pk * rows + 2 * n + e] = (pk % N) < N - 1 ? -v : 0.0;
+    rhs[pk * rows + 2 * np + e] = (pk % N) < N - 1 ? -v : 0.0;
   } else if (which == 2) {  // d_k is the lambda block of knot k + 1
     const size_t pk = g / n, e = g - pk * n;
     if ((pk % N) < N - 1) rhs[(pk + 1) * rows + e] = -v;
@@ -383,12 +404,12 @@ __device__ __forceinline__ void pack_rhs_one(const Dims& d, const int which, con
   }
 }
 
-static __global__ __launch_bounds__(256) void pack_rhs_stream_generic(Dims d, const double* __restrict__ q,
+static __global__ __launch_bounds__(256) void pack_rhs_stream_generic(Dims du, Dims d, const double* __restrict__ q,
                                                                       const double* __restrict__ r,
                                                                       const double* __restrict__ dd,
                                                                       const double* __restrict__ x0,
                                                                       double* __restrict__ rhs) {
-  const size_t nq = (size_t)d.batch * d.N * d.n, nr = (size_t)d.batch * d.N * d.m, nx = (size_t)d.batch * d.n;
+  const size_t nq = (size_t)du.batch * du.N * du.n, nr = (size_t)du.batch * du.N * du.m, nx = (size_t)du.batch * du.n;
   const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const double* src[4] = {q, r, dd, x0};
   const size_t cnt[4] = {nq, nr, nq, nx};
@@ -400,23 +421,24 @@ static __global__ __launch_bounds__(256) void pack_rhs_stream_generic(Dims d, co
     size_t i = t0;
     for (; i + 3 * stride < n; i += 4 * stride) {
       const double a = p[i], b = p[i + stride], c = p[i + 2 * stride], e = p[i + 3 * stride];
-      pack_rhs_one(d, which, i, a, rhs);
-      pack_rhs_one(d, which, i + stride, b, rhs);
-      pack_rhs_one(d, which, i + 2 * stride, c, rhs);
-      pack_rhs_one(d, which, i + 3 * stride, e, rhs);
+      pack_rhs_one(du, d, which, i, a, rhs);
+      pack_rhs_one(du, d, which, i + stride, b, rhs);
+      pack_rhs_one(du, d, which, i + 2 * stride, c, rhs);
+      pack_rhs_one(du, d, which, i + 3 * stride, e, rhs);
     }
-    for (; i < n; i += stride) pack_rhs_one(d, which, i, p[i], rhs);
+    for (; i < n; i += stride) pack_rhs_one(du, d, which, i, p[i], rhs);
   }
 }
 
 // Solutions [batch][N][2n+m] (the unused trailing u_N slot included) -> [batch][nvars] packed, the
 // layout of ndlqr_CopyBatchSolutions, in device memory. grid (N, batch).
-static __global__ void pack_solutions_generic(Dims d, const double* __restrict__ z, double* __restrict__ dst) {
-  const int k = blockIdx.x, b = blockIdx.y;
-  const size_t nvars = (size_t)d.rows * d.N - d.m;
-  const int len = k < d.N - 1 ? d.rows : d.rows - d.m;
+static __global__ void pack_solutions_generic(Dims du, Dims d, const double* __restrict__ z, double* __restrict__ dst) {
+  const int k = blockIdx.x, b = blockIdx.y, n = du.n;
+  const size_t nvars = (size_t)du.rows * du.N - du.m;
+  const int len = k < du.N - 1 ? du.rows : du.rows - du.m;
   for (int e = threadIdx.x; e < len; e += blockDim.x)
-    dst[(size_t)b * nvars + (size_t)k * d.rows + e] = z[((size_t)b * d.N + k) * d.rows + e];
+    dst[(size_t)b * nvars + (size_t)k * du.rows + e] =
+        z[((size_t)b * d.N + k) * d.rows + (e < n ? e : (e < 2 * n ? d.n + (e - n) : 2 * d.n + (e - 2 * n)))];
 }
 
 // ------------------------------------------------------------------------------------- rhs-only sweep

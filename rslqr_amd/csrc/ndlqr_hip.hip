@@ -42,6 +42,7 @@ int ndlqr_hip_device_count(void) {
 static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom", "upper"};
 
 static bool has_small_instance(int nstates, int ninputs);  // defined with the instance table below
+static void pick_pad_instance(int nstates, int ninputs, int* pn, int* pm);
 
 static size_t bytes_AB(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.n * d.w; }
 static size_t bytes_QR(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.N * d.w; }
@@ -76,9 +77,22 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
 
   NdlqrHipCtx* c = new NdlqrHipCtx();
   ndlqr::Dims& d = c->d;
-  d.n = nstates; d.m = ninputs; d.N = nhorizon; d.batch = batch;
-  d.K = 0; while ((1 << d.K) < nhorizon) ++d.K;
-  d.rows = 2 * nstates + ninputs; d.w = nstates + ninputs; d.fb = d.rows * nstates;
+  auto set_dims = [&](ndlqr::Dims& x, int n_, int m_) {
+    x.n = n_; x.m = m_; x.N = nhorizon; x.batch = batch;
+    x.K = 0; while ((1 << x.K) < nhorizon) ++x.K;
+    x.rows = 2 * n_ + m_; x.w = n_ + m_; x.fb = x.rows * n_;
+  };
+  set_dims(c->du, nstates, ninputs);
+  // Padded shapes: a block size without a size-specialised instance runs zero-padded inside the cheapest instance
+  // that contains it (dummy states and inputs with unit weights and no coupling: they solve to exactly zero and the
+  // real variables see the same arithmetic plus exact zeros) instead of the runtime-sized kernels, which are 3-4x
+  // slower below 16 states. NDLQR_NO_PAD=1 keeps the caller's block size (A/B, tests).
+  int pn = nstates, pm = ninputs;
+  if (!has_small_instance(nstates, ninputs) && nhorizon >= 8 && !getenv("NDLQR_NO_PAD"))
+    pick_pad_instance(nstates, ninputs, &pn, &pm);
+  set_dims(d, pn, pm);
+  c->padded = pn != nstates || pm != ninputs;
+  c->pad_stage = nullptr; c->pad_stage_cap = 0;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->red_bytes = 0;
   c->wfac = nullptr;
@@ -106,16 +120,20 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
             hipMalloc(&c->info, sizeof(int) * ((size_t)batch + 1)) == hipSuccess &&
             hipHostMalloc((void**)&c->h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (ok) *c->h_fail = 0;
-  if (ok && nhorizon >= 8 && has_small_instance(nstates, ninputs)) {
+  if (ok && nhorizon >= 8 && has_small_instance(d.n, d.m)) {
     // slot = DL | DR | CA | CB | gL | gR, padded to whole 128-byte lines (RedSlot<NX>::SIZE)
-    const size_t slot_doubles = (4 * (size_t)nstates * nstates + 2 * nstates + 15) / 16 * 16;
+    const size_t slot_doubles = (4 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
     const size_t red_bytes = sizeof(double) * (size_t)batch * (nhorizon / 4) * slot_doubles;
     ok = hipMalloc(&c->red, red_bytes) == hipSuccess && hipMemsetAsync(c->red, 0, red_bytes, c->stream) == hipSuccess;
     if (ok) c->red_bytes = red_bytes;
-    ok = ok && hipMalloc(&c->ytop, sizeof(double) * (size_t)batch * (nhorizon / 8) * nstates) == hipSuccess;
+    ok = ok && hipMalloc(&c->ytop, sizeof(double) * (size_t)batch * (nhorizon / 8) * d.n) == hipSuccess;
     const size_t cnt_bytes = sizeof(int) * (size_t)batch * (nhorizon / 4);
     ok = ok && hipMalloc(&c->tree_cnt, cnt_bytes) == hipSuccess &&
          hipMemsetAsync(c->tree_cnt, 0, cnt_bytes, c->stream) == hipSuccess;
+  }
+  if (ok && c->padded) {
+    hipLaunchKernelGGL(ndlqr::pad_fill_generic, dim3(d.N, d.batch), dim3(128), 0, c->stream, d, c->AB, c->QR, c->rhs);
+    ok = hipGetLastError() == hipSuccess;
   }
   if (ok) {
     // (the factor array F is allocated by the first solve whose schedule touches it: ndlqr_hip_ensure_F)
@@ -143,7 +161,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
-  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->wfac); (void)hipFree(c->xfer);
+  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->wfac); (void)hipFree(c->xfer); (void)hipFree(c->pad_stage);
   for (double* h : c->h_stage) if (h) (void)hipHostFree(h);
   if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
   for (hipEvent_t ev : c->ev_step) if (ev) (void)hipEventDestroy(ev);
@@ -314,12 +332,40 @@ static hipError_t other_stream_waits(NdlqrHipCtx* c) {
   return e != hipSuccess ? e : hipStreamWaitEvent(c->alt.stream, c->ev_inputs, 0);
 }
 
+// staging of caller-layout data of a padded shape
+static int ensure_pad_stage(NdlqrHipCtx* c, size_t doubles) {
+  if (doubles <= c->pad_stage_cap) return NDLQR_OK;
+  if (c->pad_stage) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->pad_stage); c->pad_stage = nullptr; c->pad_stage_cap = 0; }
+  HIP_TRY(hipMalloc(&c->pad_stage, sizeof(double) * doubles));
+  c->pad_stage_cap = doubles;
+  return NDLQR_OK;
+}
+
 int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB, const double* QR,
                             const double* rhs) {
   if (!c || !AB || !QR || !rhs || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
+  if (c->padded) {  // the caller's layout goes to a staging array in HBM, a kernel files it into the padded arrays
+    const ndlqr::Dims& u = c->du;
+    const size_t uAB = (size_t)u.N * u.n * u.w * count, uQR = (size_t)u.N * u.w * count, uz = (size_t)u.N * u.rows * count;
+    const int serr = ensure_pad_stage(c, uAB + uQR + uz);
+    if (serr) return serr;
+    double* s0 = c->pad_stage;
+    HIP_TRY(hipMemcpyAsync(s0, AB, sizeof(double) * uAB, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s0 + uAB, QR, sizeof(double) * uQR, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s0 + uAB + uQR, rhs, sizeof(double) * uz, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ndlqr::pad_inputs_generic, dim3(d.N, count), dim3(128), 0, c->stream, u, d, p0, s0, s0 + uAB,
+                       s0 + uAB + uQR, c->AB, c->QR, c->rhs);
+    HIP_TRY(hipGetLastError());
+    const size_t sz = (size_t)d.N * d.rows;
+    HIP_TRY(mirror_rhs(c, p0 * sz, sz * count));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->fact_valid = false;
+    c->rec_complete = false;
+    return NDLQR_OK;
+  }
   const size_t sAB = (size_t)d.N * d.n * d.w, sQR = (size_t)d.N * d.w, sz = (size_t)d.N * d.rows;
   HIP_TRY(hipMemcpyAsync(c->AB + p0 * sAB, AB, sizeof(double) * sAB * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->QR + p0 * sQR, QR, sizeof(double) * sQR * count, hipMemcpyHostToDevice, c->stream));
@@ -337,7 +383,7 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   if (!c || !A || !B || !Q || !R || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
-  hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->d, A, B, Q, R,
+  hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q, R,
                      q, r, d, x0, c->AB, c->QR, c->rhs);
   HIP_TRY(hipGetLastError());
   HIP_TRY(mirror_rhs(c, 0, (size_t)c->d.batch * c->d.N * c->d.rows));
@@ -349,6 +395,12 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
 
 int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
   if (!c || !out5) return NDLQR_ERR_INVALID;
+  if (c->padded) {
+    g_last_error = "no raw device pointers for a block size that runs zero-padded (the arrays have another layout): "
+                   "use ndlqr_hip_pack_flat_device, or NDLQR_NO_PAD=1";
+    fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+    return NDLQR_ERR_INVALID;
+  }
   const int ferr = ndlqr_hip_ensure_F(c);  // the caller asks for the factor array: it has to exist
   if (ferr) return ferr;
   const int perr = ndlqr_hip_set_pipeline_depth(c, 1);  // the caller holds raw pointers: one buffer set from now on
@@ -649,6 +701,17 @@ static bool has_small_instance(int nstates, int ninputs) {
   return false;
 }
 
+// cheapest instance (with a matrix-core path: six states or more) that contains the block size; *pn, *pm untouched
+// when there is none
+static void pick_pad_instance(int nstates, int ninputs, int* pn, int* pm) {
+  long best = -1;
+  for (const SmallInstance& si : kSmallInstances) {
+    if (si.nx < nstates || si.nu < ninputs || si.nx < 6) continue;
+    const long cost = (long)si.nx * si.nx * (si.nx + si.nu);
+    if (best < 0 || cost < best) { best = cost; *pn = si.nx; *pm = si.nu; }
+  }
+}
+
 static const SmallInstance* find_small(const ndlqr::Dims& d) {
   for (const SmallInstance& s : kSmallInstances)
     if (s.nx == d.n && s.nu == d.m) return &s;
@@ -799,7 +862,7 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
 // transfer staging of the current buffer set: max(flat right-hand side, packed solutions) doubles
 static int ensure_xfer(NdlqrHipCtx* c) {
   if (c->xfer) return NDLQR_OK;
-  const ndlqr::Dims& d = c->d;
+  const ndlqr::Dims& d = c->du;  // (caller-layout data: flat right-hand side going up, packed solutions coming down)
   HIP_TRY(hipMalloc(&c->xfer, sizeof(double) * ((size_t)d.batch * d.N * d.rows + (size_t)d.batch * d.n)));
   return NDLQR_OK;
 }
@@ -830,7 +893,8 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   // records kept, caller-owned stream, depth 1) the steps are simply stream-ordered.
   hipStream_t st = c->stream;
   HIP_TRY(hipEventRecord(c->ev_start, st));
-  const size_t nq = (size_t)d.batch * d.N * d.n, nr = (size_t)d.batch * d.N * d.m, nx = (size_t)d.batch * d.n;
+  const ndlqr::Dims& u = c->du;
+  const size_t nq = (size_t)u.batch * u.N * u.n, nr = (size_t)u.batch * u.N * u.m, nx = (size_t)u.batch * u.n;
   const double* src[4] = {q, r, dd, x0};
   const size_t cnt[4] = {nq, nr, nq, nx};
   const double* view[4];
@@ -843,15 +907,15 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
     }
     stage += cnt[k];
   }
-  hipLaunchKernelGGL(ndlqr::pack_rhs_stream_generic, dim3(512), dim3(256), 0, st, d, view[0], view[1], view[2], view[3],
-                     c->rhs);
+  hipLaunchKernelGGL(ndlqr::pack_rhs_stream_generic, dim3(512), dim3(256), 0, st, u, d, view[0], view[1], view[2],
+                     view[3], c->rhs);
   HIP_TRY(hipGetLastError());
   err = launch_solve(c);
   if (err) return err;
   // (the staging has been consumed by the pack kernel: it now takes the packed solutions)
-  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, d, c->z, c->xfer);
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, u, d, c->z, c->xfer);
   HIP_TRY(hipGetLastError());
-  const size_t nvars = (size_t)d.rows * d.N - d.m;
+  const size_t nvars = (size_t)u.rows * u.N - u.m;
   HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * nvars * d.batch, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(c->ev_stop, st));
   HIP_TRY(hipEventRecord(c->ev_step[c->step_count & 1u], st));
@@ -887,7 +951,17 @@ int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
   const size_t sz = (size_t)d.N * d.rows;
-  HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
+  if (c->padded) {
+    const size_t uz = (size_t)c->du.N * c->du.rows * count;
+    const int serr = ensure_pad_stage(c, uz);
+    if (serr) return serr;
+    HIP_TRY(hipMemcpyAsync(c->pad_stage, rhs, sizeof(double) * uz, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ndlqr::pad_inputs_generic, dim3(d.N, count), dim3(128), 0, c->stream, c->du, d, p0,
+                       (const double*)nullptr, (const double*)nullptr, (const double*)c->pad_stage, c->AB, c->QR, c->rhs);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
+  }
   HIP_TRY(mirror_rhs(c, p0 * sz, sz * count));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return NDLQR_OK;
@@ -1034,9 +1108,9 @@ int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln
   const int xerr = ensure_xfer(c);
   if (xerr) return xerr;
   const double* zl = c->z_latest ? c->z_latest : c->z;
-  const size_t nvars = (size_t)d.rows * d.N - d.m, pitch = (size_t)d.rows * d.N;
+  const size_t nvars = (size_t)c->du.rows * d.N - c->du.m, pitch = (size_t)d.rows * d.N;
   hipStream_t st = c->stream;
-  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, count), dim3(64), 0, st, d, zl + p0 * pitch, c->xfer);
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, count), dim3(64), 0, st, c->du, d, zl + p0 * pitch, c->xfer);
   HIP_TRY(hipGetLastError());
   const size_t total = nvars * count;
   if (host_ptr_is_pinned(soln)) {
@@ -1083,7 +1157,7 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* c, double* dst) {
   HIP_TRY(hipSetDevice(c->device));
   // on the stream of the latest solve: ordered behind it, asynchronous for the caller
   hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0,
-                     c->stream_latest ? c->stream_latest : c->stream, d, c->z_latest ? c->z_latest : c->z, dst);
+                     c->stream_latest ? c->stream_latest : c->stream, c->du, d, c->z_latest ? c->z_latest : c->z, dst);
   HIP_TRY(hipGetLastError());
   return NDLQR_OK;
 }
@@ -1112,8 +1186,17 @@ int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
   HIP_TRY(hipSetDevice(c->device));
   const size_t pitch = (size_t)d.rows * d.N;
   HIP_TRY(sync_all(c));
-  HIP_TRY(hipMemcpyAsync(z_full, (c->z_latest ? c->z_latest : c->z) + p * pitch, sizeof(double) * pitch,
-                         hipMemcpyDeviceToHost, c->stream));
+  const double* zp = (c->z_latest ? c->z_latest : c->z) + p * pitch;
+  if (c->padded) {
+    const size_t upitch = (size_t)c->du.rows * d.N;
+    const int serr = ensure_pad_stage(c, upitch);
+    if (serr) return serr;
+    hipLaunchKernelGGL(ndlqr::unpad_blocks_generic, dim3(d.N), dim3(64), 0, c->stream, c->du, d, zp, c->pad_stage);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(z_full, c->pad_stage, sizeof(double) * upitch, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(z_full, zp, sizeof(double) * pitch, hipMemcpyDeviceToHost, c->stream));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return NDLQR_OK;
 }
@@ -1133,15 +1216,18 @@ int ndlqr_hip_download_factors(NdlqrHipCtx* c, int p, double* fact) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   // device: [level][knot][row][col] row-major -> reference: block (k,level) at (k + N*level)*fb,
   // sub-blocks lambda (n x n), state (n x n), input (m x n), each column-major (src/nddata.c:40-53)
-  const int n = d.n, m = d.m;
+  // (a padded shape: the device blocks have np >= n columns and rows lambda [0, np), state [np, 2 np), input
+  //  [2 np, 2 np + mp); the caller gets the real rows and columns)
+  const int n = c->du.n, m = c->du.m, np = d.n;
+  const size_t ufb = c->du.fb;
   for (int lvl = 0; lvl < d.K; ++lvl)
     for (int k = 0; k < d.N; ++k) {
       const double* src = tmp.data() + ((size_t)lvl * d.N + k) * d.fb;
-      double* dst = fact + ((size_t)k + (size_t)d.N * lvl) * d.fb;
+      double* dst = fact + ((size_t)k + (size_t)d.N * lvl) * ufb;
       for (int j = 0; j < n; ++j) {
-        for (int i = 0; i < n; ++i) dst[i + n * j] = src[i * n + j];
-        for (int i = 0; i < n; ++i) dst[n * n + i + n * j] = src[(n + i) * n + j];
-        for (int i = 0; i < m; ++i) dst[2 * n * n + i + m * j] = src[(2 * n + i) * n + j];
+        for (int i = 0; i < n; ++i) dst[i + n * j] = src[i * np + j];
+        for (int i = 0; i < n; ++i) dst[n * n + i + n * j] = src[(np + i) * np + j];
+        for (int i = 0; i < m; ++i) dst[2 * n * n + i + m * j] = src[(2 * np + i) * np + j];
       }
     }
   return NDLQR_OK;

@@ -176,12 +176,14 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
                                          (33, 5, 8, 2), (50, 10, 64, 2), (63, 1, 16, 2), (64, 15, 16, 1), (3, 1, 2, 2),
                                          # inputs too wide for one wavefront per tile column: the larger workgroups
                                          (64, 200, 8, 1), (48, 150, 8, 1), (32, 100, 8, 2), (16, 60, 16, 2)])
-def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch):
-    """Every block size up to 64 states without a size-specialised instance takes the separator-only schedule on
-    the matrix cores (kernels_reduced_mfma.hpp: one launch per tree level, no factor array), down to a single
-    separator (N = 2); blocks that do not fill 16x16 tiles are zero-padded in LDS. Consecutive solves alternate
-    between the two buffer sets of the pipeline and replay the captured graph: every one of them has to
-    reproduce the oracle. A non-positive weight is reported like on every other path."""
+def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch, monkeypatch):
+    """Every block size up to 64 states takes the separator-only schedule on the matrix cores on ITS OWN block size
+    (kernels_reduced_mfma.hpp: one launch per tree level, no factor array), down to a single separator (N = 2);
+    blocks that do not fill 16x16 tiles are zero-padded in LDS. (NDLQR_NO_PAD=1: by default a block size below 16
+    states without a size-specialised instance runs padded inside the next instance instead, test_padded_shapes.)
+    Consecutive solves alternate between the two buffer sets of the pipeline and replay the captured graph: every
+    one of them has to reproduce the oracle. A non-positive weight is reported like on every other path."""
+    monkeypatch.setenv("NDLQR_NO_PAD", "1")
     probs = [synth(ndlqr, n, m, N, 1300 + p) for p in range(batch)]
     refs = [oracle.solve(prob, 1)[0][: prob.nvars] for prob in probs]
     bs = ndlqr.BatchSolver(n, m, N, batch)
@@ -745,3 +747,84 @@ def test_large_download_through_bounce_buffers(ndlqr):
     res, bn = bs.kkt_residuals()
     assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
     bs.close()
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(7, 9, 16, 3), (5, 3, 32, 2), (1, 1, 8, 2), (11, 3, 64, 2), (14, 2, 8, 2),
+                                         (9, 6, 16, 40), (7, 9, 64, 300)])
+def test_padded_shapes(ndlqr, oracle, n, m, N, batch, monkeypatch):
+    """A block size without a size-specialised instance (below 16 states, N >= 8) runs zero-padded inside the
+    cheapest instance that contains it: dummy states / inputs with unit weights and no coupling, set once on the
+    device; only the boundary functions (uploads, device-side packing, downloads, factor download, MPC step) know
+    the caller's block size. Every mode against the oracle on the caller's problem: fast (and against the
+    runtime-sized kernels on the own block size), strict (bit-exact: the pad terms are exact zeros), KEEP_FACT
+    factors, rhs-only re-solve on kept records, the MPC step, the device-side KKT residual, a non-SPD weight."""
+    probs = [synth(ndlqr, n, m, N, 4200 + p) for p in range(batch)]
+    sample = sorted({0, batch // 2, batch - 1})
+    refs = {p: oracle.solve(probs[p], 1, want_fact=True) for p in sample}
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*stack(probs))
+    for _ in range(3):
+        assert bs.solve() == 0
+    assert bs.schedule() in ("reduced", "reduced-tree")  # the instance's schedule, not the runtime-sized one
+    fast = bs.solutions()
+    for p in sample:
+        ref = refs[p][0][: probs[p].nvars]
+        assert np.linalg.norm(fast[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+    res, bn = bs.kkt_residuals()
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    for p in sample:  # the device-side residual is that of the caller's problem (the dummies contribute exact zeros)
+        r_o, b_o = oracle.kkt_residual(probs[p], fast[p])
+        assert abs(bn[p] - b_o) <= 1e-12 * b_o and res[p] <= 1e-9 * max(1.0, b_o)
+    # strict mode: bit-identical solution AND factor array (un-padded by the download)
+    bs.set_flags(ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT)
+    assert bs.solve() == 0
+    for p in sample:
+        z, fact, _, _ = refs[p]
+        assert np.array_equal(bs.solution(p), z[: probs[p].nvars])
+        assert np.array_equal(bs.factors(p), fact)
+    # fast mode with the factor array kept
+    bs.set_flags(ndlqr.FLAG_KEEP_FACT)
+    assert bs.solve() == 0
+    f = bs.factors(sample[-1])
+    assert np.linalg.norm(f - refs[sample[-1]][1]) / np.linalg.norm(refs[sample[-1]][1]) <= REL_TOL
+    # rhs-only re-solve on kept records, new right-hand side through the caller's layout
+    bs.set_flags(ndlqr.FLAG_KEEP_RECORDS)
+    assert bs.solve() == 0
+    other = [synth(ndlqr, n, m, N, 8800 + p) for p in range(batch)]
+    bs.set_rhs_flat(*[np.stack([getattr(o, k) for o in other]) for k in ("q", "r", "d", "x0")])
+    assert bs.solve_rhs_only() == 0
+    for p in sample:
+        mixed = Problem(n, m, N, probs[p].A, probs[p].B, probs[p].Q, probs[p].R, other[p].q, other[p].r, other[p].d,
+                        other[p].x0)
+        ref = oracle.solve(mixed, 1)[0][: mixed.nvars]
+        assert np.linalg.norm(bs.solution(p) - ref) / np.linalg.norm(ref) <= REL_TOL
+    # the MPC step (pack kernel from the caller's flat layout into the padded right-hand side, packed solutions back)
+    bs.set_flags(0)
+    arrs = []
+    for k in ("q", "r", "d", "x0"):
+        a = np.stack([getattr(o, k) for o in probs])
+        pa = ndlqr.pinned_empty(a.shape)
+        pa[...] = a
+        arrs.append(pa)
+    out = ndlqr.pinned_empty((batch, bs.nvars))
+    assert bs.step_async(arrs[0], arrs[1], arrs[2], arrs[3], out) == 0 and bs.synchronize() == 0
+    assert np.array_equal(out, fast)
+    ptrs = (C.c_void_p * 5)()  # no raw device pointers: the arrays have the padded layout
+    assert ndlqr.lib().ndlqr_hip_device_pointers(bs.ctx, ptrs) == -1
+    bs.close()
+    # the same block size on the runtime-sized kernels: same answer to rounding
+    monkeypatch.setenv("NDLQR_NO_PAD", "1")
+    own = ndlqr.BatchSolver(n, m, N, batch)
+    own.initialize_flat(*stack(probs))
+    assert own.solve() == 0 and own.schedule().startswith("generic")
+    assert np.linalg.norm(own.solutions() - fast) / np.linalg.norm(fast) <= REL_TOL
+    own.close()
+    monkeypatch.delenv("NDLQR_NO_PAD")
+    # a non-positive weight is reported
+    bad = probs[0]
+    R = bad.R.copy()
+    R[N // 2, 0] = -1.0
+    one = ndlqr.BatchSolver(n, m, N, 1)
+    one.initialize_flat(*[np.asarray(a)[None] for a in (bad.A, bad.B, bad.Q, R, bad.q, bad.r, bad.d, bad.x0)])
+    assert one.solve() == -3 and one.cholesky_failures() >= 1
+    one.close()
