@@ -298,7 +298,7 @@ def roofline_object(prof, steps, schedule, n, m, N, batch, flags, solves_per_s_p
         entry = {"avg_launch_ms": avg_ms, "launches_per_step": launches / steps,
                  "ms_per_step": ms / steps}
         if model and slot in model:
-            entry.update(rf.kernel_roofline(model[slot], batch, avg_ms))
+            entry.update(rf.kernel_roofline(model[slot], batch, avg_ms, launches / steps))
             assert 0.0 < entry["frac"] <= 1.0, (slot, entry)
         entry["traffic"] = traffic.get(slot)
         kernels[slot] = entry

@@ -97,6 +97,7 @@ struct NdlqrHipCtx {
   double* kkt_out;  // [2 batch] scratch of ndlqr_hip_kkt_residual (allocated on first use)
   double* xfer;     // transfer staging of the current buffer set (see NdlqrAltSlot::xfer; allocated on first use)
   double* h_stage[2];  // pinned bounce buffers of the downloads into pageable host memory (allocated on first use)
+  bool no_top;        // NDLQR_NO_TOP=1: the last three tree levels as launches of their own (A/B timing of reduced_top_mc)
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
   bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)

@@ -550,6 +550,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void re
 }
 
 
+// The top of the tree in ONE launch: the last three levels (4 + 2 + 1 separators per problem), one workgroup of four
+// wavefronts per problem, one separator per wavefront and level, a workgroup barrier between levels. These levels
+// are bound by the latency of a single wavefront (~4.5 us per separator however few there are), and as launches of
+// their own each paid that latency plus a launch boundary: 14 + 9 + 6.5 us at (12,4,256) x 1024. The hand-off between
+// levels goes through global memory like the tree schedule's (write-through pushes, L1-bypassing slot loads,
+// reduced_separator_mc<TREE>): the four wavefronts share a CU, but nothing is assumed about its L1.
+//   grid (batch), block 256; l0 = K - 3 >= 2.
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void reduced_top_mc(Dims d, const int l0, const double* __restrict__ AB,
+                                                      const double* __restrict__ QR, const double* __restrict__ rhs,
+                                                      double* red, double* __restrict__ rec, double* F,
+                                                      int* __restrict__ info, const int store_l) {
+  __shared__ ReducedLds<NX, NU> lds[4];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.x;
+  for (int l = l0; l < d.K; ++l) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));  // (opaque per round: keeps the lane-dependent addresses of the body out of the loop's preheader)
+    if (wave < (d.N >> (l + 1)))
+      reduced_separator_mc<NX, NU, true>(d, l, wave * (2 << l), b, lane, AB, QR, rhs, red, rec, F, info, store_l,
+                                         lds[wave]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pushes and record are acknowledged
+    __syncthreads();
+  }
+}
+
 //   grid (N / 4, batch), block 64; N >= 8; instances with matrix-core products only.
 // TREE: the wavefront does not stop after its level-1 separator. Every separator of level >= 2 has
 // an arrival counter; a wavefront that has finished a subtree bumps the counter of the parent

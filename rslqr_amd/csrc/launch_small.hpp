@@ -98,10 +98,18 @@ static int launch_small(NdlqrHipCtx* c) {
           hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, false>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream,
                              d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, nullptr, compact ? 1 : 0);
       }
-      for (int l = 2; l < d.K && !tree; ++l) {
+      // upper levels: one launch per level while a level has more than four separators per problem, then the
+      // last three levels in one launch (reduced_top_mc; NDLQR_NO_TOP=1: a launch per level to the root)
+      const int ltop = (d.K >= 5 && !c->no_top) ? d.K - 3 : d.K;
+      for (int l = 2; l < ltop && !tree; ++l) {
         ScopedSlot t(c, SLOT_UPPER);
         hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
                            d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+      }
+      if (!tree && ltop < d.K) {
+        ScopedSlot t(c, SLOT_UPPER);
+        hipLaunchKernelGGL((ndlqr::reduced_top_mc<NX, NU>), dim3(d.batch), dim3(256), 0, c->stream, d, ltop, c->AB,
+                           c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
       }
       ScopedSlot t(c, SLOT_APPLY);
       if (compact) {

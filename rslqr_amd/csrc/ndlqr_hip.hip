@@ -104,6 +104,7 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->rowbcast = getenv("NDLQR_ROWBCAST") ? (atoi(getenv("NDLQR_ROWBCAST")) != 0 ? 1 : 0) : -1;  // -1: by block size
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
+  c->no_top = getenv("NDLQR_NO_TOP") != nullptr;
   c->sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS")) : 0;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;

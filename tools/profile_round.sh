@@ -13,18 +13,18 @@ tag=${1:-rXX}
 shift || true
 root=$(pwd)
 export TMPDIR=/tmp
-python3 bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+python3 bench.py --steps 20 --warmup 5 "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "[profile_round] bench done"
 # the profiler passes run the solves strictly stream-ordered: per-kernel durations then are those of the
 # kernel alone (what bench.py's `roofline.kernels` holds), not of two pipelined solves sharing the chip
 export NDLQR_PIPELINE=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o run -- python3 bench.py --no-cpu --no-modes "$@" \
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o run -- python3 bench.py --no-cpu --no-modes --no-configs --no-transfers "$@" \
     > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_stats.err
 echo "[profile_round] kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_fetch -o run -- python3 bench.py --no-cpu --no-modes --steps 2 --warmup 1 "$@" \
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_fetch -o run -- python3 bench.py --no-cpu --no-modes --no-configs --no-transfers --steps 2 --warmup 1 "$@" \
     > /dev/null 2> gpurun_out/${tag}_pmc_fetch.err
 echo "[profile_round] FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_write -o run -- python3 bench.py --no-cpu --no-modes --steps 2 --warmup 1 "$@" \
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmc_write -o run -- python3 bench.py --no-cpu --no-modes --no-configs --no-transfers --steps 2 --warmup 1 "$@" \
     > /dev/null 2> gpurun_out/${tag}_pmc_write.err
 echo "[profile_round] WRITE_SIZE pass done"
 cp $(find gpurun_out/${tag}_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv

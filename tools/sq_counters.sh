@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_VMEM"; do
-  rocprofv3 --pmc $set --output-format csv -d $root/gpurun_out/${tag}_sq_$i -o run -- python3 bench.py --no-cpu --no-modes --spin-up-ms 0 --steps 2 --warmup 1 "$@" \
+  rocprofv3 --pmc $set --output-format csv -d $root/gpurun_out/${tag}_sq_$i -o run -- python3 bench.py --no-cpu --no-modes --no-configs --no-transfers --spin-up-ms 0 --steps 2 --warmup 1 "$@" \
       > /dev/null 2> gpurun_out/${tag}_sq_$i.err || echo "pass $i failed"
   echo "[sq_counters] pass $i done"
   i=$((i+1))
