@@ -278,66 +278,37 @@ __device__ __forceinline__ void store_record_mc(double* __restrict__ myrec, cons
 // block (the couplings). Under the tree schedule the stores are write-through (agent-scope
 // relaxed atomic stores, `sc1`): the reader may sit on another XCD, whose L2 is not coherent with
 // the writer's.
-// put(p, v, old): `old` = the value at p requested ahead of time (PushOld; only AddPlain uses it).
-struct StorePlain {
-  __device__ __forceinline__ void operator()(double* p, double v) const { *p = v; }
-  __device__ __forceinline__ void operator()(double* p, double v, double) const { *p = v; }
-};
+struct StorePlain { __device__ __forceinline__ void operator()(double* p, double v) const { *p = v; } };
 struct StoreThrough {
   __device__ __forceinline__ void operator()(double* p, double v) const {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __device__ __forceinline__ void operator()(double* p, double v, double) const { (*this)(p, v); }
 };
-struct AddAtomic { __device__ __forceinline__ void operator()(double* p, double v, double) const { atomicAdd(p, v); } };
-// Level-per-launch schedule: every accumulator block has exactly ONE writer per launch (a separator has one left and
-// one right neighbour; a neighbour has one adjacent subtree per level and side) and launches are stream-ordered, so
-// the add is a plain read-modify-write whose read was requested with the wavefront's first round of loads (PushOld):
-// no memory-side fp64 atomics, no second exposed round trip.
-struct AddPlain { __device__ __forceinline__ void operator()(double* p, double v, double old) const { *p = old + v; } };
-
-// What push_mc is going to add to, element for element in ITS lane layout (clamped addresses, unconditional loads).
-template <int NX>
-struct PushOld {
-  double a[4], b[4], gl;
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { a[g] = 0.0; b[g] = 0.0; }
-    gl = 0.0;
-  }
-  __device__ __forceinline__ void load(const int lane, const RedSlot<NX>& sa, const RedSlot<NX>& sb) {
-    const int li = lane & 15, lk = lane >> 4, lc = li < NX ? li : NX - 1;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int r = lk + 4 * g, rc = r < NX ? r : NX - 1;
-      a[g] = li < NX ? sa.DR()[rc * NX + li] : sa.gR()[rc];
-      b[g] = sb.DL()[rc * NX + lc];
-    }
-    gl = sb.gL()[lc];
-  }
-};
+// (Round 3 tried plain read-modify-writes in the level-per-launch schedule -- every accumulator block has exactly one
+//  writer per launch -- with the reads requested in the wavefront's first round of loads: same kernel time, 17 % more
+//  HBM traffic in the upper levels than the memory-side atomics, which read nothing. Dropped: DESIGN.md section 7.)
+struct AddAtomic { __device__ __forceinline__ void operator()(double* p, double v) const { atomicAdd(p, v); } };
 
 template <int NX, class Put, class Set>
 __device__ __forceinline__ void push_mc(const int lane, const bool hasA, const bool hasB, const bool leftchild,
                                         const RedSlot<NX>& sa, const RedSlot<NX>& sb, const acc4_t& g00,
                                         const acc4_t& g01, const acc4_t& g11, const acc4_t& pa, const acc4_t& pb01,
-                                        const acc4_t& pb11, Put put, Set set, const PushOld<NX>& po) {
+                                        const acc4_t& pb11, Put put, Set set) {
   const int li = lane & 15, lk = lane >> 4;
   if (hasA && li <= NX) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = lk + 4 * g;
-      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX))
-        put(li < NX ? sa.DR() + r * NX + li : sa.gR() + r, g00[g] + pa[g], po.a[g]);
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) put(li < NX ? sa.DR() + r * NX + li : sa.gR() + r, g00[g] + pa[g]);
     }
   }
   if (hasB && li < NX) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = lk + 4 * g;
-      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) put(sb.DL() + r * NX + li, g11[g] + pb11[g], po.b[g]);
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) put(sb.DL() + r * NX + li, g11[g] + pb11[g]);
     }
-    if (lk == NX % 4) put(sb.gL() + li, g01[NX / 4] + pb01[NX / 4], po.gl);  // row NX of g01: y_z' Y_bb
+    if (lk == NX % 4) put(sb.gL() + li, g01[NX / 4] + pb01[NX / 4]);  // row NX of g01: y_z' Y_bb
     if (hasA) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -443,8 +414,6 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
   const bool leftchild = (base & T) == 0;
   const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
   const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
-  PushOld<NX> pold;  // what the pushes of this separator add to, requested with the first round of loads
-  pold.zero();
 
   // ---- ONE round of coalesced loads into LDS (the slot is contiguous and 16-byte aligned); the
   //      operand fragments are gathered from there. (Knots s and s+1 of a level >= 2 are never the
@@ -475,7 +444,6 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
     for (int it = 0; it < IQ; ++it) { const int e = lane + 64 * it; tq[it] = qr[e < NQ ? e : NQ - 1]; }
 #pragma unroll
     for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it; tr[it] = r0[e < NR ? e : NR - 1]; }
-    if constexpr (!TREE) pold.load(lane, sa, sb);  // (behind the staged operands: vmcnt completes in order)
     // The stores are unconditional, on the same clamped index as the loads (surplus lanes rewrite the
     // last element with its own value): a store under a lane predicate makes the compiler sink the
     // load behind the predicate too, and the loads then complete one after the other.
@@ -524,10 +492,10 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
                             const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
                             if constexpr (TREE)
                               push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
-                                          StoreThrough(), pold);
+                                          StoreThrough());
                             else
-                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddPlain(),
-                                          StorePlain(), pold);
+                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
+                                          StorePlain());
                           }) &&
       lane == 0)
     flag_failure(info, d, b);
@@ -730,18 +698,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   const bool leftchild = (k0 & 4) == 0;
   const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
   const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
-  PushOld<NX> pnone;  // (the bottom levels start the accumulators of a solve: stores, nothing to add to)
-  pnone.zero();
   if (factor_solve_mc<NX>(lane, c_t, rat, rbt, m, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr, X0, X1,
                           [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
                             acc4_t g00, g01, g11;
                             gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
                             if constexpr (TREE)
                               push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
-                                          StoreThrough(), StoreThrough(), pnone);
+                                          StoreThrough(), StoreThrough());
                             else
                               push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
-                                          StorePlain(), StorePlain(), pnone);
+                                          StorePlain(), StorePlain());
                           }) &&
       lane == 0)
     flag_failure(info, d, b);

@@ -51,7 +51,7 @@ def compulsory_bytes(n, m, N):
     return 8 * (inputs_doubles(n, m, N) + N * (2 * n + m))
 
 
-def reduced_model(n, m, N, compact_level0=False, tree=False):
+def reduced_model(n, m, N, compact_level0=False):
     """Separator-only ("reduced") schedule of the size-specialised shapes: bottom kernel (leaf phase +
     tree levels 0, 1), one launch per upper level, back-substitution. Returns
     {slot: {"bytes": per solve, "flops": per solve, "launches": per solve}}."""
@@ -64,10 +64,7 @@ def reduced_model(n, m, N, compact_level0=False, tree=False):
     fs = separator_flops(n, w)
     nsep_upper = max(N // 4 - 1, 0)
     bottom_b = inputs_doubles(n, m, N) + (N // 2) * rec0 + (N // 4) * rec + (N // 4) * push
-    # (since round 3 the pushes of the level-per-launch schedule are plain read-modify-writes -- one writer per
-    #  accumulator block and launch -- instead of memory-side atomic adds: the accumulated blocks are read as well)
-    push_read = 0 if tree else 2 * n * n + 2 * n
-    upper_b = nsep_upper * (slot + n * w + w + n + rows + 2 * n + rec + push + push_read)
+    upper_b = nsep_upper * (slot + n * w + w + n + rows + 2 * n + rec + push)
     recs_read = (N // 2) * rec0 + (N // 4) * rec + nsep_upper * rec
     # back-substitution: every record once, the inputs again, the solution; the compact form adds the
     # multipliers of the top of the tree (written by rb_backsub_top, two read per eight knots)
@@ -166,9 +163,7 @@ def model_for(schedule, n, m, N):
     model for it (strict / KEEP schedules stream the whole factor array: model (B) is their roofline)."""
     if schedule == "reduced":  # compact level-0 records, two-launch back-substitution
         return reduced_model(n, m, N, compact_level0=True)
-    if schedule == "reduced-tree":
-        return reduced_model(n, m, N, tree=True)
-    if schedule == "reduced-records":
+    if schedule in ("reduced-tree", "reduced-records"):
         return reduced_model(n, m, N)
     if schedule == "knot-lean":
         return knot_lean_model(n, m, N)

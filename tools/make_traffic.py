@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (csrc_sha)
 
 SLOTS = [("bottom", ("bottom_reduced_mc", "bottom_small", "rb_bottom")),
-         ("upper", ("reduced_level_mc", "level_small")),
+         ("upper", ("reduced_level_mc", "reduced_top_mc", "level_small")),
          ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_states_generic",
                     "backsub_level0_states_generic")),
          ("leaf", ("leaf_generic",)),
@@ -42,9 +42,12 @@ def main():
     fetch, write = agg(fpath), agg(wpath)
     K = N.bit_length() - 1
     # solves in the profiled process = launches of the once-per-solve kernel
-    once = [c[0] for k, c in fetch.items() if any(s in k for s in ("bottom_", "rb_bottom", "leaf_generic", "backsub_states_generic",
-                                                             "backsub_level0_states_generic"))]
-    solves = max(once) if once else 1
+    # (the two passes are separate processes whose untimed spin-up runs by the clock: each has its own solve count)
+    def count(tab):
+        once = [c[0] for k, c in tab.items() if any(s in k for s in ("bottom_", "rb_bottom", "leaf_generic",
+                                                                     "backsub_states_generic", "backsub_level0_states_generic"))]
+        return max(once) if once else 1
+    solves, solves_w = count(fetch), count(write)
     kernels = {}
     for slot, pats in SLOTS:
         fkb = sum(c[1] for k, c in fetch.items() if any(p in k for p in pats))
@@ -58,8 +61,8 @@ def main():
         kernels[slot] = {"kernels": [k.replace("void ndlqr::", "") for k in fetch if any(p in k for p in pats)],
                          "launches_per_solve": per_solve,
                          "fetch_mb_raw_per_solve": fkb / solves / 1024,
-                         "write_mb_per_solve": wkb / solves / 1024,
-                         "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024 / solves / brackets)}
+                         "write_mb_per_solve": wkb / solves_w / 1024,
+                         "hbm_bytes_per_launch": int((2 * fkb / solves + wkb / solves_w) * 1024 / brackets)}
     json.dump({"tag": tag, "workload": [n, m, N, batch, flags], "csrc_sha": bench.csrc_sha(),
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh)",
                "correction": "FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B read request), WRITE_SIZE as reported; KB -> bytes",
