@@ -525,11 +525,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void re
 // levels goes through global memory like the tree schedule's (write-through pushes, L1-bypassing slot loads,
 // reduced_separator_mc<TREE>): the four wavefronts share a CU, but nothing is assumed about its L1.
 //   grid (batch), block 256; l0 = K - 3 >= 2.
+// ytop != nullptr: the workgroup goes straight on to the top-down sweep over the records of the separators of level
+// >= 3 of its problem (backsub_top_body, kernels_rowbcast.hpp; its [N / 8][NX] array lies over the four scratches:
+// N / 8 * NX doubles <= 4 * sizeof(ReducedLds) is checked on the host) -- one launch and its ~15 us less.
+template <int NX>
+__device__ __forceinline__ void backsub_top_body(const Dims& d, const int b, const int t,
+                                                 const double* __restrict__ recs, double* __restrict__ ytop,
+                                                 double* ytop_lds);
 template <int NX, int NU>
 __global__ __launch_bounds__(256) void reduced_top_mc(Dims d, const int l0, const double* __restrict__ AB,
                                                       const double* __restrict__ QR, const double* __restrict__ rhs,
                                                       double* red, double* __restrict__ rec, double* F,
-                                                      int* __restrict__ info, const int store_l) {
+                                                      int* __restrict__ info, const int store_l,
+                                                      double* __restrict__ ytop) {
   __shared__ ReducedLds<NX, NU> lds[4];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.x;
   for (int l = l0; l < d.K; ++l) {
@@ -541,6 +549,9 @@ __global__ __launch_bounds__(256) void reduced_top_mc(Dims d, const int l0, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pushes and record are acknowledged
     __syncthreads();
   }
+  // (the records of this launch were stored by wavefronts of this workgroup, acknowledged and behind a barrier; nobody
+  //  on this CU has read those lines before: the plain loads of the sweep fetch them from L2)
+  if (ytop) backsub_top_body<NX>(d, b, threadIdx.x, rec, ytop, reinterpret_cast<double*>(&lds[0]));
 }
 
 //   grid (N / 4, batch), block 64; N >= 8; instances with matrix-core products only.

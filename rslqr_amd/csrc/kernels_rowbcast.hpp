@@ -428,11 +428,14 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
 //   lambda_k = y_{k-1}; knot 0: lambda = Q x0 + q + A_0' y_0;
 //   x_k = Q^-1 (-q_k - A_k' y_k + y_{k-1}),  u_k = R^-1 (-r_k - B_k' y_k).
 //   rb_backsub_top: grid (batch), block 256, dynamic LDS (N / 8) * NX doubles; N >= 16.
+// (device function: called by the kernel below and, since round 3, by reduced_top_mc right behind the last tree
+//  level -- the workgroup of a problem's last three levels goes straight on to that problem's top-down sweep)
 template <int NX>
-__global__ __launch_bounds__(256) void rb_backsub_top(Dims d, const double* __restrict__ recs, double* __restrict__ ytop) {
+__device__ __forceinline__ void backsub_top_body(const Dims& d, const int b, const int t,
+                                                 const double* __restrict__ recs, double* __restrict__ ytop,
+                                                 double* ytop_lds) {
   constexpr int NN = NX * NX, REC = 2 * NN + NX;
-  extern __shared__ double ytop_lds[];  // [N / 8][NX]: y of separator 8 j + 7
-  const int N = d.N, K = d.K, b = blockIdx.x, t = threadIdx.x;
+  const int N = d.N, K = d.K;
   for (int L = K - 1; L >= 3; --L) {
     const int T = 2 << L, nsep = N >> (L + 1);
     for (int it = t; it < nsep * NX; it += 256) {
@@ -460,6 +463,12 @@ __global__ __launch_bounds__(256) void rb_backsub_top(Dims d, const double* __re
   }
   double* out = ytop + (size_t)b * (N >> 3) * NX;
   for (int e = t; e < ((N >> 3) - 1) * NX; e += 256) out[e] = ytop_lds[e];
+}
+
+template <int NX>
+__global__ __launch_bounds__(256) void rb_backsub_top(Dims d, const double* __restrict__ recs, double* __restrict__ ytop) {
+  extern __shared__ double ytop_lds[];  // [N / 8][NX]: y of separator 8 j + 7
+  backsub_top_body<NX>(d, blockIdx.x, threadIdx.x, recs, ytop, ytop_lds);
 }
 
 //   rb_backsub: grid (N / 8, batch), block 256; N >= 8.

@@ -106,15 +106,20 @@ static int launch_small(NdlqrHipCtx* c) {
         hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
                            d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
       }
+      // ... which also runs the top-down sweep over the records of level >= 3 when the back-substitution is the
+      // two-launch form and its array fits the workgroup's LDS
+      const bool top_sweeps = !tree && ltop < d.K && compact &&
+                              sizeof(double) * (size_t)(d.N >> 3) * NX <= 4 * sizeof(ndlqr::ReducedLds<NX, NU>);
       if (!tree && ltop < d.K) {
         ScopedSlot t(c, SLOT_UPPER);
         hipLaunchKernelGGL((ndlqr::reduced_top_mc<NX, NU>), dim3(d.batch), dim3(256), 0, c->stream, d, ltop, c->AB,
-                           c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
+                           c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, top_sweeps ? c->ytop : (double*)nullptr);
       }
       ScopedSlot t(c, SLOT_APPLY);
       if (compact) {
-        hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256),
-                           sizeof(double) * (size_t)(d.N >> 3) * NX, c->stream, d, c->rec, c->ytop);
+        if (!top_sweeps)
+          hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256),
+                             sizeof(double) * (size_t)(d.N >> 3) * NX, c->stream, d, c->rec, c->ytop);
         hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
                            c->QR, c->rhs, c->rec, c->ytop, c->z);
       } else {
