@@ -1,8 +1,11 @@
-# per-kernel times of the headline shape against the batch size (developer tool, GPU box):
-# does a batch whose working set fits the 256 MiB Infinity Cache run faster per problem?
-run() { python bench.py --no-cpu --no-modes "$@" 2>/dev/null | python -c "
+# Developer tool (GPU box): per-kernel time per 1024 problems as a function of the batch (does a batch tile whose
+# working set -- ~1.2 MB per (12,4,256) problem: inputs, records, slots, solution -- fits the 256 MiB Infinity Cache
+# run faster per problem? NDLQR_PIPELINE=1: one solve in flight, so a solve's own footprint is all that is live)
+export NDLQR_PIPELINE=1
+for b in 64 128 192 256 512 1024 2048; do
+python bench.py --no-cpu --no-modes --no-configs --no-transfers --steps 40 --batch $b 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']; ks=dict(r['kernels']); ks[r['kernel']]=r
-b=d['config']['batch_per_gpu'] if 'batch_per_gpu' in d['config'] else 0
-print(d['config']['workload'], '| %.0f solves/s, %.4f ms/step | depth1 %.0f |' % (d['value'], d['ms_per_step'], d['pipeline']['value_depth1']), {k: round(v['ms_per_step'],4) for k,v in ks.items()})"; }
-for b in 64 128 192 256 384 512 1024 2048; do run --nx 12 --nu 4 --horizon 256 --batch $b --steps 100; done
+b=$b
+print('batch %5d | %s | %.4f ms/step = %.4f ms per 1024 problems |' % (b, d['config']['schedule'], d['ms_per_step'], d['ms_per_step']*1024/b), {k: round(v['ms_per_step']*1024/b,4) for k,v in sorted(ks.items())})"
+done
