@@ -511,7 +511,9 @@ def main():
         local_rank = 0
     backend = os.environ.get("NDLQR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # (NDLQR_BENCH_FORCE_DIST=1: initialise the process group even for one rank -- exercises the RCCL init, reductions
+    #  and all_gather of the N > 1 path on a one-GPU box: tests/test_sharding_gloo.py::test_bench_rccl_path_one_rank)
+    distributed = world > 1 or bool(os.environ.get("NDLQR_BENCH_FORCE_DIST"))
     if distributed:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

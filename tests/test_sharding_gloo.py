@@ -132,3 +132,29 @@ def test_bench_two_ranks_on_one_gpu():
     assert res["scaling"] == "weak" and res["value"] > 0
     assert res["gather"]["every_rank_found_its_shard_intact"] is True
     assert res["config"]["kkt_residual_rel_max"] <= 1e-9 and res["config"]["cholesky_failures"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_one_rank():
+    """The RCCL calls of the N > 1 path -- process-group init with a device id, barrier, MAX all_reduce on device
+    tensors, all_gather_into_tensor of the packed solutions behind the solver's pack kernel -- executed for real
+    on the one GPU of the test box: one rank under torch.distributed.run with NDLQR_BENCH_FORCE_DIST=1 (a one-rank
+    group: the collectives are trivial, the API usage and stream ordering are not)."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, NDLQR_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--batch", "64", "--no-cpu", "--no-modes", "--no-configs", "--no-transfers", "--spin-up-ms", "5"]
+    proc = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [json.loads(l) for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = lines[0]
+    assert res["n_gpus"] == 1 and res["config"]["ranks_seen"] == 1 and res["config"]["backend"] == "nccl"
+    assert res["gather"]["every_rank_found_its_shard_intact"] is True
+    assert "RCCL" in res["gather"]["collective"]
+    assert res["config"]["kkt_residual_rel_max"] <= 1e-9
