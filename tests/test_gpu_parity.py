@@ -344,13 +344,15 @@ def test_env_variants_fast_mode(ndlqr, oracle):
         assert err <= REL_TOL, (env, err)
 
 
-def test_tree_schedule_fills_the_chip(ndlqr, oracle):
-    """The one-launch tree schedule at a size where its bottom wavefronts (32 x 256 / 4 = 2048) spread
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 256, 32), (6, 3, 256, 48), (13, 4, 512, 24), (7, 9, 256, 40)])
+def test_tree_schedule_fills_the_chip(ndlqr, oracle, n, m, N, batch):
+    """The one-launch tree schedule at sizes where its bottom wavefronts (e.g. 32 x 256 / 4 = 2048) spread
     over all eight XCDs with several wavefronts per SIMD -- the regime its hand-off protocol
     (write-through pushes, s_waitcnt vmcnt(0), relaxed agent-scope arrival counter, L1-bypassing slot
     loads) has to be right in. Two solves per process (the second starts from the counters the first
-    left and reset), every member against the level-per-launch schedule, some against the oracle."""
-    n, m, N, batch, seed = 12, 4, 256, 32, 2100
+    left and reset), every member against the level-per-launch schedule (whose last three levels, reduced_top_mc,
+    use the same hand-off inside a workgroup), some against the oracle. Several block sizes, one of them padded."""
+    seed = 2100
     tree = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "1"})
     flat = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0", "NDLQR_ROWBCAST": "0"})
     rowb = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0", "NDLQR_ROWBCAST": "1"})  # row-broadcast bottom kernel
