@@ -104,6 +104,44 @@ __device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, 
   hook(b0, rb, X0, X1);
 }
 
+// The same for a separator whose record is COMPACT (level 0 of the default schedule): nobody needs X = S-bar^-1 R, only
+// the Schur blocks R' S-bar^-1 R = (W R)'(W R). So Y = W R (the A operand W(li, k) straight from LDS), the hook's Gram
+// products run on Y in both roles (an accumulator tile is at once the A' and the B operand), and the record keeps W
+// itself (packed lower triangle; the back-substitution applies W'(W v)): 15 instead of 18 matrix-core products per
+// separator -- S-bar^-1 = W'W is never formed.
+template <int NX, class Hook>
+__device__ __forceinline__ void factor_tail_y_mc(const int lane, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
+                                                 const double (&rb)[(NX + 3) / 4], const double* Wm, Hook hook,
+                                                 double* wrec) {
+  constexpr int KS = (NX + 3) / 4, WP = McScratch<NX>::WP;
+  int lane_o = lane;
+  asm volatile("" : "+v"(lane_o));
+  const int li = lane_o & 15, lk = lane_o >> 4;
+  double wa[KS], wt[KS], b0[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    wa[q] = Wm[li * WP + 4 * q + lk];    // W(li, k): A operand of Y = W R
+    wt[q] = Wm[(4 * q + lk) * WP + li];  // W(k, li): the record
+    b0[q] = li == NX ? c[q] : ra[q];
+  }
+  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+  acc4_t Y0 = zero, Y1 = zero;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], b0[q], Y0, 0, 0, 0);
+    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], rb[q], Y1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {  // entry (r, c), c <= r, of W at r (r + 1) / 2 + c
+    const int r = 4 * q + lk;
+    if (r < NX && li <= r) wrec[r * (r + 1) / 2 + li] = wt[q];
+  }
+  double y0[KS], y1[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) { y0[q] = Y0[q]; y1[q] = Y1[q]; }
+  hook(y0, y1, Y0, Y1);
+}
+
 template <int NX, class Hook>
 __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
                                                 const double (&rb)[(NX + 3) / 4], McScratch<NX>& m,
@@ -675,29 +713,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   SEG(30);
 
   // ---- s0 (left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
+  // (compact records: the Y form of the tail -- no S-bar^-1, no X; the hooks are the same either way: their Gram
+  //  products take (R, X) or (Y, Y))
   acc4_t park_a, ca_t;
-  factor_tail_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, X0, X1,
-                     [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-                       acc4_t g11;
-                       gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
+  auto hook_s0 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+    acc4_t g11;
+    gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
 #pragma unroll
-                       for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
-                     }, compact0 ? myrec : nullptr);
-  SEG(34);  // re-arms the clock after the core's own marks
-  if (!compact0) store_record_mc<NX>(myrec, lane, hasA, true, X0, X1);
+    for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
+  };
+  if (compact0) {
+    factor_tail_y_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, hook_s0, myrec);
+  } else {
+    factor_tail_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, X0, X1, hook_s0, nullptr);
+    store_record_mc<NX>(myrec, lane, hasA, true, X0, X1);
+  }
   SEG(35);
 
   // ---- s2 (right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
   acc4_t park_b11, cb_t;
-  factor_tail_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, X0, X1,
-                     [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-                       acc4_t g00;
-                       gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
+  auto hook_s2 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+    acc4_t g00;
+    gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
 #pragma unroll
-                       for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
-                     }, compact0 ? myrec + 2 * REC : nullptr);
-  SEG(34);
-  if (!compact0) store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
+    for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
+  };
+  if (compact0) {
+    factor_tail_y_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, hook_s2, myrec + 2 * REC);
+  } else {
+    factor_tail_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, X0, X1, hook_s2, nullptr);
+    store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
+  }
   SEG(35);
   m.init(lane);  // the scratch of t: the pair's tiles lay over the zero rows of its W
 

@@ -489,12 +489,15 @@ struct alignas(16) RbBacksubLds {
   double rs[8][ROWS];     // raw right-hand sides
   double dots[8][NX];     // A_i' y_i of the odd knots (state rows)
   double vs[4][NX];       // v of the four level-0 separators
+  double ts[4][NX];       // W v (compact records that keep W instead of S-bar^-1)
 };
 
 template <int NX, int NU>
 __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                                                   const double* __restrict__ rhs, const double* __restrict__ recs,
-                                                  const double* __restrict__ ytop, double* __restrict__ z) {
+                                                  const double* __restrict__ ytop, double* __restrict__ z,
+                                                  const int rec0_w) {
+  // rec0_w: the compact level-0 records hold W = L^-1 (bottom_reduced_mc: y = W'(W v)) instead of S-bar^-1 (rb_bottom)
   using Lds = RbBacksubLds<NX, NU>;
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP;
   constexpr int R0 = Lds::R0;
@@ -638,7 +641,25 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
     lds.vs[k >> 1][r] = v;
   }
   __syncthreads();
-  if (sep_thread && l == 0) {
+  if (rec0_w) {  // (uniform) t = W v, then y = W' t: W lower triangular, packed by rows
+    if (sep_thread && l == 0) {
+      const double* v = lds.vs[(s - first) >> 1];
+      const double* wr = lds.rec0[(s - first) >> 1] + r * (r + 1) / 2;
+      double a = 0.0;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) a = fma(c <= r ? wr[c <= r ? c : 0] : 0.0, v[c], a);
+      lds.ts[(s - first) >> 1][r] = a;
+    }
+    __syncthreads();
+    if (sep_thread && l == 0) {
+      const double* tv = lds.ts[(s - first) >> 1];
+      const double* w0 = lds.rec0[(s - first) >> 1];
+      double a = 0.0;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) a = fma(c >= r ? w0[c * (c + 1) / 2 + (c >= r ? r : 0)] : 0.0, tv[c], a);
+      lds.ys[q][r] = a;
+    }
+  } else if (sep_thread && l == 0) {
     const double* v = lds.vs[(s - first) >> 1];
     const double* si = lds.rec0[(s - first) >> 1];  // symmetric: row r from the packed lower triangle
     double a = 0.0;
