@@ -178,11 +178,10 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
   // pivot, so ONE test after the last step flags the separator.
   const bool bad = rb_chol_inv<NX>(li, acc, w);
   SEG(30);
-  {  // every lane stores (lanes >= 16 zeros into the pad column): a store under a lane predicate makes the
-     // compiler sink the whole W recurrence behind it
-    const int wc = lane < 16 ? lane : 16;
+  {  // every lane stores its column (the four DPP rows hold identical copies: benign duplicates, no select, and no
+     // store under a lane predicate, which would make the compiler sink the whole W recurrence behind it)
 #pragma unroll
-    for (int r = 0; r < NX; ++r) m.W[r * WP + wc] = lane < 16 ? w[r] : 0.0;
+    for (int r = 0; r < NX; ++r) m.W[r * WP + li] = w[r];
   }
   if (lstore && lane < NX) store_row<NX>(lstore + li * NX, acc);
   wave_lds_sync();
@@ -233,12 +232,11 @@ __device__ __forceinline__ bool chol_pair_mc(const int lane_in, const acc4_t& cA
   }
   const bool bad = rb_chol_inv<NX>(li, acc, w);
   wave_lds_sync();  // (every lane has its row of S-bar: W_B may overwrite tile A)
-  {  // DPP row 0 stores W_A, row 2 W_B (column = lane of the row); rows 1 and 3 zero the pad column of theirs;
-     // unconditional stores (see factor_solve_mc)
-    double* wdst = buf + (lk < 2 ? P::W_A : P::W_B) + ((lk & 1) ? 16 : li);
-    const bool owner = (lk & 1) == 0;
+  {  // rows 0-1 store W_A, rows 2-3 W_B, every lane its column (two identical copies each: benign duplicates;
+     // unconditional stores, see factor_solve_mc)
+    double* wdst = buf + (lk < 2 ? P::W_A : P::W_B) + li;
 #pragma unroll
-    for (int r = 0; r < NX; ++r) wdst[r * WP] = owner ? w[r] : 0.0;
+    for (int r = 0; r < NX; ++r) wdst[r * WP] = w[r];
     // rows NX..15 of both: zero (the tiles that lay here were not)
 #pragma unroll
     for (int e0 = 0; e0 < (16 - NX) * WP; e0 += 32) {
