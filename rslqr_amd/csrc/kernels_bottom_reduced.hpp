@@ -60,8 +60,6 @@ struct alignas(16) McScratch {
   }
 };
 
-template <int NX> __device__ __forceinline__ constexpr bool rows_none_v(int g) { return 4 * g >= NX; }
-
 // c: [S-bar | b~] tile (column NX = rhs). ra / rb: B-operand fragments of r_a / r_bb, i.e.
 // ra[q] = r_a(4 q + lk, li) (any finite value outside the block). On return X0 = [f_a | z_sep],
 // X1 = [f_bb] in accumulator layout. hook(R0, R1, X0, X1) sees the panel fragments and the solution.
@@ -70,7 +68,7 @@ template <int NX> __device__ __forceinline__ constexpr bool rows_none_v(int g) {
 template <int NX, class Hook>
 __device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
                                                const double (&rb)[(NX + 3) / 4], const double* Wm, acc4_t& X0,
-                                               acc4_t& X1, Hook hook, double* sinv_store) {
+                                               acc4_t& X1, Hook hook) {
   constexpr int KS = (NX + 3) / 4, WP = McScratch<NX>::WP;
   int lane_o = lane;  // (opaque: the lane predicates of one core are recomputed, not kept in scalar registers)
   asm volatile("" : "+v"(lane_o));
@@ -88,13 +86,6 @@ __device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, 
   acc4_t Si = zero;
 #pragma unroll
   for (int q = 0; q < KS; ++q) Si = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], wt[q], Si, 0, 0, 0);
-  if (sinv_store) {  // compact level-0 record: S-bar^-1, lower triangle packed (entry (r, c), c <= r, at r (r + 1) / 2 + c)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int r = lk + 4 * g;
-      if (!rows_none_v<NX>(g) && r < NX && li <= r) sinv_store[r * (r + 1) / 2 + li] = Si[g];
-    }
-  }
   X0 = zero; X1 = zero;
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
@@ -145,8 +136,7 @@ __device__ __forceinline__ void factor_tail_y_mc(const int lane, const acc4_t& c
 template <int NX, class Hook>
 __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
                                                 const double (&rb)[(NX + 3) / 4], McScratch<NX>& m,
-                                                double* lstore, acc4_t& X0, acc4_t& X1, Hook hook,
-                                                double* sinv_store = nullptr) {
+                                                double* lstore, acc4_t& X0, acc4_t& X1, Hook hook) {
   constexpr int SP = McScratch<NX>::SP, WP = McScratch<NX>::WP;
   // the lane id is made opaque here so that the lane predicates of one core are recomputed (one
   // v_cmp) instead of being kept in scalar registers across the whole kernel (spills)
@@ -186,7 +176,7 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
   if (lstore && lane < NX) store_row<NX>(lstore + li * NX, acc);
   wave_lds_sync();
   SEG(31);
-  factor_tail_mc<NX>(lane, c, ra, rb, m.W, X0, X1, hook, sinv_store);
+  factor_tail_mc<NX>(lane, c, ra, rb, m.W, X0, X1, hook);
   SEG(33);
   return bad;
 }
@@ -723,7 +713,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   if (compact0) {
     factor_tail_y_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, hook_s0, myrec);
   } else {
-    factor_tail_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, X0, X1, hook_s0, nullptr);
+    factor_tail_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, X0, X1, hook_s0);
     store_record_mc<NX>(myrec, lane, hasA, true, X0, X1);
   }
   SEG(35);
@@ -739,7 +729,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   if (compact0) {
     factor_tail_y_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, hook_s2, myrec + 2 * REC);
   } else {
-    factor_tail_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, X0, X1, hook_s2, nullptr);
+    factor_tail_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, X0, X1, hook_s2);
     store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
   }
   SEG(35);
