@@ -95,44 +95,6 @@ __device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, 
   hook(b0, rb, X0, X1);
 }
 
-// The same for a separator whose record is COMPACT (level 0 of the default schedule): nobody needs X = S-bar^-1 R, only
-// the Schur blocks R' S-bar^-1 R = (W R)'(W R). So Y = W R (the A operand W(li, k) straight from LDS), the hook's Gram
-// products run on Y in both roles (an accumulator tile is at once the A' and the B operand), and the record keeps W
-// itself (packed lower triangle; the back-substitution applies W'(W v)): 15 instead of 18 matrix-core products per
-// separator -- S-bar^-1 = W'W is never formed.
-template <int NX, class Hook>
-__device__ __forceinline__ void factor_tail_y_mc(const int lane, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
-                                                 const double (&rb)[(NX + 3) / 4], const double* Wm, Hook hook,
-                                                 double* wrec) {
-  constexpr int KS = (NX + 3) / 4, WP = McScratch<NX>::WP;
-  int lane_o = lane;
-  asm volatile("" : "+v"(lane_o));
-  const int li = lane_o & 15, lk = lane_o >> 4;
-  double wa[KS], wt[KS], b0[KS];
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    wa[q] = Wm[li * WP + 4 * q + lk];    // W(li, k): A operand of Y = W R
-    wt[q] = Wm[(4 * q + lk) * WP + li];  // W(k, li): the record
-    b0[q] = li == NX ? c[q] : ra[q];
-  }
-  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-  acc4_t Y0 = zero, Y1 = zero;
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], b0[q], Y0, 0, 0, 0);
-    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], rb[q], Y1, 0, 0, 0);
-  }
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {  // entry (r, c), c <= r, of W at r (r + 1) / 2 + c
-    const int r = 4 * q + lk;
-    if (r < NX && li <= r) wrec[r * (r + 1) / 2 + li] = wt[q];
-  }
-  double y0[KS], y1[KS];
-#pragma unroll
-  for (int q = 0; q < KS; ++q) { y0[q] = Y0[q]; y1[q] = Y1[q]; }
-  hook(y0, y1, Y0, Y1);
-}
-
 template <int NX, class Hook>
 __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
                                                 const double (&rb)[(NX + 3) / 4], McScratch<NX>& m,
@@ -236,6 +198,80 @@ __device__ __forceinline__ bool chol_pair_mc(const int lane_in, const acc4_t& cA
   }
   if (lstoreA && lane < NX) store_row<NX>(lstoreA + li * NX, acc);
   if (lstoreB && lane >= 32 && lane < 32 + NX) store_row<NX>(lstoreB + li * NX, acc);
+  wave_lds_sync();
+  return bad;
+}
+
+// The pass for two separators whose records are COMPACT (level 0 of the default schedule): instead of W = L^-1 (the
+// forward substitution of the unit vectors) the lanes carry the panel itself, one column each -- half h = lane & 31 of
+// DPP rows 0-1 (separator A) / 2-3 (B): h < NX column h of r_a, h == NX the rhs column b~, NX < h <= 2 NX column
+// h - NX - 1 of r_bb -- and leave the pass with Y = L^-1 [r_a | b~ | r_bb]: the six matrix-core products Y = W R of a
+// level-0 separator and the LDS round trip of W disappear, the Gram hooks read Y from LDS tiles (Y0 = L^-1 [r_a | b~],
+// Y1 = L^-1 r_bb, rows = k, pitch 17), and the compact record keeps L itself (packed lower triangle, row i by lane i;
+// rb_backsub substitutes with it).  w: in = this lane's panel column (the b~ lanes: anything), out = its column of Y.
+// LDS: S-bar tiles A | B at buf[0, 576); then the four Y tiles of 4 KS rows over them.
+template <int NX>
+struct McPairYLayout {
+  static constexpr int SP = McScratch<NX>::SP, KS = (NX + 3) / 4, YP = 17, TILE = 4 * KS * YP;
+  static constexpr int SCR_A = 0, SCR_B = 16 * SP;
+  static constexpr int SIZE = 4 * TILE > 32 * SP ? 4 * TILE : 32 * SP;
+  // tile t of separator x (x: 0 = A, 1 = B; t: 0 = Y0, 1 = Y1)
+  static constexpr int tile(const int x, const int t) { return (2 * x + t) * TILE; }
+};
+template <int NX>
+__device__ __forceinline__ bool chol_pair_y_mc(const int lane_in, const acc4_t& cA, const acc4_t& cB, double* buf,
+                                               double (&w)[NX], double* lrecA, double* lrecB) {
+  using P = McPairYLayout<NX>;
+  constexpr int SP = P::SP, YP = P::YP, KS = P::KS;
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  const int li = lane & 15, lk = lane >> 4, h = lane & 31;
+  const int ri = li < NX ? li : NX - 1;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    buf[P::SCR_A + (lk + 4 * g) * SP + li] = cA[g];
+    buf[P::SCR_B + (lk + 4 * g) * SP + li] = cB[g];
+  }
+  wave_lds_sync();
+  const double* tile = buf + (lk < 2 ? P::SCR_A : P::SCR_B);
+  double acc[NX];
+  if constexpr (NX % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < NX; j += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(&tile[ri * SP + j]);
+      acc[j] = t.x; acc[j + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) acc[j] = tile[ri * SP + j];
+  }
+  if (h == NX) {  // the rhs column of the tile (plain loads under a lane predicate: no cross-lane operation inside)
+#pragma unroll
+    for (int k = 0; k < NX; ++k) w[k] = tile[k * SP + NX];
+  }
+  const bool bad = rb_chol_inv<NX, false>(li, acc, w);
+  wave_lds_sync();  // (every lane has its row of S-bar and the rhs column: the Y tiles may overwrite the S-bar tiles)
+  {
+    const int x = lk >> 1;
+    // column h of Y0 (h <= NX), column h - NX - 1 of Y1 (h <= 2 NX); the idle lanes dump into the pad column of Y1
+    double* ydst = buf + (h <= NX ? P::tile(x, 0) + h : P::tile(x, 1) + (h <= 2 * NX ? h - NX - 1 : YP - 1));
+#pragma unroll
+    for (int k = 0; k < NX; ++k) ydst[k * YP] = w[k];
+    if constexpr (4 * KS > NX) {  // rows NX .. 4 KS - 1 of the tiles are read by the last k-step: zero
+#pragma unroll
+      for (int e0 = 0; e0 < (4 * KS - NX) * YP; e0 += 16) {
+        const int e = e0 + li;
+        if (e < (4 * KS - NX) * YP) buf[P::tile(x, lk & 1) + NX * YP + e] = 0.0;
+      }
+    }
+  }
+  // the record: row li of L (entries 0 .. li) by lane li of DPP rows 0 (A) and 2 (B)
+  if ((lk & 1) == 0 && li < NX) {
+    double* lr = (lk == 0 ? lrecA : lrecB) + li * (li + 1) / 2;
+#pragma unroll
+    for (int c = 0; c < NX; ++c)
+      if (c <= li) lr[c] = acc[c];
+  }
   wave_lds_sync();
   return bad;
 }
@@ -402,8 +438,10 @@ struct alignas(16) ReducedLds {
   static constexpr int SLOT = RedSlot<NX>::SIZE, NSC = (int)(sizeof(McScratch<NX>) / 8);
   static constexpr int NB0 = 4 * NX * WP, NB1 = SLOT + NX * WP;
   static constexpr int NB2 = McPairLayout<NX>::SIZE;  // the paired Cholesky of the bottom levels
+  static constexpr int NB3 = McPairYLayout<NX>::SIZE;  // ... and its compact-record form (Y tiles)
   static constexpr int NB01 = (NB0 > NB1 ? NB0 : NB1) > NSC ? (NB0 > NB1 ? NB0 : NB1) : NSC;
-  static constexpr int NBUF = NB01 > NB2 ? NB01 : NB2;
+  static constexpr int NB23 = NB2 > NB3 ? NB2 : NB3;
+  static constexpr int NBUF = NB01 > NB23 ? NB01 : NB23;
   double buf[NBUF];
   double rq[4 * W];
   double rh[4 * ROWS];
@@ -673,6 +711,63 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   acc4_t c_t = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + NX * WP, rq + W, rq + 2 * W, rh + ROWS, rh + 2 * ROWS, none);
   acc4_t c_s2 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + 2 * NX * WP, rq + 2 * W, rq + 3 * W, rh + 2 * ROWS,
                                          rh + 3 * ROWS, none);
+  acc4_t X0, X1, unused;
+  double* myrec = rec + ((size_t)b * N + k0) * REC;
+  // what the two level-0 separators hand to t and to the neighbours of the group (the Gram products take (R, X) or,
+  // for compact records, (Y, Y))
+  acc4_t park_a, ca_t, park_b11, cb_t;
+  auto hook_s0 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+    acc4_t g11;  // s0 (left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
+    gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
+  };
+  auto hook_s2 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+    acc4_t g00;  // s2 (right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
+    gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
+  };
+
+  if (compact0) {
+    // ---- compact records: the panel columns ride through the Cholesky pass, one per lane (chol_pair_y_mc)
+    double wcol[NX];
+    {
+      const int h = lane & 31, x = lane >> 5;  // x = 0: s0 (knots k0, k0 + 1), 1: s2 (knots k0 + 2, k0 + 3)
+      const bool is_a = h < NX, is_b = h > NX && h <= 2 * NX;
+      const int ca = is_a ? h : 0, cb = is_b ? h - NX - 1 : 0;
+      // r_a(k, ca) = -A_s(k, ca) / Q_s(ca): column ca of [A_s | B_s], stride WP, one weight;
+      // r_bb(k, cb) = -A_{s+1}(cb, k) / Q_{s+1}(k): row cb of [A_{s+1} | B_{s+1}], stride 1, weight k
+      const double* src = abs_ + (2 * x) * NX * WP + (is_a ? ca : NX * WP + cb * WP);
+      const double* scl = rq + (2 * x) * W + (is_a ? ca : W);
+      const int sstr = is_a ? WP : 1, wstr = is_a ? 0 : 1;
+      const bool on = (is_a && (x == 1 || hasA)) || (is_b && (x == 0 || hasB));
+      const double sign = on ? -1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) wcol[k] = (src[k * sstr] * scl[k * wstr]) * sign;
+    }
+    wave_lds_sync();  // last read of the staged [A | B]
+    SEG(21);
+    if (chol_pair_y_mc<NX>(lane, c_s0, c_s2, lds.buf, wcol, myrec, myrec + 2 * REC) && (lane == 0 || lane == 32))
+      flag_failure(info, d, b);
+    SEG(30);
+    using PY = McPairYLayout<NX>;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const double* Y0 = lds.buf + PY::tile(x, 0);
+      const double* Y1 = lds.buf + PY::tile(x, 1);
+      double y0[KSN], y1[KSN];
+      acc4_t Z0 = {0.0, 0.0, 0.0, 0.0}, Z1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < KSN; ++q) {
+        y0[q] = Y0[(4 * q + lk) * PY::YP + li];
+        y1[q] = Y1[(4 * q + lk) * PY::YP + li];
+        Z0[q] = y0[q]; Z1[q] = y1[q];
+      }
+      if (x == 0) hook_s0(y0, y1, Z0, Z1); else hook_s2(y0, y1, Z0, Z1);
+    }
+    SEG(35);
+  } else {
   // operand fragments of the couplings: r_a(i, j) = -A_s(i, j) / Q_s(j), r_bb(i, j) = -A_{s+1}(j, i) / Q_{s+1}(i)
   double ra0[KSN], rb0[KSN], ra2[KSN], rb2[KSN];
 #pragma unroll
@@ -689,9 +784,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   wave_lds_sync();  // last read of the staged [A | B]
   SEG(21);
 
-  acc4_t X0, X1, unused;
-  double* myrec = rec + ((size_t)b * N + k0) * REC;
-
   // ---- Cholesky + inverse of the two level-0 separators s0 = k0 and s2 = k0 + 2 in ONE pass (DPP rows 0-1 / 2-3)
   using Pair = McPairLayout<NX>;
   if (chol_pair_mc<NX>(lane, c_s0, c_s2, lds.buf, store_l ? Fblk(F, d, b, 0, k0 + 1) : nullptr,
@@ -699,40 +791,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
       (lane == 0 || lane == 32))
     flag_failure(info, d, b);
   SEG(30);
-
-  // ---- s0 (left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
-  // (compact records: the Y form of the tail -- no S-bar^-1, no X; the hooks are the same either way: their Gram
-  //  products take (R, X) or (Y, Y))
-  acc4_t park_a, ca_t;
-  auto hook_s0 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-    acc4_t g11;
-    gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
-  };
-  if (compact0) {
-    factor_tail_y_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, hook_s0, myrec);
-  } else {
-    factor_tail_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, X0, X1, hook_s0);
-    store_record_mc<NX>(myrec, lane, hasA, true, X0, X1);
-  }
+  factor_tail_mc<NX>(lane, c_s0, ra0, rb0, lds.buf + Pair::W_A, X0, X1, hook_s0);
+  store_record_mc<NX>(myrec, lane, hasA, true, X0, X1);
+  factor_tail_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, X0, X1, hook_s2);
+  store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
   SEG(35);
-
-  // ---- s2 (right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
-  acc4_t park_b11, cb_t;
-  auto hook_s2 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-    acc4_t g00;
-    gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
-  };
-  if (compact0) {
-    factor_tail_y_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, hook_s2, myrec + 2 * REC);
-  } else {
-    factor_tail_mc<NX>(lane, c_s2, ra2, rb2, lds.buf + Pair::W_B, X0, X1, hook_s2);
-    store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
   }
-  SEG(35);
   m.init(lane);  // the scratch of t: the pair's tiles lay over the zero rows of its W
 
   // ---- t = k0 + 1 (level 1): r_a = -CA[t] = -Y_bb'Y_a of s0, r_bb = -CB[t] = -Y_a'Y_bb of s2;

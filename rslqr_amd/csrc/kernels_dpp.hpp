@@ -75,11 +75,15 @@ __device__ __forceinline__ void dpp_fence(double (&x)[N]) {
 // step, a chain of j dependent FMAs in front of the pivot chain: the kernels that use this are bound by the
 // dependent-instruction latency of a wavefront at 3-4 wavefronts per SIMD, not by issue slots. Every element still
 // receives the same products in the same order (k ascending): results are bit-identical to the left-looking form.
-template <int NX>
+// UNIT = false: w comes in as ANY right-hand-side column (one per lane) and leaves as L^-1 times it -- the forward
+// substitution of a panel column rides on the factorisation exactly like that of a unit vector.
+template <int NX, bool UNIT = true>
 __device__ __forceinline__ bool rb_chol_inv(const int i, double (&acc)[NX], double (&w)[NX]) {
   bool bad = false;
+  if constexpr (UNIT) {
 #pragma unroll
-  for (int k = 0; k < NX; ++k) w[k] = (k == i) ? 1.0 : 0.0;
+    for (int k = 0; k < NX; ++k) w[k] = (k == i) ? 1.0 : 0.0;
+  }
   // 1 / sqrt(pivot): hardware estimate + one Newton step (a few ulp; see factor_solve_mc)
   auto rsqrt_newton = [](const double pivot) {
     const double y0 = __builtin_amdgcn_rsq(pivot);

@@ -489,15 +489,14 @@ struct alignas(16) RbBacksubLds {
   double rs[8][ROWS];     // raw right-hand sides
   double dots[8][NX];     // A_i' y_i of the odd knots (state rows)
   double vs[4][NX];       // v of the four level-0 separators
-  double ts[4][NX];       // W v (compact records that keep W instead of S-bar^-1)
 };
 
 template <int NX, int NU>
 __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                                                   const double* __restrict__ rhs, const double* __restrict__ recs,
                                                   const double* __restrict__ ytop, double* __restrict__ z,
-                                                  const int rec0_w) {
-  // rec0_w: the compact level-0 records hold W = L^-1 (bottom_reduced_mc: y = W'(W v)) instead of S-bar^-1 (rb_bottom)
+                                                  const int rec0_l) {
+  // rec0_l: the compact level-0 records hold the Cholesky factor L of S-bar (bottom_reduced_mc) instead of S-bar^-1 (rb_bottom)
   using Lds = RbBacksubLds<NX, NU>;
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP;
   constexpr int R0 = Lds::R0;
@@ -641,23 +640,37 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
     lds.vs[k >> 1][r] = v;
   }
   __syncthreads();
-  if (rec0_w) {  // (uniform) t = W v, then y = W' t: W lower triangular, packed by rows
-    if (sep_thread && l == 0) {
-      const double* v = lds.vs[(s - first) >> 1];
-      const double* wr = lds.rec0[(s - first) >> 1] + r * (r + 1) / 2;
-      double a = 0.0;
+  if (rec0_l) {  // (uniform) the records hold the Cholesky factor L of S-bar (packed rows): y = L^-T (L^-1 v)
+    if (t < 64) {
+      // wavefront 0: the four level-0 separators of the tile in its four DPP rows, row r of L per lane; both
+      // substitutions broadcast the freshly resolved entry inside the row (v_mov_b64_dpp row_newbcast): no LDS
+      // round trip and no barrier per step. (All 64 lanes run it -- DPP needs them active --, lanes r >= NX idle.)
+      const int j = t >> 4, r15 = t & 15, rc = r15 < NX ? r15 : NX - 1;
+      const double* Lp = lds.rec0[j];
+      const double dinv = 1.0 / Lp[rc * (rc + 1) / 2 + rc];
+      double lrow[NX], lcol[NX];
 #pragma unroll
-      for (int c = 0; c < NX; ++c) a = fma(c <= r ? wr[c <= r ? c : 0] : 0.0, v[c], a);
-      lds.ts[(s - first) >> 1][r] = a;
-    }
-    __syncthreads();
-    if (sep_thread && l == 0) {
-      const double* tv = lds.ts[(s - first) >> 1];
-      const double* w0 = lds.rec0[(s - first) >> 1];
-      double a = 0.0;
-#pragma unroll
-      for (int c = 0; c < NX; ++c) a = fma(c >= r ? w0[c * (c + 1) / 2 + (c >= r ? r : 0)] : 0.0, tv[c], a);
-      lds.ys[q][r] = a;
+      for (int c = 0; c < NX; ++c) {
+        const double lo = Lp[rc * (rc + 1) / 2 + (c < rc ? c : rc)];  // L(r, c), c < r
+        const double up = Lp[(c > rc ? c : rc) * ((c > rc ? c : rc) + 1) / 2 + rc];  // L(c, r), c > r
+        lrow[c] = (c < r15 && r15 < NX) ? lo : 0.0;
+        lcol[c] = (c > r15 && r15 < NX) ? up : 0.0;
+      }
+      double x = lds.vs[j][rc];
+      sfor<NX>([&](auto cc) {  // forward: t_c = x_c / L(c, c) is final when step c starts
+        constexpr int c = decltype(cc)::value;
+        double xs = x * dinv;
+        dpp_fence(xs);
+        x = fma(-lrow[c], row_bc<c>(xs), x);
+      });
+      x = x * dinv;  // t_r
+      sfor<NX>([&](auto cc) {  // backward, c descending: y_c is final when its step starts
+        constexpr int c = NX - 1 - decltype(cc)::value;
+        double xs = x * dinv;
+        dpp_fence(xs);
+        x = fma(-lcol[c], row_bc<c>(xs), x);
+      });
+      if (r15 < NX) lds.ys[2 * j][r15] = x * dinv;
     }
   } else if (sep_thread && l == 0) {
     const double* v = lds.vs[(s - first) >> 1];
