@@ -729,7 +729,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
     for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
   };
 
-  if (compact0) {
+  // (the tree schedule never asks for compact records: its instantiation does not carry that path)
+  const bool compact_path = !TREE && compact0 != 0;
+  if (!TREE && compact_path) {
     // ---- compact records: the panel columns ride through the Cholesky pass, one per lane (chol_pair_y_mc)
     double wcol[NX];
     {
