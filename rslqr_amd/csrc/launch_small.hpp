@@ -53,8 +53,10 @@ static SmallPlan plan_small(const NdlqrHipCtx* c) {
       // row-broadcast bottom kernel (one DPP row holds the rows of S-bar and of [A | B]'): its cost falls
       // with the block size, the matrix-core kernel's does not (16x16 tiles whatever n is). Measured bottom
       // kernel, N = 256 x 1024: (6,3) 0.105 vs 0.170 ms, (8,4) 0.144 vs 0.190, (9,3) 0.202 vs 0.244,
-      // (10,4) 0.230 vs 0.271, (12,4) 0.301 vs 0.290 -- so it serves n <= 10 (NDLQR_ROWBCAST=0/1 overrides)
-      p.rowbcast = p.compact && NX <= 16 && NX + NU <= 16 && (c->rowbcast == 1 || (c->rowbcast < 0 && NX <= 10));
+      // (10,4) 0.230 vs 0.271, (12,4) 0.301 vs 0.290 in round 2. Round 3 (paired Cholesky pass that carries the panel):
+      // (10,4) 0.230 vs 0.207, (9,3) 0.203 vs 0.187, (8,4) 0.143 vs 0.152, (6,3) 0.104 vs 0.134 -- so it serves n <= 8
+      // (NDLQR_ROWBCAST=0/1 overrides)
+      p.rowbcast = p.compact && NX <= 16 && NX + NU <= 16 && (c->rowbcast == 1 || (c->rowbcast < 0 && NX <= 8));
     }
   }
   // the separator-only schedule touches F only to park the factors of KEEP_RECORDS
