@@ -27,7 +27,7 @@ int ndlqr_hip_ensure_F(NdlqrHipCtx* c);
 
 // ------------------------------------------------------------------------------ context
 
-enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_BOUNDARY, SLOT_APPLY, SLOT_BOTTOM, SLOT_UPPER, SLOT_COUNT };
+enum { SLOT_LEAF = 0, SLOT_SEP, SLOT_SCHUR, SLOT_BOUNDARY, SLOT_APPLY, SLOT_BOTTOM, SLOT_UPPER, SLOT_TOP, SLOT_COUNT };
 
 struct PendingEvent {
   int slot;

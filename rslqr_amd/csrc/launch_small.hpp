@@ -115,7 +115,7 @@ static int launch_small(NdlqrHipCtx* c) {
       const bool top_sweeps = !tree && ltop < d.K && compact &&
                               sizeof(double) * (size_t)(d.N >> 3) * NX <= 4 * sizeof(ndlqr::ReducedLds<NX, NU>);
       if (!tree && ltop < d.K) {
-        ScopedSlot t(c, SLOT_UPPER);
+        ScopedSlot t(c, SLOT_TOP);  // (a profile slot of its own: one kernel name per slot, like rocprofv3's per-kernel averages)
         hipLaunchKernelGGL((ndlqr::reduced_top_mc<NX, NU>), dim3(d.batch), dim3(256), 0, c->stream, d, ltop, c->AB,
                            c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, top_sweeps ? c->ytop : (double*)nullptr);
       }

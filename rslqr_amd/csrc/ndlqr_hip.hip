@@ -39,7 +39,7 @@ int ndlqr_hip_device_count(void) {
   return count;
 }
 
-static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom", "upper"};
+static const char* kSlotNames[SLOT_COUNT] = {"leaf", "separator", "schur", "schur_boundary", "apply", "bottom", "upper", "top"};
 
 static bool has_small_instance(int nstates, int ninputs);  // defined with the instance table below
 static void pick_pad_instance(int nstates, int ninputs, int* pn, int* pm);

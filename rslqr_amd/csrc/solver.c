@@ -272,7 +272,8 @@ int ndlqr_Solve(NdLqrSolver* solver) {
     int launches = 0;
     if (ndlqr_hip_profile_get(ctx, sl, name, (int)sizeof(name), &ms, &launches) != 0) continue;
     if (strncmp(name, "leaf", 4) == 0 || strncmp(name, "bottom", 6) == 0) solver->profile.t_leaves_ms += ms;
-    else if (strncmp(name, "separator", 9) == 0 || strncmp(name, "upper", 5) == 0) solver->profile.t_products_ms += ms;
+    else if (strncmp(name, "separator", 9) == 0 || strncmp(name, "upper", 5) == 0 || strncmp(name, "top", 3) == 0)
+      solver->profile.t_products_ms += ms;
     else solver->profile.t_shur_ms += ms;
   }
   solver->profile.t_total_ms = wall_ms() - t0;

@@ -75,6 +75,19 @@ def reduced_model(n, m, N, compact_level0=False):
     }
     if K > 2:
         out["upper"] = {"bytes": 8 * upper_b, "flops": nsep_upper * fs, "launches": K - 2}
+    if K >= 5 and compact_level0:
+        # round 3: the last three levels (7 separators) run in ONE launch (reduced_top_mc, profile slot "top") together
+        # with the top-down sweep of the back-substitution over the records of level >= 3 (N / 8 - 1 of them, written
+        # into ytop): their bytes and flops move from "upper" / "apply" to "top"
+        per_sep = upper_b // nsep_upper
+        sweep_b = (N // 8 - 1) * rec + (N // 8) * n
+        sweep_f = (N // 8 - 1) * 4 * n * n
+        out["top"] = {"bytes": 8 * (7 * per_sep + sweep_b), "flops": 7 * fs + sweep_f, "launches": 1}
+        out["upper"] = {"bytes": 8 * (nsep_upper - 7) * per_sep, "flops": (nsep_upper - 7) * fs, "launches": K - 5}
+        out["apply"] = {"bytes": out["apply"]["bytes"] - 8 * sweep_b, "flops": out["apply"]["flops"] - sweep_f,
+                        "launches": 1}
+        if nsep_upper == 7:
+            del out["upper"]
     return out
 
 

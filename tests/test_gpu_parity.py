@@ -830,3 +830,27 @@ def test_padded_shapes(ndlqr, oracle, n, m, N, batch, monkeypatch):
     one.initialize_flat(*[np.asarray(a)[None] for a in (bad.A, bad.B, bad.Q, R, bad.q, bad.r, bad.d, bad.x0)])
     assert one.solve() == -3 and one.cholesky_failures() >= 1
     one.close()
+
+
+@pytest.mark.parametrize("n,m", [(12, 4), (13, 4), (15, 2), (12, 8), (8, 16), (9, 3), (10, 4), (6, 3), (8, 4), (14, 2),
+                                 (11, 3), (7, 9)])
+def test_level_per_launch_schedule_every_instance(ndlqr, oracle, n, m):
+    """The level-per-launch separator-only schedule (compact level-0 records: the panel rides through the paired
+    Cholesky pass of the matrix-core bottom kernel -- row-broadcast kernel up to 8 states --, L or S-bar^-1 in the
+    record, the DPP substitution of rb_backsub, the last three levels + top-down sweep in one launch) at a batch
+    that selects it, for every size-specialised instance incl. the buckets and three padded block sizes: three
+    members against the oracle, every member's KKT residual on the device."""
+    N, batch = 64, 160  # 160 x 16 = 2560 bottom wavefronts: beyond the tree schedule's range
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_synthetic(31000)
+    for _ in range(3):
+        assert bs.solve() == 0
+    assert bs.schedule() == "reduced"
+    sol = bs.solutions()
+    res, bn = bs.kkt_residuals()
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    for p in (0, 77, batch - 1):
+        prob = synth(ndlqr, n, m, N, 31000 + p)
+        ref = oracle.solve(prob, 1)[0][: prob.nvars]
+        assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL, (n, m, p)
+    bs.close()

@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (csrc_sha)
 
 SLOTS = [("bottom", ("bottom_reduced_mc", "bottom_small", "rb_bottom")),
-         ("upper", ("reduced_level_mc", "reduced_top_mc", "level_small")),
+         ("upper", ("reduced_level_mc", "level_small")),
+         ("top", ("reduced_top_mc",)),
          ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_states_generic",
                     "backsub_level0_states_generic")),
          ("leaf", ("leaf_generic",)),
