@@ -92,6 +92,80 @@ __device__ __forceinline__ int tri_row(const int t) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------- block substitutions (vector ALU)
+// One block step of L v = t (forward) or L'y = v (backward) for ONE vector, by ONE wavefront, with what the blocked
+// Cholesky leaves behind: Lo(i, k) = L(i, k) for (i, k) in different 16-blocks (i > k), Di(i, k) = entry (i, k) of the
+// inverse of the diagonal block that holds both (i >= k). Lane = (row r of the block, quarter `seg` of the summation
+// index); `vec` (LDS, n entries) holds the right-hand side and receives the solution block by block; `tmp`: 16 doubles
+// of LDS. n need not be a multiple of 16 (the last block is then short). The wavefront's own LDS accesses complete in
+// order; the fences only keep the compiler from moving them across.
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+template <class LoAt, class DiAt>
+__device__ __forceinline__ void tri_forward_block(const int ib, const int n, double* vec, double* tmp, const int lane,
+                                                  LoAt Lo, DiAt Di) {
+  const int r = lane >> 2, seg = lane & 3, i = 16 * ib + r, ic = i < n ? i : n - 1;
+  double acc = 0.0;
+  for (int k0 = 0; k0 < 16 * ib; k0 += 16) {
+    double lv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { lv[u] = Lo(ic, k0 + seg + 4 * u); vv[u] = vec[k0 + seg + 4 * u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fma(lv[u], vv[u], acc);
+  }
+  const double t = vec[ic] - quad_sum(acc);
+  if (seg == 0) tmp[r] = t;
+  wave_lds_order();
+  double a2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = seg + 4 * u, cc = c <= r ? c : r;
+    const int col = 16 * ib + cc < ic ? 16 * ib + cc : ic;
+    a2 = fma(c <= r ? Di(ic, col) : 0.0, tmp[cc], a2);
+  }
+  a2 = quad_sum(a2);
+  if (seg == 0 && i < n) vec[i] = a2;
+  wave_lds_order();
+}
+template <class LoAt, class DiAt>
+__device__ __forceinline__ void tri_backward_block(const int ib, const int n, double* vec, double* tmp, const int lane,
+                                                   LoAt Lo, DiAt Di) {
+  const int r = lane >> 2, seg = lane & 3, i = 16 * ib + r, ic = i < n ? i : n - 1;
+  double acc = 0.0;
+  for (int k0 = 16 * (ib + 1); k0 < n; k0 += 16) {
+    double lv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + seg + 4 * u, kc = k < n ? k : n - 1;
+      lv[u] = Lo(kc, ic);
+      vv[u] = k < n ? vec[kc] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fma(lv[u], vv[u], acc);
+  }
+  const double t = vec[ic] - quad_sum(acc);
+  if (seg == 0) tmp[r] = t;
+  wave_lds_order();
+  double a2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = seg + 4 * u;
+    const bool ok = c >= r && 16 * ib + c < n;
+    const int cc = ok ? c : r, row = ok ? 16 * ib + c : ic;
+    a2 = fma(ok ? Di(row, ic) : 0.0, tmp[cc], a2);
+  }
+  a2 = quad_sum(a2);
+  if (seg == 0 && i < n) vec[i] = a2;
+  wave_lds_order();
+}
+
 // wavefronts per SIMD the register budget is cut for: what LDS lets share a CU (two-round mode at n = 48, 64: three or
 // four workgroups of NB wavefronts)
 constexpr int reduced_min_waves(const int nb, const int nthr) { return (nthr == 64 * nb && nb >= 3) ? 3 : 4; }
@@ -305,9 +379,15 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   __syncthreads();
   SEG(52);
 
-  sep_cholesky(geo, S, Wd, info, d, b);
+  // ---- blocked Cholesky; beside it the second wavefront takes the right-hand-side column through the forward
+  //      substitution, a block behind: y~ = L^-1 b~ (in place over b~)
+  auto Lo = [&](const int i, const int k) -> double { return S[i * ns + k]; };
+  auto Di = [&](const int i, const int k) -> double { return Wd[(i >> 4) * 16 * 17 + (i & 15) * 17 + (k & 15)]; };
+  sep_cholesky(geo, S, Wd, info, d, b, [&](const int jb) {
+    if (jb > 0) tri_forward_block(jb - 1, n, bz, zc, lane, Lo, Di);
+  });
   SEG(53);
-  // the column tile(s) of [r_a | r_bb] this wavefront will solve: requested here, consumed behind the inverse
+  // the column tile(s) of [r_a | r_bb] this wavefront will solve: requested here, consumed behind the last block of y~
   // (not before the Cholesky: its diagonal-block wavefront needs the registers, and a spilled load waits)
   double rfk[MAXT][NB][4];  // element (16 kb + 4 q + lk, 16 c + li) of r_a / r_bb (raw operand until phase B)
 #pragma unroll
@@ -324,83 +404,52 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
         else rfk[m][kb][q] = LEVEL0 ? ab1[(size_t)j * w + k] : myslot[3 * nnl + k * nl + j];
       }
   }
-
-  sep_invert(geo, S, Wd);
-  SEG(54);
-  if (wfac) {  // NDLQR_FLAG_KEEP_RECORDS: W = L^-1 (strictly lower blocks in S, diagonal blocks in Wd) for rhs-only re-solves
+  if (wfac) {  // NDLQR_FLAG_KEEP_RECORDS: L (strictly lower blocks in S) and the inverses of its diagonal blocks (Wd)
     constexpr int WF = reduced_wfac_doubles(n);
     double* wf = wfac + ((size_t)b * N + s) * WF;
     for (int e = tid; e < WF; e += NTHR) wf[e] = S[e];  // (S and Wd are contiguous)
   }
   if constexpr (LEVEL0) {
-    // compact level-0 record: W, lower triangle packed with the problem's own size (entry (i, k), k <= i, at
-    // i (i + 1) / 2 + k), instead of f_a | f_bb -- a quarter of the bytes; the back-substitution of level 0
-    // (backsub_level0_states_generic) forms f_a y_A + f_bb y_B = W'W (r_a y_A + r_bb y_B) from the problem data it
-    // reads anyway. A row per wavefront and round.
+    // compact level-0 record: L with the inverses of its diagonal blocks in their place, lower triangle packed with
+    // the problem's own size (entry (i, k), k <= i, at i (i + 1) / 2 + k), instead of f_a | f_bb -- a quarter of the
+    // bytes; the back-substitution of level 0 (backsub_level0_states_generic) forms f_a y_A + f_bb y_B =
+    // S-bar^-1 (r_a y_A + r_bb y_B) from the problem data it reads anyway. A row per wavefront and round.
     for (int i = wave; i < nl; i += NW) {
       double* dst = myrec + (size_t)i * (i + 1) / 2;
       for (int k = lane; k <= i; k += 64)
         dst[k] = (i >> 4) == (k >> 4) ? Wd[(i >> 4) * 16 * 17 + (i & 15) * 17 + (k & 15)] : S[i * ns + k];
     }
   }
-  // ---- z_sep = W'(W b~) on the vector ALU, all wavefronts: eight rows per wavefront, eight lanes per row (a
-  //      seventeenth column does not pay a matrix-core tile, and one wavefront alone would keep the others waiting)
-  auto w_ptr = [&](const int r, const int cidx) -> const double* {  // &W(r, cidx), cidx <= r
-    return (r >> 4) == (cidx >> 4) ? Wd + (r >> 4) * 16 * 17 + (r & 15) * 17 + (cidx & 15) : S + r * ns + cidx;
-  };
-  for (int i0 = 8 * wave; i0 < n; i0 += 8 * NW) {  // y = W b~
-    const int i = i0 + (lane >> 3), sg = lane & 7;
-    double wv[n / 8], bv[n / 8];
-#pragma unroll
-    for (int u = 0; u < n / 8; ++u) {
-      const int k = sg + 8 * u, kk = k <= i ? k : i;  // (above the diagonal: a valid address, weight zero)
-      wv[u] = *w_ptr(i, kk);
-      bv[u] = bz[k];
-    }
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < n / 8; ++u) acc = fma(sg + 8 * u <= i ? wv[u] : 0.0, bv[u], acc);
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (sg == 0) zc[i] = acc;  // (zc is dead since the leafS products)
-  }
-  __syncthreads();
-  for (int i0 = 8 * wave; i0 < n; i0 += 8 * NW) {  // z_sep = W'y
-    const int i = i0 + (lane >> 3), sg = lane & 7;
-    double wv[n / 8], yv[n / 8];
-#pragma unroll
-    for (int u = 0; u < n / 8; ++u) {
-      const int k = sg + 8 * u, kk = k >= i ? k : i;
-      wv[u] = *w_ptr(kk, i);
-      yv[u] = zc[k];
-    }
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < n / 8; ++u) acc = fma(sg + 8 * u >= i ? wv[u] : 0.0, yv[u], acc);
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (sg == 0) {
-      if (i < nl) myrec[2 * nnl + i] = acc;
-      zsv[i] = acc;  // for the vector pushes (phase D)
+  if (wave == (NW > 1 ? 1 : 0)) {
+    // last block of y~; levels >= 1 keep z_sep = L^-T y~ in the record (backsub_multipliers_generic), level 0 y~ itself
+    tri_forward_block(NB - 1, n, bz, zc, lane, Lo, Di);
+    if constexpr (LEVEL0) {
+      if (lane < nl) myrec[2 * nnl + lane] = bz[lane];
+    } else {
+      if (lane < n) zsv[lane] = bz[lane];
+      wave_lds_order();
+#pragma unroll 1
+      for (int ib = NB - 1; ib >= 0; --ib) tri_backward_block(ib, n, zsv, zc, lane, Lo, Di);
+      if (lane < nl) myrec[2 * nnl + lane] = zsv[lane];
     }
   }
+  SEG(54);
   // ================================================================================================= phase B
-  // Column tile gt of the panel: [0, NB) columns of r_a, [NB, 2 NB) of r_bb. xk[m][kb][q] =
-  // X(16 kb + 4 q + lk, 16 c + li): accumulator tile kb of the solved column tile -- as it stands the B operand
-  // of k-steps 4 kb .. 4 kb + 3 (and, transposed, the A operand) of the push products.
-  mfma_acc_t xk[MAXT][NB];
+  // Column tile gt of the panel: [0, NB) columns of r_a, [NB, 2 NB) of r_bb. Y = L^-1 R by block forward
+  // substitution in the accumulators: yk[m][kb][q] = Y(16 kb + 4 q + lk, 16 c + li) -- an accumulator tile is at once
+  // the B operand of k-steps 4 kb .. 4 kb + 3 (and, transposed, the A operand) of the products that follow, so
+  // nothing goes through LDS and nobody waits for anybody. Right-looking: block kb of Y, once final, goes into the
+  // accumulators of all blocks below it.
+  mfma_acc_t yk[MAXT][NB];
 #pragma unroll
   for (int m = 0; m < MAXT; ++m) {
     const int gt = wave + m * NW;
     double (&rf)[NB][4] = rfk[m];
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      xk[m][kb] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
-    }
+    for (int kb = 0; kb < NB; ++kb) yk[m][kb] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
     if (gt >= 2 * NB) continue;
     const int c = gt < NB ? gt : gt - NB;
+    // the accumulators start from -R (r_a = -CA, r_bb = -CB: the raw operand; level 0: scaled by the weights)
     if (gt < NB) {
       const double dj = dq[16 * c + li];
 #pragma unroll
@@ -408,7 +457,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const bool in = hasA && (!PAD || (16 * kb + 4 * q + lk < nl && 16 * c + li < nl));
-          rf[kb][q] = !in ? 0.0 : LEVEL0 ? -rf[kb][q] * dj : -rf[kb][q];
+          yk[m][kb][q] = !in ? 0.0 : LEVEL0 ? rf[kb][q] * dj : rf[kb][q];
         }
     } else {
 #pragma unroll
@@ -416,93 +465,89 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const bool in = hasB && (!PAD || (16 * kb + 4 * q + lk < nl && 16 * c + li < nl));
-          rf[kb][q] = !in ? 0.0 : LEVEL0 ? -rf[kb][q] * q1[16 * kb + 4 * q + lk] : -rf[kb][q];
-          if constexpr (!TWO) Rb[(16 * kb + 4 * q + lk) * PR + 16 * c + li] = rf[kb][q];  // operand of the push phase
+          yk[m][kb][q] = !in ? 0.0 : LEVEL0 ? rf[kb][q] * q1[16 * kb + 4 * q + lk] : rf[kb][q];
         }
     }
-    // Y = W R: block lower triangular; block (it, kb) of W as A operand (row li, k = 4 q + lk)
-    mfma_acc_t y[NB];
 #pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = 0; kb < NB; ++kb) {
+      // Y_kb = D_kb^-1 (R_kb - sum_{j < kb} L_kb,j Y_j) = (-D_kb^-1) (accumulator)
+      double a[4];
 #pragma unroll
-      for (int kb = 0; kb <= it; ++kb) {
-        double a[4];
+      for (int q = 0; q < 4; ++q) a[q] = -Wd[kb * 16 * 17 + li * 17 + 4 * q + lk];
+      mfma_acc_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          a[q] = kb == it ? Wd[it * 16 * 17 + li * 17 + 4 * q + lk] : S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
-        acc = mfma4(a, rf[kb], acc);
+      for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], yk[m][kb][q], y, 0, 0, 0);
+      yk[m][kb] = y;
+#pragma unroll
+      for (int it = kb + 1; it < NB; ++it) {
+        double al[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) al[q] = S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yk[m][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], y[q], yk[m][it], 0, 0, 0);
       }
-      y[it] = acc;
     }
-    // X = W'Y: block (it, kb) of W' -- W'(16 it + li, 16 kb + 4 q + lk) = W(16 kb + 4 q + lk, 16 it + li); the
-    // accumulator tile y[kb] is the B operand as it stands
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kb = it; kb < NB; ++kb) {
-        double a[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          a[q] = kb == it ? Wd[it * 16 * 17 + (4 * q + lk) * 17 + li] : S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], y[kb][q], acc, 0, 0, 0);
-      }
-      xk[m][it] = acc;
-    }
-    // record f_a | f_bb | z_sep (what the back-substitution reads): rows 16 it + lk + 4 g, columns 16 c + li
-    // (level 0 keeps the compact record written above instead)
-    if (!LEVEL0 && (gt < NB ? hasA : hasB) && (!PAD || 16 * c + li < nl)) {
+    if constexpr (!LEVEL0) {
+      // record f_a | f_bb (what backsub_multipliers_generic reads): X = L^-T Y by block backward substitution,
+      // block by block into the record: rows 16 it + lk + 4 g, columns 16 c + li. (Level 0 keeps the compact record.)
+      const bool keep = (gt < NB ? hasA : hasB) && (!PAD || 16 * c + li < nl);
       double* dst = myrec + (gt < NB ? 0 : nnl) + (size_t)lk * nl + 16 * c + li;
+      mfma_acc_t xa[NB];
 #pragma unroll
-      for (int it = 0; it < NB; ++it)
+      for (int kb = 0; kb < NB; ++kb) xa[kb] = -yk[m][kb];
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg)
-          if (!PAD || 16 * it + 4 * gg + lk < nl) dst[(size_t)(16 * it + 4 * gg) * nl] = xk[m][it][gg];
+      for (int kb = NB - 1; kb >= 0; --kb) {
+        // X_kb = D_kb^-T (Y_kb - sum_{j > kb} L_j,kb' X_j) = (-D_kb^-T) (accumulator)
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = -Wd[kb * 16 * 17 + (4 * q + lk) * 17 + li];
+        mfma_acc_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xa[kb][q], x, 0, 0, 0);
+        if (keep) {
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg)
+            if (!PAD || 16 * kb + 4 * gg + lk < nl) dst[(size_t)(16 * kb + 4 * gg) * nl] = x[gg];
+        }
+#pragma unroll
+        for (int it = 0; it < kb; ++it) {
+          double al[4];  // block (it, kb) of L': L'(16 it + li, 16 kb + 4 q + lk) = L(16 kb + 4 q + lk, 16 it + li)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) al[q] = S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xa[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], x[q], xa[it], 0, 0, 0);
+        }
+      }
     }
-  }
-  SEG(55);
-  __syncthreads();  // S-bar / W and b~ are dead
-  SEG(56);
-
-  // ================================================================================================= phase C
-  // coupling block from global memory (L2: it was read in phase B) into the coupling array, padded and masked
-  auto stage_coupling = [&](const bool a_side) {
-    constexpr int RS = (n * n + NTHR - 1) / NTHR;
-    const bool have = a_side ? hasA : hasB;
-    double t[RS];
-#pragma unroll
-    for (int u = 0; u < RS; ++u) {
-      const int e = tid + u * NTHR, ec = e < n * n ? e : n * n - 1, hi = ec / n, lo = ec % n;
-      const int hc = hi < nl ? hi : nl - 1, lc = lo < nl ? lo : nl - 1;
-      // level 0: r_a(k, j) = -A_s(k, j) / Q_s(j);  r_bb(k, j) = -A_{s+1}(j, k) / Q_{s+1}(k): walk the rows of A_{s+1}
-      if (a_side) t[u] = LEVEL0 ? ab[(size_t)hc * w + lc] : myslot[2 * nnl + hc * nl + lc];
-      else t[u] = LEVEL0 ? ab1[(size_t)hc * w + lc] : myslot[3 * nnl + hc * nl + lc];
-    }
-#pragma unroll
-    for (int u = 0; u < RS; ++u) {
-      const int e = tid + u * NTHR, ec = e < n * n ? e : n * n - 1, hi = ec / n, lo = ec % n;
-      const bool in = have && hi < nl && lo < nl;
-      if (a_side) S[hi * PR + lo] = !in ? 0.0 : LEVEL0 ? -t[u] * dq[lo] : -t[u];
-      else if (LEVEL0) S[lo * PR + hi] = !in ? 0.0 : -t[u] * q1[lo];
-      else S[hi * PR + lo] = !in ? 0.0 : -t[u];
-    }
-  };
-  if constexpr (TWO) {
-    stage_coupling(true);
-  } else {
-#pragma unroll
-    for (int m = 0; m < MAXT; ++m) {
-      const int gt = wave + m * NW;
-      if (gt < NB) {
+    if constexpr (!TWO) {
+      if (gt >= NB) {  // Y of r_bb: operand of the push phase, into its own array
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Ra[(16 * kb + 4 * q + lk) * PR + 16 * gt + li] = rfk[m][kb][q];
+          for (int q = 0; q < 4; ++q) Rb[(16 * kb + 4 * q + lk) * PR + 16 * c + li] = yk[m][kb][q];
       }
     }
   }
+  SEG(55);
+  __syncthreads();  // S-bar / L are dead
+  SEG(56);
+
+  // ================================================================================================= phase C
+  // Y of r_a (two rounds: later Y of r_bb) from the registers into the coupling array over the dead S-bar / L
+  auto stage_y = [&](const bool a_side) {
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      const int gt = wave + m * NW;
+      if (gt < 2 * NB && (gt < NB) == a_side) {
+        const int c = gt < NB ? gt : gt - NB;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) S[(16 * kb + 4 * q + lk) * PR + 16 * c + li] = yk[m][kb][q];
+      }
+    }
+  };
+  stage_y(true);
   __syncthreads();
   SEG(58);
 
@@ -569,25 +614,25 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
         if constexpr (TWO) {  // (registers are short with two solved tiles per wavefront: tile by tile)
 #pragma unroll
           for (int rt = 0; rt < NB; ++rt)
-            if (rt >= c) push_tile(Rl, rt, xk[m], false, pblk, rt, c, start_tile(rt));
+            if (rt >= c) push_tile(Rl, rt, yk[m], false, pblk, rt, c, start_tile(rt));
         } else {
           mfma_acc_t pacc[NB];
 #pragma unroll
           for (int rt = 0; rt < NB; ++rt) pacc[rt] = start_tile(rt);
 #pragma unroll
           for (int rt = 0; rt < NB; ++rt)
-            if (rt >= c) push_tile(Rl, rt, xk[m], false, pblk, rt, c, pacc[rt]);
+            if (rt >= c) push_tile(Rl, rt, yk[m], false, pblk, rt, c, pacc[rt]);
         }
       } else if (hasA && hasB) {
         if (atile) {  // with r_bb: coupling tiles (c, j <= c) as f_a' r_bb
           for (int j = 0; j <= c; ++j) {
-            if (leftchild) push_tile(Rl, j, xk[m], false, slotB + 2 * nnl, j, c, zero4);  // CA[B] = (f_a' r_bb)': rows bb-tile j
-            else push_tile(Rl, j, xk[m], true, slotA + 3 * nnl, c, j, zero4);           // CB[A] = f_a' r_bb: rows a-tile c
+            if (leftchild) push_tile(Rl, j, yk[m], false, slotB + 2 * nnl, j, c, zero4);  // CA[B] = (f_a' r_bb)': rows bb-tile j
+            else push_tile(Rl, j, yk[m], true, slotA + 3 * nnl, c, j, zero4);           // CB[A] = f_a' r_bb: rows a-tile c
           }
         } else {      // with r_a: coupling tiles (i < c, c) as r_a' f_bb
           for (int i = 0; i < c; ++i) {
-            if (leftchild) push_tile(Rl, i, xk[m], true, slotB + 2 * nnl, c, i, zero4);   // CA[B] = f_bb' r_a: rows bb-tile c
-            else push_tile(Rl, i, xk[m], false, slotA + 3 * nnl, i, c, zero4);          // CB[A] = r_a' f_bb: rows a-tile i
+            if (leftchild) push_tile(Rl, i, yk[m], true, slotB + 2 * nnl, c, i, zero4);   // CA[B] = f_bb' r_a: rows bb-tile c
+            else push_tile(Rl, i, yk[m], false, slotA + 3 * nnl, i, c, zero4);          // CB[A] = r_a' f_bb: rows a-tile i
           }
         }
       }
@@ -602,7 +647,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
         for (int k0 = 0; k0 < n; k0 += 8) {  // (not unrolled: the solved tiles are still live for the second round)
           double rv[8], zv[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { rv[u] = Rl[(k0 + u) * PR + j]; zv[u] = zsv[k0 + u]; }
+          for (int u = 0; u < 8; ++u) { rv[u] = Rl[(k0 + u) * PR + j]; zv[u] = bz[k0 + u]; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc = fma(rv[u], zv[u], acc);
         }
@@ -613,7 +658,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   pushes(true);
   if constexpr (TWO) {
     __syncthreads();  // r_a has been read
-    stage_coupling(false);
+    stage_y(false);
     __syncthreads();
   }
   pushes(false);
@@ -628,7 +673,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
 // with W from `wfac`, r_a = -CA, r_bb = -CB from the slots the factorisation left behind (level 0: from the
 // problem data); f_a, f_bb of the records stay. The back-substitution then runs as after a full solve.
 // Runtime-sized; np = padded block size of the factorisation.
-//   grid (N >> (l+1), batch), block 256, dynamic LDS = 2 (n + m) + n + 3 np + 256 doubles.
+//   grid (N >> (l+1), batch), block 256, dynamic LDS = 2 (n + m) + n + 3 np + 256 + reduced_wfac_doubles(np) doubles.
 static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l, int np, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
                                                                   const double* __restrict__ rhs, double* red,
@@ -643,7 +688,7 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
   double* zc = dq + w;    // rhs(s).xu scaled likewise (state entries of knot 0: -x0)
   double* q1 = zc + w;    // 1 / Q_{s+1}
   double* bz = q1 + nl;   // b~
-  double* yv = bz + np;   // W b~
+  double* yv = bz + np;   // scratch of the block substitutions
   double* zs = yv + np;   // z_sep
   double* part = zs + np; // partial column sums: 256 / np segments of the summation index per column
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -655,16 +700,26 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
   double* slotA = reduced_slot(red, d, b, hasA ? base - 1 : 1);
   double* slotB = reduced_slot(red, d, b, hasB ? base + T - 1 : 1);
   double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nnl + nl);
-  const double* Sg = wfac + ((size_t)b * N + s) * reduced_wfac_doubles(np);
-  const double* Wdg = Sg + (size_t)np * ns;
-  auto w_at = [&](const int r, const int c) -> double {  // W(r, c), c <= r
-    return (r >> 4) == (c >> 4) ? Wdg[(r >> 4) * 16 * 17 + (r & 15) * 17 + (c & 15)] : Sg[(size_t)r * ns + c];
-  };
+  const double* wf = wfac + ((size_t)b * N + s) * reduced_wfac_doubles(np);
+  double* Sl = part + 256;              // L (strictly lower blocks, pitch np + 1) and, behind it, the inverses of its
+  double* Wdl = Sl + (size_t)np * ns;   // diagonal blocks (16 x 17 each): the separator's factor, staged
+  auto Lo = [&](const int r, const int c) -> double { return Sl[r * ns + c]; };
+  auto Di = [&](const int r, const int c) -> double { return Wdl[(r >> 4) * 16 * 17 + (r & 15) * 17 + (c & 15)]; };
   auto wave_sum = [](double v) -> double {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
   };
+  {  // the factor: every load in flight before the first LDS store
+    const int WF = reduced_wfac_doubles(np);
+    for (int e0 = 0; e0 < WF; e0 += 8 * 256) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; t[u] = wf[e < WF ? e : WF - 1]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; if (e < WF) Sl[e] = t[u]; }
+    }
+  }
 
   for (int k = tid; k < w; k += 256) {
     const bool fx = first && k < nl;
@@ -690,11 +745,15 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
     }
   }
   __syncthreads();
-  for (int i = wave; i < np; i += 4) {  // y = W b~
-    double acc = 0.0;
-    for (int k = lane; k <= i; k += 64) acc = fma(w_at(i, k), bz[k], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) yv[i] = acc;
+  // y~ = L^-1 b~ and z_sep = L^-T y~ (block substitutions, first wavefront); the record keeps y~ at level 0 (compact
+  // record: backsub_level0_states_generic) and z_sep above it (backsub_multipliers_generic)
+  if (wave == 0) {
+    for (int ib = 0; ib < np / 16; ++ib) tri_forward_block(ib, np, bz, yv, lane, Lo, Di);
+    if (level0 && lane < nl) myrec[2 * nnl + lane] = bz[lane];
+    if (lane < np) zs[lane] = bz[lane];
+    wave_lds_order();
+    for (int ib = np / 16 - 1; ib >= 0; --ib) tri_backward_block(ib, np, zs, yv, lane, Lo, Di);
+    if (!level0 && lane < nl) myrec[2 * nnl + lane] = zs[lane];
   }
   __syncthreads();
   // column sums sum_k f(k, j): thread (j, seg) takes k = seg, seg + nseg, ..; consecutive threads read consecutive
@@ -712,14 +771,6 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
     __syncthreads();
     return tot;
   };
-  {  // z_sep = W'y
-    const double zi = column_sums([&](const int k, const int j) { return k >= j ? w_at(k, j) * yv[k] : 0.0; }, np);
-    if (cseg == 0) {
-      zs[cj] = zi;
-      if (cj < nl) myrec[2 * nnl + cj] = zi;
-    }
-  }
-  __syncthreads();
   // gR[A] (+)= r_a' z_sep: a column of r_a per thread
   if (hasA) {  // (uniform)
     double* dst = slotA + 4 * nnl + nl;
@@ -858,22 +909,18 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
     }
   }
   __syncthreads();
-  // v = W t (a row per wavefront and round), then y_s = z_sep - W'v (a column per thread)
-  for (int i = wave; i < n; i += nwave) {
-    double acc = 0.0;
-    for (int k = lane; k <= i; k += 64) acc = fma(Wp[i * (i + 1) / 2 + k], tv[k], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) ys[i] = acc;  // (v, for the moment)
-  }
-  __syncthreads();
-  double yi = 0.0;
-  if (tid < n) {  // (n <= 64)
-    double acc = 0.0;
-    for (int k = tid; k < n; ++k) acc = fma(Wp[k * (k + 1) / 2 + tid], ys[k], acc);
-    yi = zs[tid] - acc;
+  // y_s = L^-T (y~ - L^-1 t): two block substitutions on the packed factor (first wavefront)
+  if (wave == 0) {
+    auto P = [&](const int i, const int k) -> double { return Wp[i * (i + 1) / 2 + k]; };
+    const int nblk = (n + 15) >> 4;
+    for (int ib = 0; ib < nblk; ++ib) tri_forward_block(ib, n, tv, part, lane, P, P);
+    if (lane < n) tv[lane] = zs[lane] - tv[lane];  // (n <= 64)
+    wave_lds_order();
+    for (int ib = nblk - 1; ib >= 0; --ib) tri_backward_block(ib, n, tv, part, lane, P, P);
   }
   __syncthreads();
   if (tid < n) {
+    const double yi = tv[tid];
     ys[tid] = yi;
     zk[rows + tid] = yi;  // lambda rows of knot s + 1
   }

@@ -567,7 +567,7 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
 static void launch_rhs_reduced_generic(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   const int np = (d.n + 15) / 16 * 16;
-  const size_t lds = sizeof(double) * (2 * (size_t)d.w + d.n + 3 * (size_t)np + 256);
+  const size_t lds = sizeof(double) * (2 * (size_t)d.w + d.n + 3 * (size_t)np + 256 + (size_t)ndlqr::reduced_wfac_doubles(np));
   for (int l = 0; l < d.K; ++l) {
     ScopedSlot t(c, SLOT_SEP);
     hipLaunchKernelGGL(ndlqr::rhs_reduced_generic, dim3(d.N >> (l + 1), d.batch), dim3(256), lds, c->stream, d, l, np,
