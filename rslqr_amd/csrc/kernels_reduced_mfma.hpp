@@ -82,7 +82,7 @@ __host__ __device__ inline int reduced_lds_doubles(const int n, const int w, con
   // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
   const int later = n * (n + 1) + 17 * n + (two_round ? 0 : n * (n + 1));
   if (later > big) big = later;
-  return w + (w > n ? w : n) + 3 * n + big;  // dq (w), zc (later y of the z column: max(w, n)), q1, b~, z_sep (n each)
+  return w + (w > n ? w : n) + 2 * n + big;  // dq (w), zc (later scratch of the substitutions: max(w, n)), q1, b~ (n each)
 }
 
 // lower-triangle tile t -> its block row (block column: t - row (row + 1) / 2)
@@ -197,8 +197,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   double* zc = dq + wp;      // rhs(s).xu scaled likewise (state entries of knot 0: -x0)
   double* q1 = zc + (wp > n ? wp : n);  // 1 / Q_{s+1}  (zc doubles as the y of the z column: n entries)
   double* bz = q1 + n;       // b~
-  double* zsv = bz + n;      // z_sep
-  double* S = zsv + n;       // S-bar / L / W
+  double* S = bz + n;        // S-bar / L
   double* Wd = S + n * ns;   // NB blocks of 16 x 17: inverses of the diagonal blocks of L
   double* stage = S;         // [A_s | B_s], pitch P, until S-bar is formed
   double* Ra = S;            // r_a (pitch PR) once W is dead
@@ -409,29 +408,21 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
     double* wf = wfac + ((size_t)b * N + s) * WF;
     for (int e = tid; e < WF; e += NTHR) wf[e] = S[e];  // (S and Wd are contiguous)
   }
-  if constexpr (LEVEL0) {
-    // compact level-0 record: L with the inverses of its diagonal blocks in their place, lower triangle packed with
-    // the problem's own size (entry (i, k), k <= i, at i (i + 1) / 2 + k), instead of f_a | f_bb -- a quarter of the
-    // bytes; the back-substitution of level 0 (backsub_level0_states_generic) forms f_a y_A + f_bb y_B =
-    // S-bar^-1 (r_a y_A + r_bb y_B) from the problem data it reads anyway. A row per wavefront and round.
+  {
+    // compact record: L with the inverses of its diagonal blocks in their place, lower triangle packed with the
+    // problem's own size (entry (i, k), k <= i, at i (i + 1) / 2 + k), and y~ -- instead of f_a | f_bb | z_sep: a
+    // quarter of the bytes, and X = L^-T Y is never formed. The back-substitution (backsub_multipliers_compact,
+    // level 0: backsub_level0_states_generic) forms f_a y_A + f_bb y_B = S-bar^-1 (r_a y_A + r_bb y_B) from the
+    // couplings, which stay where this kernel read them (slot / problem data). A row per wavefront and round.
     for (int i = wave; i < nl; i += NW) {
       double* dst = myrec + (size_t)i * (i + 1) / 2;
       for (int k = lane; k <= i; k += 64)
         dst[k] = (i >> 4) == (k >> 4) ? Wd[(i >> 4) * 16 * 17 + (i & 15) * 17 + (k & 15)] : S[i * ns + k];
     }
   }
-  if (wave == (NW > 1 ? 1 : 0)) {
-    // last block of y~; levels >= 1 keep z_sep = L^-T y~ in the record (backsub_multipliers_generic), level 0 y~ itself
+  if (wave == (NW > 1 ? 1 : 0)) {  // last block of y~
     tri_forward_block(NB - 1, n, bz, zc, lane, Lo, Di);
-    if constexpr (LEVEL0) {
-      if (lane < nl) myrec[2 * nnl + lane] = bz[lane];
-    } else {
-      if (lane < n) zsv[lane] = bz[lane];
-      wave_lds_order();
-#pragma unroll 1
-      for (int ib = NB - 1; ib >= 0; --ib) tri_backward_block(ib, n, zsv, zc, lane, Lo, Di);
-      if (lane < nl) myrec[2 * nnl + lane] = zsv[lane];
-    }
+    if (lane < nl) myrec[2 * nnl + lane] = bz[lane];
   }
   SEG(54);
   // ================================================================================================= phase B
@@ -485,38 +476,6 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
         for (int q = 0; q < 4; ++q) al[q] = S[(16 * it + li) * ns + 16 * kb + 4 * q + lk];
 #pragma unroll
         for (int q = 0; q < 4; ++q) yk[m][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], y[q], yk[m][it], 0, 0, 0);
-      }
-    }
-    if constexpr (!LEVEL0) {
-      // record f_a | f_bb (what backsub_multipliers_generic reads): X = L^-T Y by block backward substitution,
-      // block by block into the record: rows 16 it + lk + 4 g, columns 16 c + li. (Level 0 keeps the compact record.)
-      const bool keep = (gt < NB ? hasA : hasB) && (!PAD || 16 * c + li < nl);
-      double* dst = myrec + (gt < NB ? 0 : nnl) + (size_t)lk * nl + 16 * c + li;
-      mfma_acc_t xa[NB];
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) xa[kb] = -yk[m][kb];
-#pragma unroll
-      for (int kb = NB - 1; kb >= 0; --kb) {
-        // X_kb = D_kb^-T (Y_kb - sum_{j > kb} L_j,kb' X_j) = (-D_kb^-T) (accumulator)
-        double a[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = -Wd[kb * 16 * 17 + (4 * q + lk) * 17 + li];
-        mfma_acc_t x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xa[kb][q], x, 0, 0, 0);
-        if (keep) {
-#pragma unroll
-          for (int gg = 0; gg < 4; ++gg)
-            if (!PAD || 16 * kb + 4 * gg + lk < nl) dst[(size_t)(16 * kb + 4 * gg) * nl] = x[gg];
-        }
-#pragma unroll
-        for (int it = 0; it < kb; ++it) {
-          double al[4];  // block (it, kb) of L': L'(16 it + li, 16 kb + 4 q + lk) = L(16 kb + 4 q + lk, 16 it + li)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) al[q] = S[(16 * kb + 4 * q + lk) * ns + 16 * it + li];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) xa[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], x[q], xa[it], 0, 0, 0);
-        }
       }
     }
     if constexpr (!TWO) {
@@ -745,15 +704,13 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
     }
   }
   __syncthreads();
-  // y~ = L^-1 b~ and z_sep = L^-T y~ (block substitutions, first wavefront); the record keeps y~ at level 0 (compact
-  // record: backsub_level0_states_generic) and z_sep above it (backsub_multipliers_generic)
+  // y~ = L^-1 b~ -> record, and z_sep = L^-T y~ for the pushes (block substitutions, first wavefront)
   if (wave == 0) {
     for (int ib = 0; ib < np / 16; ++ib) tri_forward_block(ib, np, bz, yv, lane, Lo, Di);
-    if (level0 && lane < nl) myrec[2 * nnl + lane] = bz[lane];
+    if (lane < nl) myrec[2 * nnl + lane] = bz[lane];
     if (lane < np) zs[lane] = bz[lane];
     wave_lds_order();
     for (int ib = np / 16 - 1; ib >= 0; --ib) tri_backward_block(ib, np, zs, yv, lane, Lo, Di);
-    if (!level0 && lane < nl) myrec[2 * nnl + lane] = zs[lane];
   }
   __syncthreads();
   // column sums sum_k f(k, j): thread (j, seg) takes k = seg, seg + nseg, ..; consecutive threads read consecutive
@@ -796,6 +753,85 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
       }, nl);
       if (cseg == 0 && cj < nl) dst[cj] += g;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------- back-substitution, levels >= 1
+// Multipliers of the separators of level l >= 1 from the compact records, top-down (one launch per level):
+//     y_s = S-bar^-1 (b~ - r_a y_A - r_bb y_B) = L^-T (y~ + L^-1 (CA y_A + CB y_B))
+// with CA = -r_a, CB = -r_bb where the factorisation read them (the separator's slot: nothing writes it after its
+// elimination), L and y~ from the record; y_A, y_B are final (higher levels) in the lambda rows of knots A + 1, B + 1.
+// One workgroup per separator: the rows of CA | CB are dealt to the wavefronts eight at a time (lanes along a row:
+// coalesced, sixteen loads in flight per lane), the two block substitutions run on the first wavefront.
+//   grid (N >> (l+1), batch), block 256, dynamic LDS = n (n + 1) / 2 + 2 n + 16 doubles.
+static __global__ __launch_bounds__(256) void backsub_multipliers_compact(Dims d, int l, const double* __restrict__ red,
+                                                                          const double* __restrict__ recs, double* z) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = d.n, nn = n * n, rows = d.rows, N = d.N, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
+  const bool hasA = base > 0, hasB = base + T < N;
+  double* Lp = sm;                     // L / inverses of its diagonal blocks, packed lower triangle
+  double* tv = Lp + n * (n + 1) / 2;   // CA y_A + CB y_B, then the substitutions
+  double* yt = tv + n;                 // y~
+  double* tmp = yt + n;                // scratch of the substitutions (16)
+  const double* rc = recs + ((size_t)b * N + s) * (2 * (size_t)nn + n);
+  const double* slot = red + ((size_t)b * (N >> 1) + (s >> 1)) * (4 * (size_t)nn + 2 * n);
+  const double* CA = slot + 2 * (size_t)nn;
+  const double* CB = slot + 3 * (size_t)nn;
+  const double* yA = z + ((size_t)b * N + base) * rows;      // y_A lives in the lambda rows of knot A + 1 = base
+  const double* yB = z + ((size_t)b * N + base + T) * rows;
+  double* out = z + ((size_t)b * N + s + 1) * rows;
+  {  // the factor: every load in flight before the first LDS store
+    const int np = n * (n + 1) / 2;
+    for (int e0 = 0; e0 < np; e0 += 8 * 256) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; t[u] = rc[e < np ? e : np - 1]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; if (e < np) Lp[e] = t[u]; }
+    }
+    if (tid < n) yt[tid] = rc[2 * (size_t)nn + tid];
+  }
+  for (int r0 = 8 * wave; r0 < n; r0 += 32) {
+    double part[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) part[u] = 0.0;
+    for (int c = lane; c < n; c += 64) {
+      double fa[8], fb[8], ya = 0.0, yb = 0.0;
+      if (hasA) {  // uniform
+        ya = yA[c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fa[u] = CA[(size_t)(r0 + u < n ? r0 + u : n - 1) * n + c];
+      }
+      if (hasB) {
+        yb = yB[c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fb[u] = CB[(size_t)(r0 + u < n ? r0 + u : n - 1) * n + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (hasA) part[u] = fma(fa[u], ya, part[u]);
+        if (hasB) part[u] = fma(fb[u], yb, part[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      double p = part[u];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+      if (lane == 0 && r0 + u < n) tv[r0 + u] = p;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    auto P = [&](const int i, const int k) -> double { return Lp[i * (i + 1) / 2 + k]; };
+    const int nblk = (n + 15) >> 4;
+    for (int ib = 0; ib < nblk; ++ib) tri_forward_block(ib, n, tv, tmp, lane, P, P);
+    if (lane < n) tv[lane] += yt[lane];  // (n <= 64)
+    wave_lds_order();
+    for (int ib = nblk - 1; ib >= 0; --ib) tri_backward_block(ib, n, tv, tmp, lane, P, P);
+    if (lane < n) out[lane] = tv[lane];
   }
 }
 

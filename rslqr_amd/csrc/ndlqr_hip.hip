@@ -494,27 +494,16 @@ static int ensure_red_generic(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
-// back-substitution over the separator records (runtime-sized schedules): multipliers level by level, then the
-// states and inputs of every knot
-static void launch_backsub_generic(NdlqrHipCtx* c) {
-  const ndlqr::Dims& d = c->d;
-  ScopedSlot t(c, SLOT_APPLY);
-  for (int l = d.K - 1; l >= 0; --l)
-    hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
-                       c->rec, c->z);
-  const int work = d.N * d.rows;
-  hipLaunchKernelGGL(ndlqr::backsub_states_generic, dim3((work + 255) / 256, d.batch), dim3(256), 0, c->stream, d,
-                     c->AB, c->QR, c->rhs, c->z);
-}
-
-// the same for the runtime-sized separator-only schedule: its level-0 records are compact (W instead of f_a | f_bb),
-// and one launch resolves the level-0 multipliers and the states / inputs of every knot
+// back-substitution of the runtime-sized separator-only schedule: its records are compact (the Cholesky factor and y~ instead of
+// f_a | f_bb | z_sep, the couplings come from the slots / the problem data), and one launch resolves the level-0
+// multipliers and the states / inputs of every knot
 static void launch_backsub_reduced_generic(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   ScopedSlot t(c, SLOT_APPLY);
+  const size_t lds_m = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 2 * (size_t)d.n + 16);
   for (int l = d.K - 1; l >= 1; --l)
-    hipLaunchKernelGGL(ndlqr::backsub_multipliers_generic, dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d, l,
-                       c->rec, c->z);
+    hipLaunchKernelGGL(ndlqr::backsub_multipliers_compact, dim3(d.N >> (l + 1), d.batch), dim3(256), lds_m, c->stream, d, l,
+                       c->red, c->rec, c->z);
   const int thr = d.n <= 16 ? 64 : (d.n <= 32 ? 128 : 256);  // (its y_s step wants n <= threads)
   const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 5 * (size_t)d.n + 4 * (size_t)d.w + 2 * (size_t)d.rows + thr);
   hipLaunchKernelGGL(ndlqr::backsub_level0_states_generic, dim3(d.N >> 1, d.batch), dim3(thr), lds, c->stream, d, c->AB,
