@@ -54,21 +54,15 @@ __device__ __forceinline__ mfma_acc_t block_chain(mfma_acc_t acc, const int kb0,
 // Blocked Cholesky of S (lower triangle; different summation grouping than the reference: fast mode
 // only): diagonal block + its inverse by one wavefront (chol16_and_inverse), the panel below it and the
 // trailing update as rank-16 matrix-core products.
-// side(jb): work of ONE wavefront that runs beside the diagonal block of step jb (the second wavefront, which would
-// wait at the barrier; the only one when there is no second). It may read what step jb - 1 completed: the block
-// rows < jb of L and the inverses of the diagonal blocks < jb.
-template <class Side>
 __device__ __forceinline__ void sep_cholesky(const SepGeom& g, double* S, double* Wd, int* __restrict__ info,
-                                             const Dims& d, const int b, Side side) {
+                                             const Dims& d, const int b) {
   const int ns = g.ns, tiles = g.tiles, li = g.li, lk = g.lk;
-  const int side_wave = g.nwave > 1 ? 1 : 0;
   for (int jb = 0; jb < tiles; ++jb) {
     const int j0 = 16 * jb, rem = tiles - 1 - jb;
     if (g.wave == 0) {
       const bool bad = chol16_and_inverse(S + j0 * ns + j0, ns, Wd + jb * 16 * 17, g.lane);
       if (bad && g.lane == 0) flag_failure(info, d, b);
     }
-    if (g.wave == side_wave) side(jb);
     __syncthreads();
     const double* Wb = Wd + jb * 16 * 17;
     for (int it = jb + 1 + g.wave; it < tiles; it += g.nwave) {  // L21 = A21 W'
@@ -93,11 +87,6 @@ __device__ __forceinline__ void sep_cholesky(const SepGeom& g, double* S, double
     }
     if (rem > 0) __syncthreads();
   }
-}
-
-__device__ __forceinline__ void sep_cholesky(const SepGeom& g, double* S, double* Wd, int* __restrict__ info,
-                                             const Dims& d, const int b) {
-  sep_cholesky(g, S, Wd, info, d, b, [](const int) {});
 }
 
 // W = L^-1, in place over the strictly lower blocks of L (diagonal blocks: Wd), block row by block

@@ -73,14 +73,14 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 
 // what a separator keeps for the record-based re-solve: the n x (n + 1) array that holds W below its diagonal
 // blocks, then the inverses of the diagonal blocks (n / 16 blocks of 16 x 17); n = padded block size
-__host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * (n + 1) + 17 * n; }
+__host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * (n + 1); }
 
 // two_round: one wavefront per tile column (NTHR = 64 NB): r_a and r_bb take turns in ONE array over the dead
 // S-bar / W (no separate r_bb array)
 __host__ __device__ inline int reduced_lds_doubles(const int n, const int w, const bool two_round) {
   int big = n * reduced_stage_pitch(w);  // staged [A_s | B_s]
   // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
-  const int later = n * (n + 1) + 17 * n + (two_round ? 0 : n * (n + 1));
+  const int later = n * (n + 1) + (two_round ? 0 : n * (n + 1));
   if (later > big) big = later;
   return w + (w > n ? w : n) + 2 * n + big;  // dq (w), zc (later scratch of the substitutions: max(w, n)), q1, b~ (n each)
 }
@@ -166,6 +166,93 @@ __device__ __forceinline__ void tri_backward_block(const int ib, const int n, do
   wave_lds_order();
 }
 
+// ------------------------------------------------------------------------------------- blocked Cholesky, in place
+// Lower Cholesky of one 16 x 16 diagonal block by ONE wavefront (rb_chol_inv, kernels_dpp.hpp) that leaves the INVERSE
+// of the block's factor in its place (row pitch ns; zeros above the diagonal): nothing after this step wants the
+// diagonal block of L itself -- the panel below it, the substitutions and the records all work with the inverse.
+// Every lane stores (lanes >= 16, replicas, into the column behind the block -- the tile above the diagonal, never
+// read, or the pad column): a store under a lane predicate makes the compiler sink the recurrence behind it.
+__device__ __forceinline__ bool chol16_inverse_in_place(double* Sblk, const int ns, const int lane) {
+  const int r = lane & 15;
+  double acc[16], w[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = Sblk[r * ns + c];
+  const bool bad = rb_chol_inv<16>(r, acc, w);
+  const int wc = lane < 16 ? lane : 16;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) Sblk[rr * ns + wc] = w[rr];
+  return bad;
+}
+
+// Blocked Cholesky of S (n = 16 NB, lower block triangle, row pitch ns) by NW wavefronts, with look-ahead: per block
+// column two workgroup barriers -- behind the panel L21 = A21 D^-T and behind the trailing update -- and the first
+// wavefront takes the NEXT diagonal tile through its update and straight on into its factorisation while the others
+// finish the trailing update. On return S holds L below the diagonal blocks and the inverses of the diagonal blocks
+// of L in their place. side(jb, wave): called by every wavefront but the first (by the only one when NW = 1) once block
+// row jb is final (its L blocks and the inverse of its diagonal block), beside the factorisation of the next diagonal
+// block: work that would otherwise wait at the barrier.
+template <int NB, int NW, class Side>
+__device__ __forceinline__ void reduced_cholesky(double* S, const int ns, const int lane, const int wave, int* __restrict__ info,
+                                                 const Dims& d, const int b, Side side) {
+  const int li = lane & 15, lk = lane >> 4;
+  auto diag = [&](const int jb) {
+    const bool bad = chol16_inverse_in_place(S + 16 * jb * ns + 16 * jb, ns, lane);
+    if (bad && lane == 0) flag_failure(info, d, b);
+  };
+  // tile (it, ct) -= L(it, jb) L(ct, jb)'
+  auto trailing_tile = [&](const int jb, const int it, const int ct) {
+    double* Ct = S + (16 * it + lk) * ns + 16 * ct + li;
+    double a[4], bl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = -S[(16 * it + li) * ns + 16 * jb + 4 * q + lk];
+      bl[q] = S[(16 * ct + li) * ns + 16 * jb + 4 * q + lk];
+    }
+    mfma_acc_t acc = {Ct[0], Ct[4 * ns], Ct[8 * ns], Ct[12 * ns]};
+    acc = mfma4(a, bl, acc);
+    Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+  };
+  if (wave == 0) diag(0);
+  __syncthreads();
+#pragma unroll
+  for (int jb = 0; jb < NB; ++jb) {
+    const int rem = NB - 1 - jb;
+    if (rem == 0) {
+      if (NW == 1 || wave != 0) side(jb, wave);
+      break;
+    }
+    for (int it = jb + 1 + wave; it < NB; it += NW) {  // L21 = A21 D^-T (D^-1: the inverse in the diagonal block)
+      double a[4], bw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = S[(16 * it + li) * ns + 16 * jb + 4 * q + lk];
+        bw[q] = S[(16 * jb + li) * ns + 16 * jb + 4 * q + lk];
+      }
+      const mfma_acc_t acc = mfma4(a, bw, mfma_acc_t{0.0, 0.0, 0.0, 0.0});
+      double* Ct = S + (16 * it + lk) * ns + 16 * jb + li;
+      Ct[0] = acc[0]; Ct[4 * ns] = acc[1]; Ct[8 * ns] = acc[2]; Ct[12 * ns] = acc[3];
+    }
+    __syncthreads();
+    // trailing update: tile 0 = the next diagonal tile (first wavefront, which goes on to factor it), the others dealt
+    // to the remaining wavefronts
+    if (wave == 0) {
+      trailing_tile(jb, jb + 1, jb + 1);
+      diag(jb + 1);
+    }
+    if (NW == 1 || wave != 0) {
+      int idx = 0;
+      for (int it = jb + 1; it < NB; ++it)
+        for (int ct = jb + 1; ct <= it; ++ct) {
+          if (it == jb + 1 && ct == jb + 1) continue;
+          if (NW == 1 || idx % (NW - 1) == wave - 1) trailing_tile(jb, it, ct);
+          ++idx;
+        }
+      side(jb, wave);
+    }
+    __syncthreads();
+  }
+}
+
 // wavefronts per SIMD the register budget is cut for: what LDS lets share a CU (two-round mode at n = 48, 64: three or
 // four workgroups of NB wavefronts)
 constexpr int reduced_min_waves(const int nb, const int nthr) { return (nthr == 64 * nb && nb >= 3) ? 3 : 4; }
@@ -198,16 +285,14 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   double* q1 = zc + (wp > n ? wp : n);  // 1 / Q_{s+1}  (zc doubles as the y of the z column: n entries)
   double* bz = q1 + n;       // b~
   double* S = bz + n;        // S-bar / L
-  double* Wd = S + n * ns;   // NB blocks of 16 x 17: inverses of the diagonal blocks of L
   double* stage = S;         // [A_s | B_s], pitch P, until S-bar is formed
   double* Ra = S;            // r_a (pitch PR) once W is dead
-  double* Rb = TWO ? S : Wd + 17 * n;  // r_bb (pitch PR): written in phase B, or (two rounds) staged over r_a
+  double* Rb = TWO ? S : S + n * ns;  // Y of r_bb (pitch PR): written in phase B, or (two rounds) staged over that of r_a
   const int P = reduced_stage_pitch(wp);
   const int tid = threadIdx.x;
   // (the wavefront index as a scalar: everything that depends on it branches uniformly)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const SepGeom geo = {n, ns, 0, NB, lane, wave, NW, li, lk};
   SEG_INIT();
 
   const double* ab = AB + ((size_t)b * N + s) * nl * w;  // [A_s | B_s]
@@ -378,12 +463,36 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   __syncthreads();
   SEG(52);
 
-  // ---- blocked Cholesky; beside it the second wavefront takes the right-hand-side column through the forward
-  //      substitution, a block behind: y~ = L^-1 b~ (in place over b~)
-  auto Lo = [&](const int i, const int k) -> double { return S[i * ns + k]; };
-  auto Di = [&](const int i, const int k) -> double { return Wd[(i >> 4) * 16 * 17 + (i & 15) * 17 + (k & 15)]; };
-  sep_cholesky(geo, S, Wd, info, d, b, [&](const int jb) {
-    if (jb > 0) tri_forward_block(jb - 1, n, bz, zc, lane, Lo, Di);
+  // ---- blocked Cholesky. Beside it, as soon as a block row of the factor is final: the second wavefront takes the
+  //      right-hand-side column through the forward substitution (y~ = L^-1 b~, in place over b~), the others store the
+  //      block row into the compact record -- L with the inverses of its diagonal blocks in their place, lower triangle
+  //      packed with the problem's own size (entry (i, k), k <= i, at i (i + 1) / 2 + k), and y~, instead of
+  //      f_a | f_bb | z_sep: a quarter of the bytes, and X = L^-T Y is never formed. The back-substitution
+  //      (backsub_multipliers_compact, level 0: backsub_level0_states_generic) forms f_a y_A + f_bb y_B =
+  //      S-bar^-1 (r_a y_A + r_bb y_B) from the couplings, which stay where this kernel reads them (slot / data).
+  auto At = [&](const int i, const int k) -> double { return S[i * ns + k]; };
+  reduced_cholesky<NB, NW>(S, ns, lane, wave, info, d, b, [&](const int jb, const int wv) {
+    constexpr int YW = NW > 1 ? 1 : 0;                     // the wavefront of y~
+    constexpr int SW0 = NW >= 3 ? 2 : YW, NSW = NW - SW0;  // the wavefronts that store
+    if (wv == YW) {
+      tri_forward_block(jb, n, bz, zc, lane, At, At);
+      if (jb == NB - 1 && lane < nl) myrec[2 * nnl + lane] = bz[lane];
+    }
+    if (wv >= SW0) {
+      for (int r0 = wv - SW0; r0 < 16; r0 += 4 * NSW) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = 16 * jb + r0 + u * NSW, ic = i < n ? i : n - 1;
+          v[u] = S[ic * ns + (lane <= ic ? lane : ic)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * NSW, i = 16 * jb + r;
+          if (r < 16 && i < nl && lane <= i) myrec[(size_t)i * (i + 1) / 2 + lane] = v[u];
+        }
+      }
+    }
   });
   SEG(53);
   // the column tile(s) of [r_a | r_bb] this wavefront will solve: requested here, consumed behind the last block of y~
@@ -403,26 +512,10 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
         else rfk[m][kb][q] = LEVEL0 ? ab1[(size_t)j * w + k] : myslot[3 * nnl + k * nl + j];
       }
   }
-  if (wfac) {  // NDLQR_FLAG_KEEP_RECORDS: L (strictly lower blocks in S) and the inverses of its diagonal blocks (Wd)
+  if (wfac) {  // NDLQR_FLAG_KEEP_RECORDS: the factor as it stands in S, for rhs-only re-solves
     constexpr int WF = reduced_wfac_doubles(n);
     double* wf = wfac + ((size_t)b * N + s) * WF;
-    for (int e = tid; e < WF; e += NTHR) wf[e] = S[e];  // (S and Wd are contiguous)
-  }
-  {
-    // compact record: L with the inverses of its diagonal blocks in their place, lower triangle packed with the
-    // problem's own size (entry (i, k), k <= i, at i (i + 1) / 2 + k), and y~ -- instead of f_a | f_bb | z_sep: a
-    // quarter of the bytes, and X = L^-T Y is never formed. The back-substitution (backsub_multipliers_compact,
-    // level 0: backsub_level0_states_generic) forms f_a y_A + f_bb y_B = S-bar^-1 (r_a y_A + r_bb y_B) from the
-    // couplings, which stay where this kernel read them (slot / problem data). A row per wavefront and round.
-    for (int i = wave; i < nl; i += NW) {
-      double* dst = myrec + (size_t)i * (i + 1) / 2;
-      for (int k = lane; k <= i; k += 64)
-        dst[k] = (i >> 4) == (k >> 4) ? Wd[(i >> 4) * 16 * 17 + (i & 15) * 17 + (k & 15)] : S[i * ns + k];
-    }
-  }
-  if (wave == (NW > 1 ? 1 : 0)) {  // last block of y~
-    tri_forward_block(NB - 1, n, bz, zc, lane, Lo, Di);
-    if (lane < nl) myrec[2 * nnl + lane] = bz[lane];
+    for (int e = tid; e < WF; e += NTHR) wf[e] = S[e];
   }
   SEG(54);
   // ================================================================================================= phase B
@@ -464,7 +557,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
       // Y_kb = D_kb^-1 (R_kb - sum_{j < kb} L_kb,j Y_j) = (-D_kb^-1) (accumulator)
       double a[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a[q] = -Wd[kb * 16 * 17 + li * 17 + 4 * q + lk];
+      for (int q = 0; q < 4; ++q) a[q] = -S[(16 * kb + li) * ns + 16 * kb + 4 * q + lk];
       mfma_acc_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], yk[m][kb][q], y, 0, 0, 0);
@@ -660,10 +753,9 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
   double* slotB = reduced_slot(red, d, b, hasB ? base + T - 1 : 1);
   double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nnl + nl);
   const double* wf = wfac + ((size_t)b * N + s) * reduced_wfac_doubles(np);
-  double* Sl = part + 256;              // L (strictly lower blocks, pitch np + 1) and, behind it, the inverses of its
-  double* Wdl = Sl + (size_t)np * ns;   // diagonal blocks (16 x 17 each): the separator's factor, staged
+  double* Sl = part + 256;  // the separator's factor, staged: L (pitch np + 1), the inverses of its diagonal blocks in their place
   auto Lo = [&](const int r, const int c) -> double { return Sl[r * ns + c]; };
-  auto Di = [&](const int r, const int c) -> double { return Wdl[(r >> 4) * 16 * 17 + (r & 15) * 17 + (c & 15)]; };
+  auto Di = Lo;
   auto wave_sum = [](double v) -> double {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

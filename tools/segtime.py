@@ -37,8 +37,8 @@ NAMES = {0: "level: stage operands", 1: "level core: P1", 2: "level core: P2 (Ch
          44: "generic separator: stores + drain",
          50: "reduced sep: stage [A|B], weights", 51: "reduced sep: leafS products + b~ (+ barrier)",
          52: "reduced sep: S-bar write-out (slot loads) + barrier", 53: "reduced sep: blocked Cholesky",
-         54: "reduced sep: blocked inverse", 55: "reduced sep: column tiles X = W'(W R) + record (own work)", 56: "reduced sep: barrier behind the column tiles",
-         58: "reduced sep: stage r_a, r_bb + barrier", 59: "reduced sep: pushes",
+         54: "reduced sep: record stores, last block of y~, panel loads requested", 55: "reduced sep: column tiles Y = L^-1 R (own work)", 56: "reduced sep: barrier behind the column tiles",
+         58: "reduced sep: Y_a into LDS + barrier", 59: "reduced sep: pushes",
          25: "bottom: row update + rotate", 26: "bottom: barrier end of level", 27: "bottom: hand-off"}
 
 
