@@ -37,7 +37,13 @@ __device__ __forceinline__ double* reduced_slot(double* red, const Dims& d, cons
 
 // pitch of the staged [A_s | B_s] rows in LDS: = 4 (mod 8) doubles, so that the sixteen rows a
 // matrix-core operand fetch touches (lane li: row, lk: four consecutive doubles) fall into disjoint banks
-__host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 == 4) ? w : w + 4; }
+__host__ __device__ constexpr int reduced_stage_pitch(const int w) { return (w % 8 == 4) ? w : w + 4; }
+// pitch of S-bar / L (n = 16 NB): the same rule -- its blocks are fetched as A operands (lane li: row) by every product
+// of the Cholesky and of the panel substitution; n + 1 would put four lanes on a bank
+__host__ __device__ constexpr int reduced_s_pitch(const int n) { return reduced_stage_pitch(n); }
+// pitch of the solved panel halves Y in the push phase, = 16 (mod 32) doubles: they are written from accumulator tiles
+// and fetched as the transposed operand (lane lk: row, li: column), and lk * pitch + li then covers every bank twice
+__host__ __device__ constexpr int reduced_y_pitch(const int n) { return n % 32 == 16 ? n : n + 16; }
 
 // NB = ceil(n / 16), NTHR threads (a multiple of 64, at least 64 NB and max(16 NB, n + m rounded up to 4)).
 //   grid (N >> (l+1), batch), block NTHR;
@@ -73,15 +79,15 @@ __host__ __device__ inline int reduced_stage_pitch(const int w) { return (w % 8 
 
 // what a separator keeps for the record-based re-solve: the n x (n + 1) array that holds W below its diagonal
 // blocks, then the inverses of the diagonal blocks (n / 16 blocks of 16 x 17); n = padded block size
-__host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * (n + 1); }
+__host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * reduced_s_pitch(n); }
 
 // two_round: one wavefront per tile column (NTHR = 64 NB): r_a and r_bb take turns in ONE array over the dead
 // S-bar / W (no separate r_bb array)
 __host__ __device__ inline int reduced_lds_doubles(const int n, const int w, const bool two_round) {
   int big = n * reduced_stage_pitch(w);  // staged [A_s | B_s]
-  // S-bar / W, diagonal-block inverses, r_bb (r_a: over S-bar)
-  const int later = n * (n + 1) + (two_round ? 0 : n * (n + 1));
-  if (later > big) big = later;
+  if (n * reduced_s_pitch(n) > big) big = n * reduced_s_pitch(n);  // S-bar / L
+  if (n * reduced_y_pitch(n) > big) big = n * reduced_y_pitch(n);  // Y of r_a (two rounds: then of r_bb) over it
+  if (!two_round) big += n * reduced_y_pitch(n);                   // Y of r_bb
   return w + (w > n ? w : n) + 2 * n + big;  // dq (w), zc (later scratch of the substitutions: max(w, n)), q1, b~ (n each)
 }
 
@@ -264,12 +270,12 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
                                                                   double* __restrict__ rec, int* __restrict__ info,
                                                                   double* __restrict__ wfac) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  constexpr int n = 16 * NB, ns = n + 1;
+  constexpr int n = 16 * NB, ns = reduced_s_pitch(n);
   constexpr int NW = NTHR / 64;
   constexpr int NT = NB * (NB + 1) / 2;          // tiles of the lower triangle of S-bar / DL / DR: all that is ever read
   constexpr int MAXS = (NT + NW - 1) / NW;       // S-bar tiles per wavefront
   constexpr int MAXT = (2 * NB + NW - 1) / NW;   // panel column tiles (of r_a, r_bb) per wavefront
-  constexpr int PR = n + 1;                      // pitch of r_a, r_bb in the push phase
+  constexpr int PR = reduced_y_pitch(n);         // pitch of the panel halves in the push phase
   constexpr bool TWO = NW == NB;                 // two-round pushes on one coupling array (see above)
   static_assert(NW >= NB && n / 4 <= 16, "work distribution of the shared phases");
   // PAD: the block does not fill its tiles (nl < n rows / columns, or n + m not a multiple of 4). Everything in
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   double* S = bz + n;        // S-bar / L
   double* stage = S;         // [A_s | B_s], pitch P, until S-bar is formed
   double* Ra = S;            // r_a (pitch PR) once W is dead
-  double* Rb = TWO ? S : S + n * ns;  // Y of r_bb (pitch PR): written in phase B, or (two rounds) staged over that of r_a
+  double* Rb = TWO ? S : S + (n * ns > n * PR ? n * ns : n * PR);  // Y of r_bb (pitch PR): written in phase B, or (two rounds) staged over that of r_a
   const int P = reduced_stage_pitch(wp);
   const int tid = threadIdx.x;
   // (the wavefront index as a scalar: everything that depends on it branches uniformly)
@@ -732,7 +738,7 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
                                                                   double* __restrict__ rec,
                                                                   const double* __restrict__ wfac) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int nl = d.n, nnl = nl * nl, w = d.w, N = d.N, rows = d.rows, ns = np + 1;
+  const int nl = d.n, nnl = nl * nl, w = d.w, N = d.N, rows = d.rows, ns = reduced_s_pitch(np);
   const int b = blockIdx.y;
   const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
   const bool hasA = base > 0, hasB = base + T < N, first = s == 0, level0 = l == 0;
@@ -753,7 +759,7 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
   double* slotB = reduced_slot(red, d, b, hasB ? base + T - 1 : 1);
   double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nnl + nl);
   const double* wf = wfac + ((size_t)b * N + s) * reduced_wfac_doubles(np);
-  double* Sl = part + 256;  // the separator's factor, staged: L (pitch np + 1), the inverses of its diagonal blocks in their place
+  double* Sl = part + 256;  // the separator's factor, staged: L (pitch reduced_s_pitch(np)), the inverses of its diagonal blocks in their place
   auto Lo = [&](const int r, const int c) -> double { return Sl[r * ns + c]; };
   auto Di = Lo;
   auto wave_sum = [](double v) -> double {

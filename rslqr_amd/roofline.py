@@ -145,13 +145,12 @@ def generic_lean_model(n, m, N):
 def generic_reduced_model(n, m, N):
     """Separator-only schedule of the runtime-sized blocks (separator_reduced_mfma once per level,
     back-substitution over the records): config 5's path since round 2. DL, DR (and S-bar) are symmetric: only
-    the 16x16 tiles on and below the diagonal are computed, stored and read; level-0 records are compact (W
-    instead of f_a | f_bb: the last back-substitution launch re-forms their action from the inputs it reads
-    anyway)."""
+    the 16x16 tiles on and below the diagonal are computed, stored and read; the records are compact at every level
+    (round 3: the Cholesky factor, packed lower triangle, and y~ instead of f_a | f_bb | z_sep -- the
+    back-substitution re-forms their action from the couplings: the slots above level 0, the inputs at level 0)."""
     K = int(math.log2(N))
     w, rows = n + m, 2 * n + m
-    rec = 2 * n * n + n
-    rec0 = n * (n + 1) // 2 + n          # compact level-0 record: W (packed lower triangle) | z_sep
+    rec0 = n * (n + 1) // 2 + n          # compact record: factor (packed lower triangle) | y~
     sym = min(n * n, n * (n + 16) // 2)  # doubles of the lower tiles of an n x n block
     slot = 2 * sym + 2 * n * n + 2 * n   # DL, DR (lower tiles) | CA | CB | gL | gR
     push = 2 * sym + n * n + 2 * n       # DR + gR, DL + gL, one coupling block
@@ -162,12 +161,13 @@ def generic_reduced_model(n, m, N):
         if l == 0:
             sep_b += L * (own + n * n + rec0 + push)        # + A_{s+1} (r_bb); the pushes are stores
         else:
-            sep_b += L * (own + slot + rec + push + (2 * sym + 2 * n))  # + own slot; the pushes read-modify-write
+            sep_b += L * (own + slot + rec0 + push + (2 * sym + 2 * n))  # + own slot; the pushes read-modify-write
     return {
         "separator": {"bytes": 8 * sep_b, "flops": (N - 1) * separator_flops(n, w), "launches": K},
-        # every record once (level 0: the compact one), the inputs, the solution; K launches inside ONE event bracket
-        "apply": {"bytes": 8 * ((N // 2 - 1) * rec + (N // 2) * rec0 + inputs_doubles(n, m, N) + N * rows),
-                  "flops": backsub_flops(n, m, N) + (N // 2) * 2 * n * n, "launches": 1},
+        # every record once, the couplings CA | CB of the separators above level 0, the inputs, the solution; K launches
+        # inside ONE event bracket
+        "apply": {"bytes": 8 * ((N - 1) * rec0 + (N // 2 - 1) * 2 * n * n + inputs_doubles(n, m, N) + N * rows),
+                  "flops": backsub_flops(n, m, N) + (N - 1) * 2 * n * n, "launches": 1},
     }
 
 
