@@ -976,10 +976,11 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   };
   // out[c] = sum_j m[j * w + c] y[j], c < w (a block transposed times a vector): thread (c, seg) sums the rows
   // j = seg, seg + nseg, .. -- consecutive threads read consecutive words of a row of the block
-  auto block_t_times = [&](const double* m, const double* y, double* out) {
-    const int nseg = 2 * w <= nthr ? nthr / w : 1;
+  // (m: first column of the range, nc columns, row pitch w)
+  auto block_t_times = [&](const double* m, const int nc, const double* y, double* out) {
+    const int nseg = 2 * nc <= nthr ? nthr / nc : 1;
     if (nseg > 1) {
-      const int c = tid % w, seg = tid / w;
+      const int c = tid % nc, seg = tid / nc;
       double acc = 0.0;
       if (seg < nseg) {
         for (int j0 = seg; j0 < n; j0 += 8 * nseg) {  // eight loads in flight
@@ -998,12 +999,12 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
       __syncthreads();
       if (seg == 0) {
         double tot = 0.0;
-        for (int g = 0; g < nseg; ++g) tot += part[g * w + c];
+        for (int g = 0; g < nseg; ++g) tot += part[g * nc + c];
         out[c] = tot;
       }
       __syncthreads();
     } else {
-      for (int c = tid; c < w; c += nthr) {
+      for (int c = tid; c < nc; c += nthr) {
         double acc = 0.0;
         for (int j = 0; j < n; ++j) acc = fma(m[(size_t)j * w + c], y[j], acc);
         out[c] = acc;
@@ -1012,6 +1013,16 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
     }
   };
 
+  // (requested first, consumed behind the pass over [A_{s+1} | B_{s+1}]: see the product with A_s below)
+  double areg[16];
+  {
+    const int jc = lane < n ? lane : n - 1;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = wave + u * nwave;
+      areg[u] = ab[(size_t)(i < n ? i : n - 1) * w + jc];
+    }
+  }
   for (int e = tid; e < n * (n + 1) / 2; e += nthr) Wp[e] = myrec[e];
   for (int i = tid; i < n; i += nthr) {
     yA[i] = hasA ? zk[i] : 0.0;
@@ -1021,24 +1032,17 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   for (int e = tid; e < 2 * w; e += nthr) qv[e] = qr[e];
   for (int e = tid; e < 2 * rows; e += nthr) rv[e] = r0[e];
   __syncthreads();
-  block_t_times(ab1, yB, d1);  // [A_{s+1} | B_{s+1}]' y_{s+1}: enters t, x_{s+1} and u_{s+1}
-  // t = r_a y_A + r_bb y_B = -A_s (y_A / Q_s) - (A_{s+1}' y_{s+1}) / Q_{s+1}: a row of A_s per wavefront and round
-  for (int i0 = 4 * wave; i0 < n; i0 += 4 * nwave) {  // (four rows per wavefront and round: four loads in flight)
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (hasA) {
-      for (int j = lane; j < n; j += 64) {
-        const double yq = yA[j] / qv[j];
-        double av[4];
+  block_t_times(ab1, w, yB, d1);  // [A_{s+1} | B_{s+1}]' y_{s+1}: enters t, x_{s+1} and u_{s+1}
+  // t = r_a y_A + r_bb y_B = -A_s (y_A / Q_s) - (A_{s+1}' y_{s+1}) / Q_{s+1}. A_s stays in registers for the second
+  // product with it further down (A_s' y_s): wavefront wv holds the rows wv, wv + nwave, .. (at most sixteen: n <= 64
+  // with four wavefronts, <= 32 with two, <= 16 with one), lane = column -- every row is one coalesced request, all of
+  // them in flight together, and the block comes from HBM once.
+  {
+    const double yq = (hasA && lane < n) ? yA[lane] / qv[lane] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) av[u] = ab[(size_t)(i0 + u < n ? i0 + u : n - 1) * w + j];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = fma(av[u], yq, acc[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double a = wave_sum(acc[u]);
-      const int i = i0 + u;
+    for (int u = 0; u < 16; ++u) {
+      const int i = wave + u * nwave;
+      const double a = wave_sum(areg[u] * yq);
       if (lane == 0 && i < n) tv[i] = -a - (hasB ? d1[i] / qv[w + i] : 0.0);
     }
   }
@@ -1059,7 +1063,25 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
     zk[rows + tid] = yi;  // lambda rows of knot s + 1
   }
   __syncthreads();
-  block_t_times(ab, ys, d0);  // [A_s | B_s]' y_s  (second pass over the block: L2)
+  // [A_s | B_s]' y_s: the state columns from the registers (partial sums per wavefront, then across them), the input
+  // columns from memory (their first and only pass)
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = wave + u * nwave;
+      acc = fma(areg[u], i < n ? ys[i] : 0.0, acc);
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < n) {
+      double tot = 0.0;
+      for (int g = 0; g < nwave; ++g) tot += part[64 * g + tid];
+      d0[tid] = tot;
+    }
+    __syncthreads();
+    if (w > n) block_t_times(ab + n, w - n, ys, d0 + n);
+  }
   // states and inputs of knots s and s + 1 (the arithmetic of backsub_states_generic); thread -> (knot, row)
   for (int e = tid; e < 2 * rows; e += nthr) {
     const int kk = e / rows, r = e - kk * rows, k = s + kk;

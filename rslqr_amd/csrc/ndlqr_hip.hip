@@ -442,7 +442,6 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   p.threads = wpad <= 64 * p.nb ? 64 * p.nb : (p.nb >= 3 ? 512 : 256);
   if (wpad > p.threads) return p;  // one weight / rhs entry per thread
   p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(npad, wpad, p.threads == 64 * p.nb);
-  if (const char* e = getenv("NDLQR_LDS_PAD")) p.lds += (size_t)atoi(e);  // (experiment: fewer workgroups per CU)
   if (p.lds > 160 * 1024) return p;
   p.ok = true;
   return p;
