@@ -297,7 +297,11 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   const int P = reduced_stage_pitch(wp);
   const int tid = threadIdx.x;
   // (the wavefront index as a scalar: everything that depends on it branches uniformly)
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The roles of the wavefronts differ (the first factors the diagonal blocks, the second carries the rhs column, ..) and
+  // wavefront k of every workgroup lands on SIMD k of its CU: the roles rotate with the workgroup, or one SIMD of
+  // every CU carries all the diagonal blocks.
+  const int lane = tid & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (int)((blockIdx.x + (blockIdx.x >> 3) + (blockIdx.x >> 6) + blockIdx.y) % NW)) % NW;
   const int li = lane & 15, lk = lane >> 4;
   SEG_INIT();
 
