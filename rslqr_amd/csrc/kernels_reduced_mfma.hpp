@@ -84,10 +84,11 @@ __host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n *
 // two_round: one wavefront per tile column (NTHR = 64 NB): r_a and r_bb take turns in ONE array over the dead
 // S-bar / W (no separate r_bb array)
 __host__ __device__ inline int reduced_lds_doubles(const int n, const int w, const bool two_round) {
-  int big = n * reduced_stage_pitch(w);  // staged [A_s | B_s]
-  if (n * reduced_s_pitch(n) > big) big = n * reduced_s_pitch(n);  // S-bar / L
-  if (n * reduced_y_pitch(n) > big) big = n * reduced_y_pitch(n);  // Y of r_a (two rounds: then of r_bb) over it
-  if (!two_round) big += n * reduced_y_pitch(n);                   // Y of r_bb
+  // S-bar / L, then Y of r_a (two rounds: and of r_bb) over it; otherwise Y of r_bb behind the two
+  int later = n * reduced_s_pitch(n) > n * reduced_y_pitch(n) ? n * reduced_s_pitch(n) : n * reduced_y_pitch(n);
+  if (!two_round) later += n * reduced_y_pitch(n);
+  int big = n * reduced_stage_pitch(w);  // staged [A_s | B_s]: dead before any of them
+  if (later > big) big = later;
   return w + (w > n ? w : n) + 2 * n + big;  // dq (w), zc (later scratch of the substitutions: max(w, n)), q1, b~ (n each)
 }
 
