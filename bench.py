@@ -106,6 +106,23 @@ def committed_traffic(n, m, N, batch, flags):
     return {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}, "profiles/" + name
 
 
+def committed_issue(n, m, N, batch, flags):
+    """{slot: entry of profiles/*_issue.json} (instructions per wavefront, fp64-pipe time per solve: tools/make_issue.py)
+    taken on exactly this source tree and workload, else ({}, why)."""
+    pdir = os.path.join(ROOT, "profiles")
+    sha = csrc_sha()
+    for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+        if not name.endswith("_issue.json"):
+            continue
+        try:
+            tj = json.load(open(os.path.join(pdir, name)))
+        except (OSError, ValueError):
+            continue
+        if tj.get("workload") == [n, m, N, batch, flags] and tj.get("csrc_sha") == sha:
+            return tj["kernels"], "profiles/" + name
+    return {}, "no committed SQ-counter summary of this tree for this workload"
+
+
 def cpu_baseline(n, m, N, probs, gpu_solutions):
     """Times the CPU checker on a bounded sample; returns (dict, parity_rel_err)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -292,6 +309,7 @@ def roofline_object(prof, steps, schedule, n, m, N, batch, flags, solves_per_s_p
     used = {k: v for k, v in prof.items() if v[1] > 0}
     model = rf.model_for(schedule, n, m, N)
     traffic, traffic_src = committed_traffic(n, m, N, batch, flags)
+    issue, issue_src = committed_issue(n, m, N, batch, flags)
     kernels = {}
     for slot, (ms, launches) in used.items():
         avg_ms = ms / launches
@@ -301,6 +319,14 @@ def roofline_object(prof, steps, schedule, n, m, N, batch, flags, solves_per_s_p
             entry.update(rf.kernel_roofline(model[slot], batch, avg_ms, launches / steps))
             assert 0.0 < entry["frac"] <= 1.0, (slot, entry)
         entry["traffic"] = traffic.get(slot)
+        if slot in issue:
+            # the time the launch's instructions take on the fp64 pipe of the SIMDs (vector and fp64 matrix-core
+            # instructions execute one after the other on gfx950): the bound of a kernel that is not waiting for memory
+            i = issue[slot]
+            entry["fp64_pipe"] = {"vector_per_wavefront": round(i["vector_per_wavefront"], 1),
+                                  "matrix_per_wavefront": round(i["matrix_per_wavefront"], 1),
+                                  "exec_ms_per_step": i["exec_ms_per_solve"],
+                                  "frac": i["exec_ms_per_solve"] / (ms / steps), "source": issue_src}
         kernels[slot] = entry
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     roofline = dict(kernels[dom])

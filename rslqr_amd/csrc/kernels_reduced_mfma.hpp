@@ -2,9 +2,9 @@
 // that has no size-specialised instance, on 16x16 matrix-core tiles (BASELINE.json config 5's (64,16) fills
 // them; other sizes are zero-padded in LDS). Fast mode without KEEP_FACT. One kernel, launched once per tree
 // level; no factor array, no knot states, no leaf pass, no Schur pass. With NDLQR_FLAG_KEEP_RECORDS the sweep
-// also keeps W = L^-1 of every separator, and rhs_reduced_generic (below) re-solves for new right-hand sides.
+// also keeps the Cholesky factor of every separator, and rhs_reduced_generic (below) re-solves for new right-hand sides.
 //
-// DESIGN.md section 3.1 (same algebra as kernels_bottom_reduced.hpp, which serves 6 <= n <= 15):
+// DESIGN.md section 3.5a (same algebra as kernels_bottom_reduced.hpp, which serves 6 <= n <= 15):
 // eliminating the states and inputs of every knot (ndlqr_SolveLeaf, src/nested_dissection.c:10-105)
 // leaves a block-tridiagonal system in the multipliers,
 //     leafS_s = [A_s | B_s] diag(1/Q_s, 1/R_s) [A_s | B_s]' + Q_{s+1}^-1
@@ -14,11 +14,14 @@
 // of src/solve.c:87-98, ndlqr_SolveCholeskyFactor :136-152, ndlqr_UpdateShurFactor :154-171) are block
 // cyclic reduction on it. Separator s of level l with the subtree [base, base + 2^(l+1)), neighbours
 // A = base - 1 and B = base + 2^(l+1) - 1 (both of a higher level):
-//     S-bar = leafS - DL - DR      R = [r_a | r_bb | b~],  r_a = -CA, r_bb = -CB (level 0: from the data),
-//                                  b~ = leafb - gL - gR
-//     X = S-bar^-1 R = [f_a | f_bb | z_sep]                  -> record of s (back-substitution; level 0: W | z_sep)
-//     DR[A] += r_a' f_a    gR[A] += r_a' z_sep    DL[B] += r_bb' f_bb    gL[B] += r_bb' z_sep
-//     left child of B:  CA[B] = f_bb' r_a          right child of A:  CB[A] = r_a' f_bb
+//     S-bar = leafS - DL - DR = L L'   R = [r_a | r_bb | b~],  r_a = -CA, r_bb = -CB (level 0: from the data),
+//                                      b~ = leafb - gL - gR
+//     Y = L^-1 R = [Y_a | Y_b | y~]    (X = S-bar^-1 R = [f_a | f_bb | z_sep] of the reference is never formed)
+//     DR[A] += Y_a'Y_a    gR[A] += Y_a'y~    DL[B] += Y_b'Y_b    gL[B] += Y_b'y~      (= r_a' f_a, r_a' z_sep, ..)
+//     left child of B:  CA[B] = Y_b'Y_a          right child of A:  CB[A] = Y_a'Y_b   (= f_bb' r_a, r_a' f_bb)
+//     record of s: L (the inverses of its diagonal 16x16 blocks in their place), packed lower triangle, and y~; the
+//     back-substitution solves  y_s = L^-T (y~ - L^-1 (r_a y_A + r_bb y_B))  with the couplings from where this
+//     kernel read them (slot / problem data)
 // Every slot block has ONE writer per launch (a separator has one left and one right neighbour, a
 // neighbour one adjacent subtree per level and side), so the pushes are plain read-modify-writes;
 // the level-0 launch reaches DL, DR, gL, gR of every separator of a higher level and stores instead
@@ -48,37 +51,32 @@ __host__ __device__ constexpr int reduced_y_pitch(const int n) { return n % 32 =
 // NB = ceil(n / 16), NTHR threads (a multiple of 64, at least 64 NB and max(16 NB, n + m rounded up to 4)).
 //   grid (N >> (l+1), batch), block NTHR;
 //   dynamic LDS = reduced_lds_doubles(padded n, padded w) doubles: the weights / rhs arrays, then a region that
-//   first holds the staged [A_s | B_s] (n rows of reduced_stage_pitch(w)), then S-bar / L / W (n x (n + 1)), the
-//   inverses of the diagonal blocks (17 n) and r_bb (n x (n + 1)); r_a goes over S-bar once W is dead. 77 KB at
-//   (64,16): two workgroups per CU.
+//   first holds the staged [A_s | B_s] (n rows of reduced_stage_pitch(w)), then S-bar / L (n rows of reduced_s_pitch(n)),
+//   then the solved panel halves Y_a, Y_b (n rows of reduced_y_pitch(n)) for the pushes.
 // LEVEL0: the launch of tree level 0 (couplings from the problem data, pushes are stores). PAD: see below.
 // wfac != nullptr: NDLQR_FLAG_KEEP_RECORDS.
 // NTHR = 64 NB ("two rounds"): every wavefront solves column tile c of r_a AND of r_bb; the pushes run in two rounds on
-// ONE coupling array in LDS (r_a, then r_bb, each fetched again from L2) -- 45 KB instead of 77 KB at (64,16), so
-// that THREE workgroups share a CU. The kernel is bound by the latency chain of a workgroup, not by its
-// matrix-core time: four wavefronts per workgroup cost 4 % of a workgroup's throughput, the third workgroup
-// brings 50 % more of them.
+// ONE panel array in LDS (Y_a, then Y_b, both from the registers of phase B) -- 45 KB at (64,16): THREE workgroups
+// share a CU. NTHR = 128 NB (inputs too wide for the lanes of 64 NB threads): Y_b in its own array.
 //
 // Phases (workgroup barriers only between them):
 //   A  stage [A_s | B_s]; leafS tiles on the matrix cores; S-bar = leafS - DL - DR + Q_{s+1}^-1 into LDS; blocked
-//      Cholesky; blocked inverse W = L^-1 (sep_cholesky, sep_invert of kernels_mfma.hpp)
-//   B  the 2 NB column tiles of [r_a | r_bb] are dealt to the wavefronts (the column b~: vector ALU). A wavefront takes
-//      the operand fragments of its tile straight from global memory, forms Y = W R and X = W'Y in the
-//      accumulators -- an accumulator tile is at once the B operand of the next product, so nothing goes through
-//      LDS and nobody waits for anybody -- stores X into the record and KEEPS it in registers
-//   C  r_a into LDS over the dead S-bar / W, from the registers of phase B (r_bb went into its own array there):
-//      no operand is fetched twice
-//   D  pushes: the wavefront that holds column tile c of f_a forms the tiles of DR[A](:, c) = r_a' f_a(:, c) on and
+//      Cholesky with look-ahead (reduced_cholesky below); beside it y~ = L^-1 b~ (vector ALU) and the record stores
+//   B  the 2 NB column tiles of [r_a | r_bb] are dealt to the wavefronts. A wavefront takes the operand fragments of
+//      its tile straight from global memory and solves Y = L^-1 R by block forward substitution in the accumulators
+//      -- an accumulator tile is at once the B operand of the next product, so nothing goes through LDS and nobody
+//      waits for anybody -- and KEEPS Y in registers
+//   C  Y_a into LDS over the dead S-bar / L, from the registers (Y_b: its own array, or the second round)
+//   D  pushes: the wavefront that holds column tile c of Y_a forms the tiles of DR[A](:, c) = Y_a' Y_a(:, c) on and
 //      below the diagonal (DR, DL and S-bar are symmetric: their upper tiles are neither computed, stored nor
-//      read anywhere) and the coupling tiles (c, j <= c) as f_a' r_bb (= r_a' S-bar^-1 r_bb); the one that holds
-//      tile c of f_bb forms the lower tiles of DL[B](:, c) and the coupling tiles (i < c, c) as r_a' f_bb: NB + 1
-//      and NB tile products, the solved operand from registers
+//      read anywhere) and the coupling tiles (c, j <= c) as Y_a' Y_b; the one that holds tile c of Y_b forms the lower
+//      tiles of DL[B](:, c) and the coupling tiles (i < c, c): NB + 1 and NB tile products, one operand from registers
 // Written for memory-level parallelism: loads are unconditional on clamped indices and requested as early as
 // their address is known, LDS stores likewise (a store under a lane predicate makes the compiler sink its load
 // behind the predicate, and the loads then complete one after the other).
 
-// what a separator keeps for the record-based re-solve: the n x (n + 1) array that holds W below its diagonal
-// blocks, then the inverses of the diagonal blocks (n / 16 blocks of 16 x 17); n = padded block size
+// what a separator keeps for the record-based re-solve: S as it stands in LDS behind the Cholesky (L below the
+// diagonal blocks, the inverses of the diagonal blocks of L in their place); n = padded block size
 __host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * reduced_s_pitch(n); }
 
 // two_round: one wavefront per tile column (NTHR = 64 NB): r_a and r_bb take turns in ONE array over the dead

@@ -19,7 +19,7 @@ import bench  # noqa: E402  (csrc_sha)
 SLOTS = [("bottom", ("bottom_reduced_mc", "bottom_small", "rb_bottom")),
          ("upper", ("reduced_level_mc", "level_small")),
          ("top", ("reduced_top_mc",)),
-         ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_states_generic",
+         ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_multipliers_compact", "backsub_states_generic",
                     "backsub_level0_states_generic")),
          ("leaf", ("leaf_generic",)),
          ("separator", ("separator_generic", "separator_mfma", "separator_reduced_mfma")),

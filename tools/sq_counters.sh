@@ -31,3 +31,14 @@ with open("gpurun_out/${tag}_sq_summary.txt", "w") as out:
             out.write("    %-28s %.4g  (%d launches)\n" % (c, sum(v) / len(v), len(v)))
 print(open("gpurun_out/${tag}_sq_summary.txt").read())
 PY
+# instructions per wavefront and the fp64-pipe time of every kernel kind -> gpurun_out/TAG_issue.json (needs the workload:
+# default = the headline one)
+read nx nu N batch < <(python3 - "$@" <<PY
+import sys
+a = sys.argv[1:]
+g = lambda k, d: a[a.index(k) + 1] if k in a else d
+print(g("--nx", 12), g("--nu", 4), g("--horizon", 256), g("--batch", 1024))
+PY
+)
+python3 tools/make_issue.py $tag $nx $nu $N $batch 0 > gpurun_out/${tag}_issue.json
+

@@ -127,7 +127,57 @@ static void run(const char* name, int instr_per_rep8) {
   (void)hipFree(out); (void)hipFree(cyc);
 }
 
+// Two wavefronts per SIMD with DIFFERENT streams: wavefronts 0..3 (one per SIMD) issue `nm` v_mfma_f64_16x16x4
+// (4 accumulators), wavefronts 4..7 `nv` v_fma_f64 (8 chains). Do the two streams overlap on a SIMD, or does the
+// SIMD execute one at a time (elapsed = sum)?
+__global__ void mixed(double* out, long long* cyc, int trips_m, int trips_v) {
+  double a = out[threadIdx.x & 63], b = out[(threadIdx.x + 7) & 63];
+  double c0 = a, c1 = b, c2 = a + 1, c3 = b + 1, c4 = a + 2, c5 = b + 2, c6 = a + 3, c7 = b + 3;
+  d4 m0 = {a, b, a, b}, m1 = m0, m2 = m0, m3 = m0;
+  const bool mf = (threadIdx.x >> 6) < 4;  // (uniform per wavefront)
+  __syncthreads();
+  const long long t0 = clock64();
+  if (mf) {
+    for (int t = 0; t < trips_m; ++t)
+      asm volatile(
+          "v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n v_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n"
+          "v_mfma_f64_16x16x4_f64 %2, %4, %5, %2\n v_mfma_f64_16x16x4_f64 %3, %4, %5, %3\n"
+          "v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n v_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n"
+          "v_mfma_f64_16x16x4_f64 %2, %4, %5, %2\n v_mfma_f64_16x16x4_f64 %3, %4, %5, %3\n"
+          : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(a), "v"(b));
+  } else {
+    for (int t = 0; t < trips_v; ++t)
+      asm volatile(
+          "v_fma_f64 %0, %8, %9, %0\n v_fma_f64 %1, %8, %9, %1\n v_fma_f64 %2, %8, %9, %2\n v_fma_f64 %3, %8, %9, %3\n"
+          "v_fma_f64 %4, %8, %9, %4\n v_fma_f64 %5, %8, %9, %5\n v_fma_f64 %6, %8, %9, %6\n v_fma_f64 %7, %8, %9, %7\n"
+          : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));
+  }
+  const long long t1 = clock64();
+  out[64 + (threadIdx.x & 63)] = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7 + m0[0] + m1[1] + m2[2] + m3[3];
+  if ((threadIdx.x & 63) == 0) cyc[threadIdx.x / 64] = t1 - t0;
+}
+
+static void run_mixed() {
+  double* out; long long* cyc;
+  (void)hipMalloc(&out, 128 * sizeof(double)); (void)hipMalloc(&cyc, 64 * sizeof(long long));
+  std::vector<double> h(128, 0.0); for (int i = 0; i < 128; ++i) h[i] = 1e-3 * (i + 1);
+  // 512 x 8 matrix-core instructions (~ 262 k cycles alone) beside 0 / 6144 x 8 vector FMAs (~ 262 k cycles alone) and v.v.
+  const int cases[3][2] = {{512, 0}, {0, 6144}, {512, 6144}};
+  for (auto& cs : cases) {
+    (void)hipMemcpy(out, h.data(), 128 * sizeof(double), hipMemcpyHostToDevice);
+    mixed<<<1, 512>>>(out, cyc, cs[0], cs[1]);
+    mixed<<<1, 512>>>(out, cyc, cs[0], cs[1]);
+    (void)hipDeviceSynchronize();
+    long long c[8];
+    (void)hipMemcpy(c, cyc, sizeof(c), hipMemcpyDeviceToHost);
+    printf("two wavefronts per SIMD, %4d x 8 v_mfma_f64_16x16x4 on one, %4d x 8 v_fma_f64 on the other: matrix-core wavefront %8lld cycles, vector wavefront %8lld cycles\n",
+           cs[0], cs[1], c[0], c[4]);
+  }
+  (void)hipFree(out); (void)hipFree(cyc);
+}
+
 int main() {
+  run_mixed();
   run<0>("v_fma_f64 (8 chains)", 8);
   run<8>("v_fma_f64 (1 dependent chain)", 8);
   run<1>("v_fmac_f64_dpp row_newbcast (8 chains)", 8);
