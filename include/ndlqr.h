@@ -338,7 +338,7 @@ typedef struct NdLqrBatchSolver NdLqrBatchSolver;
                                      records + Cholesky factors, ~3.5 KB per knot at (12,4)) without
                                      materialising the factor array: ndlqr_SolveBatchRhsOnly works,
                                      ndlqr_CopyBatchFactors does not. Size-specialised shapes and every
-                                     other one up to 64 states (beyond: NDLQR_FLAG_KEEP_FACT). */
+                                     other one up to 128 states (beyond: NDLQR_FLAG_KEEP_FACT). */
 
 NdLqrBatchSolver* ndlqr_NewBatchSolver(int nstates, int ninputs, int nhorizon, int batch,
                                        int device);
@@ -360,7 +360,7 @@ int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0);
 int ndlqr_SolveBatch(NdLqrBatchSolver* bs);      /* launch + wait */
 /* Factor / solve split (MPC re-solves): replace q, r, d, x0 (flat layout as above) and run only
  * the solution sweep against the factorisation cached by the last ndlqr_SolveBatch; needs
- * NDLQR_FLAG_KEEP_FACT (or, in fast mode up to 64 states, the lighter
+ * NDLQR_FLAG_KEEP_FACT (or, in fast mode up to 128 states, the lighter
  * NDLQR_FLAG_KEEP_RECORDS) to have been set for that solve. A, B, Q, R are those of that solve. */
 int ndlqr_BatchSetRhsFlat(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
                           const double* x0);

@@ -260,7 +260,7 @@ __device__ __forceinline__ void reduced_cholesky(double* S, const int ns, const 
 
 // wavefronts per SIMD the register budget is cut for: what LDS lets share a CU (two-round mode at n = 48, 64: three or
 // four workgroups of NB wavefronts)
-constexpr int reduced_min_waves(const int nb, const int nthr) { return (nthr == 64 * nb && nb >= 3) ? 3 : 4; }
+constexpr int reduced_min_waves(const int nb, const int nthr) { return nb >= 5 ? 1 : ((nthr == 64 * nb && nb >= 3) ? 3 : 4); }
 
 template <int NB, int NTHR, bool LEVEL0, bool PAD>
 __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
   constexpr int MAXT = (2 * NB + NW - 1) / NW;   // panel column tiles (of r_a, r_bb) per wavefront
   constexpr int PR = reduced_y_pitch(n);         // pitch of the panel halves in the push phase
   constexpr bool TWO = NW == NB;                 // two-round pushes on one coupling array (see above)
-  static_assert(NW >= NB && n / 4 <= 16, "work distribution of the shared phases");
+  static_assert(NW >= NB && NTHR >= n && n <= 128, "work distribution of the shared phases");
   // PAD: the block does not fill its tiles (nl < n rows / columns, or n + m not a multiple of 4). Everything in
   // global memory keeps the problem's own pitch nl; LDS holds the padded tiles: zero rows / columns of [A | B], r_a,
   // r_bb, DL, DR, unit diagonal of S-bar (so L, W are the identity there and the padding never reaches a result).
@@ -485,20 +485,25 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
     constexpr int SW0 = NW >= 3 ? 2 : YW, NSW = NW - SW0;  // the wavefronts that store
     if (wv == YW) {
       tri_forward_block(jb, n, bz, zc, lane, At, At);
-      if (jb == NB - 1 && lane < nl) myrec[2 * nnl + lane] = bz[lane];
+      if (jb == NB - 1)
+        for (int i = lane; i < nl; i += 64) myrec[2 * nnl + i] = bz[i];
     }
     if (wv >= SW0) {
+      constexpr int KC = (n + 63) / 64;  // lanes along a row of L: one or two entries each
       for (int r0 = wv - SW0; r0 < 16; r0 += 4 * NSW) {
-        double v[4];
+        double v[4][KC];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = 16 * jb + r0 + u * NSW, ic = i < n ? i : n - 1;
-          v[u] = S[ic * ns + (lane <= ic ? lane : ic)];
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) v[u][kc] = S[ic * ns + (lane + 64 * kc <= ic ? lane + 64 * kc : ic)];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int r = r0 + u * NSW, i = 16 * jb + r;
-          if (r < 16 && i < nl && lane <= i) myrec[(size_t)i * (i + 1) / 2 + lane] = v[u];
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc)
+            if (r < 16 && i < nl && lane + 64 * kc <= i) myrec[(size_t)i * (i + 1) / 2 + lane + 64 * kc] = v[u][kc];
         }
       }
     }
@@ -808,8 +813,10 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
   // y~ = L^-1 b~ -> record, and z_sep = L^-T y~ for the pushes (block substitutions, first wavefront)
   if (wave == 0) {
     for (int ib = 0; ib < np / 16; ++ib) tri_forward_block(ib, np, bz, yv, lane, Lo, Di);
-    if (lane < nl) myrec[2 * nnl + lane] = bz[lane];
-    if (lane < np) zs[lane] = bz[lane];
+    for (int i = lane; i < np; i += 64) {
+      if (i < nl) myrec[2 * nnl + i] = bz[i];
+      zs[i] = bz[i];
+    }
     wave_lds_order();
     for (int ib = np / 16 - 1; ib >= 0; --ib) tri_backward_block(ib, np, zs, yv, lane, Lo, Di);
   }
@@ -929,10 +936,10 @@ static __global__ __launch_bounds__(256) void backsub_multipliers_compact(Dims d
     auto P = [&](const int i, const int k) -> double { return Lp[i * (i + 1) / 2 + k]; };
     const int nblk = (n + 15) >> 4;
     for (int ib = 0; ib < nblk; ++ib) tri_forward_block(ib, n, tv, tmp, lane, P, P);
-    if (lane < n) tv[lane] += yt[lane];  // (n <= 64)
+    for (int i = lane; i < n; i += 64) tv[i] += yt[i];
     wave_lds_order();
     for (int ib = nblk - 1; ib >= 0; --ib) tri_backward_block(ib, n, tv, tmp, lane, P, P);
-    if (lane < n) out[lane] = tv[lane];
+    for (int i = lane; i < n; i += 64) out[i] = tv[i];
   }
 }
 
@@ -1017,13 +1024,14 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   };
 
   // (requested first, consumed behind the pass over [A_{s+1} | B_{s+1}]: see the product with A_s below)
+  const bool wide = n > 64;  // (uniform) more than 64 states: A_s does not fit the registers this way, it is read twice
   double areg[16];
   {
     const int jc = lane < n ? lane : n - 1;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int i = wave + u * nwave;
-      areg[u] = ab[(size_t)(i < n ? i : n - 1) * w + jc];
+      areg[u] = wide ? 0.0 : ab[(size_t)(i < n ? i : n - 1) * w + jc];
     }
   }
   for (int e = tid; e < n * (n + 1) / 2; e += nthr) Wp[e] = myrec[e];
@@ -1037,16 +1045,36 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   __syncthreads();
   block_t_times(ab1, w, yB, d1);  // [A_{s+1} | B_{s+1}]' y_{s+1}: enters t, x_{s+1} and u_{s+1}
   // t = r_a y_A + r_bb y_B = -A_s (y_A / Q_s) - (A_{s+1}' y_{s+1}) / Q_{s+1}. A_s stays in registers for the second
-  // product with it further down (A_s' y_s): wavefront wv holds the rows wv, wv + nwave, .. (at most sixteen: n <= 64
-  // with four wavefronts, <= 32 with two, <= 16 with one), lane = column -- every row is one coalesced request, all of
+  // product with it further down (A_s' y_s), up to 64 states: wavefront wv holds the rows wv, wv + nwave, .. (at most
+  // sixteen: n <= 64 with four wavefronts, <= 32 with two, <= 16 with one), lane = column -- every row is one coalesced request, all of
   // them in flight together, and the block comes from HBM once.
-  {
+  if (!wide) {
     const double yq = (hasA && lane < n) ? yA[lane] / qv[lane] : 0.0;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int i = wave + u * nwave;
       const double a = wave_sum(areg[u] * yq);
       if (lane == 0 && i < n) tv[i] = -a - (hasB ? d1[i] / qv[w + i] : 0.0);
+    }
+  } else {
+    for (int i0 = 4 * wave; i0 < n; i0 += 4 * nwave) {  // four rows of A_s per wavefront and round, lanes along the row
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (hasA) {
+        for (int j = lane; j < n; j += 64) {
+          const double yq = yA[j] / qv[j];
+          double av[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) av[u] = ab[(size_t)(i0 + u < n ? i0 + u : n - 1) * w + j];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] = fma(av[u], yq, acc[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double a = wave_sum(acc[u]);
+        const int i = i0 + u;
+        if (lane == 0 && i < n) tv[i] = -a - (hasB ? d1[i] / qv[w + i] : 0.0);
+      }
     }
   }
   __syncthreads();
@@ -1055,7 +1083,7 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
     auto P = [&](const int i, const int k) -> double { return Wp[i * (i + 1) / 2 + k]; };
     const int nblk = (n + 15) >> 4;
     for (int ib = 0; ib < nblk; ++ib) tri_forward_block(ib, n, tv, part, lane, P, P);
-    if (lane < n) tv[lane] = zs[lane] - tv[lane];  // (n <= 64)
+    for (int i = lane; i < n; i += 64) tv[i] = zs[i] - tv[i];
     wave_lds_order();
     for (int ib = nblk - 1; ib >= 0; --ib) tri_backward_block(ib, n, tv, part, lane, P, P);
   }
@@ -1068,7 +1096,7 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   __syncthreads();
   // [A_s | B_s]' y_s: the state columns from the registers (partial sums per wavefront, then across them), the input
   // columns from memory (their first and only pass)
-  {
+  if (!wide) {
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -1084,6 +1112,8 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
     }
     __syncthreads();
     if (w > n) block_t_times(ab + n, w - n, ys, d0 + n);
+  } else {
+    block_t_times(ab, w, ys, d0);
   }
   // states and inputs of knots s and s + 1 (the arithmetic of backsub_states_generic); thread -> (knot, row)
   for (int e = tid; e < 2 * rows; e += nthr) {

@@ -430,7 +430,7 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   ReducedGenericPlan p = {false, 0, 0, 0, false, false};
   if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT)) return p;
-  if (c->no_mfma || d.n > 64 || d.N < 2) return p;
+  if (c->no_mfma || d.n > 128 || d.N < 2) return p;
   p.keep = (c->flags & NDLQR_FLAG_KEEP_RECORDS) != 0;  // W of every separator kept for rhs-only re-solves
   p.nb = (d.n + 15) / 16;
   const int npad = 16 * p.nb, wpad = (d.w + 3) / 4 * 4;
@@ -441,6 +441,7 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   // workgroups, three or more of them per CU), else twice that
   p.threads = wpad <= 64 * p.nb ? 64 * p.nb : (p.nb >= 3 ? 512 : 256);
   if (wpad > p.threads) return p;  // one weight / rhs entry per thread
+  if (p.nb >= 5 && p.threads != 64 * p.nb) return p;  // (beyond 64 states the second panel array does not fit the LDS)
   p.lds = sizeof(double) * (size_t)ndlqr::reduced_lds_doubles(npad, wpad, p.threads == 64 * p.nb);
   if (p.lds > 160 * 1024) return p;
   p.ok = true;
@@ -540,9 +541,21 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
         if (p.threads == 192) NDLQR_LAUNCH_SEP(3, 192);
         else NDLQR_LAUNCH_SEP(3, 512);
         break;
-      default:
+      case 4:
         if (p.threads == 256) NDLQR_LAUNCH_SEP(4, 256);
         else NDLQR_LAUNCH_SEP(4, 512);
+        break;
+      case 5:  // (beyond 64 states: one workgroup per CU, the form with one wavefront per tile column only)
+        NDLQR_LAUNCH_SEP(5, 320);
+        break;
+      case 6:
+        NDLQR_LAUNCH_SEP(6, 384);
+        break;
+      case 7:
+        NDLQR_LAUNCH_SEP(7, 448);
+        break;
+      default:
+        NDLQR_LAUNCH_SEP(8, 512);
         break;
     }
 #undef NDLQR_LAUNCH_SEP2

@@ -139,12 +139,13 @@ def test_json_fixture_through_dropin_api(ndlqr, oracle, fname):
 
 
 @pytest.mark.parametrize("n,m,N,batch", [(64, 16, 32, 2), (32, 8, 64, 2), (20, 20, 16, 3), (32, 16, 64, 2),
-                                         (16, 16, 128, 3), (48, 16, 16, 2), (72, 8, 8, 1), (80, 16, 4, 1)])
+                                         (16, 16, 128, 3), (48, 16, 16, 2), (72, 8, 8, 1), (80, 16, 4, 1), (16, 300, 4, 1)])
 def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
     """Shapes without a specialised instance (config 5 family, nx=64 nu=16) run the runtime-sized
     kernels; where the blocks fill 16x16 tiles the fast mode puts the Schur update on
     v_mfma_f64_16x16x4_f64 (kernels_mfma.hpp). Strict mode bit-exact, fast mode within tolerance. (Fast mode
-    without KEEP: the separator-only schedule up to 64 states, the knot-based lean schedule beyond.)"""
+    without KEEP: the separator-only schedule up to 128 states -- beyond what the knot-based kernels reach --, the knot-based
+    lean schedule only where the inputs are wider than a workgroup.)"""
     probs = [synth(ndlqr, n, m, N, 900 + p) for p in range(batch)]
     # strict + KEEP, fast + KEEP (full Schur passes), fast without KEEP (boundary knots only +
     # back-substitution over the separator records)
@@ -154,7 +155,7 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
         bs.initialize_flat(*stack(probs))
         assert bs.solve() == 0
         if not strict and not keep:
-            assert bs.schedule() == ("generic-reduced" if n <= 64 else "generic-lean")
+            assert bs.schedule() == ("generic-reduced" if n + m <= 256 else "generic-lean")  # (inputs wider than a workgroup)
         sol = bs.solutions()
         for p, prob in enumerate(probs):
             z, fact, _, fails = oracle.solve(prob, 8, want_fact=True)
@@ -175,9 +176,13 @@ def test_large_blocks_generic_path(ndlqr, oracle, n, m, N, batch):
                                          (20, 20, 16, 3), (7, 9, 16, 2), (5, 3, 32, 2), (1, 1, 4, 2), (17, 3, 16, 2),
                                          (33, 5, 8, 2), (50, 10, 64, 2), (63, 1, 16, 2), (64, 15, 16, 1), (3, 1, 2, 2),
                                          # inputs too wide for one wavefront per tile column: the larger workgroups
-                                         (64, 200, 8, 1), (48, 150, 8, 1), (32, 100, 8, 2), (16, 60, 16, 2)])
+                                         (64, 200, 8, 1), (48, 150, 8, 1), (32, 100, 8, 2), (16, 60, 16, 2),
+                                         # beyond 64 states: five to eight tile columns, one workgroup per CU
+                                         (80, 16, 16, 2), (96, 16, 8, 1), (72, 8, 32, 2), (90, 6, 8, 1), (65, 3, 4, 1),
+                                         (96, 32, 4, 1), (112, 16, 8, 1), (128, 16, 8, 2), (120, 10, 8, 1), (100, 4, 4, 1),
+                                         (113, 7, 4, 1)])
 def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch, monkeypatch):
-    """Every block size up to 64 states takes the separator-only schedule on the matrix cores on ITS OWN block size
+    """Every block size up to 128 states (whose staged [A | B] fits the LDS) takes the separator-only schedule on the matrix cores on ITS OWN block size
     (kernels_reduced_mfma.hpp: one launch per tree level, no factor array), down to a single separator (N = 2);
     blocks that do not fill 16x16 tiles are zero-padded in LDS. (NDLQR_NO_PAD=1: by default a block size below 16
     states without a size-specialised instance runs padded inside the next instance instead, test_padded_shapes.)
@@ -198,8 +203,11 @@ def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch, mon
     assert np.all(res <= 1e-9 * np.maximum(1.0, bnorm))
     # strict mode and KEEP_FACT leave the schedule (they need the factor array)
     bs.set_flags(ndlqr.FLAG_KEEP_FACT)
-    assert bs.solve() == 0 and bs.schedule() == "generic-keep"
-    assert np.linalg.norm(bs.solution(0) - refs[0]) / np.linalg.norm(refs[0]) <= REL_TOL
+    if 3 * n * n + 2 * n <= 20480 or (n % 16 == 0 and (n + m) % 4 == 0 and n * (n + 1) + 66 * n <= 20480):
+        assert bs.solve() == 0 and bs.schedule() == "generic-keep"
+        assert np.linalg.norm(bs.solution(0) - refs[0]) / np.linalg.norm(refs[0]) <= REL_TOL
+    else:  # (the knot-based separator kernel stages S-bar and the panel in LDS: up to 82 states, tile-filling blocks up to 112)
+        assert bs.solve() == -1
     bs.close()
     if N >= 4:
         bad = probs[0]
@@ -251,7 +259,8 @@ def test_non_spd_block_is_reported(ndlqr):
 
 @pytest.mark.parametrize("n,m,N", [(12, 4, 64), (12, 4, 256), (6, 3, 32), (13, 4, 16), (4, 1, 8), (10, 4, 128),
                                    # runtime-sized separator-only schedule: records + slots + W of every separator
-                                   (16, 4, 16), (20, 20, 16), (64, 16, 32), (7, 9, 8), (16, 4, 2), (33, 5, 4), (48, 16, 64)])
+                                   (16, 4, 16), (20, 20, 16), (64, 16, 32), (7, 9, 8), (16, 4, 2), (33, 5, 4), (48, 16, 64),
+                                   (80, 16, 8), (90, 5, 4), (128, 8, 4), (100, 4, 4)])
 def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
     """NDLQR_FLAG_KEEP_RECORDS: the lean fast-mode solve keeps just the separator records and
     factors; new right-hand sides are then solved without the factor array -- also after the
@@ -279,8 +288,8 @@ def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
     with pytest.raises(RuntimeError):  # no factor array in this mode
         bs.factors(0)
     bs.close()
-    # beyond 64 states (knot-based runtime-sized kernels) a re-solve needs the factor array: NDLQR_FLAG_KEEP_FACT
-    bs = ndlqr.BatchSolver(72, 2, 4, 1, flags=ndlqr.FLAG_KEEP_RECORDS)
+    # on the knot-based runtime-sized kernels (inputs wider than a workgroup) a re-solve needs the factor array: NDLQR_FLAG_KEEP_FACT
+    bs = ndlqr.BatchSolver(16, 300, 4, 1, flags=ndlqr.FLAG_KEEP_RECORDS)
     bs.initialize_synthetic(5)
     assert bs.solve() == 0
     assert bs.solve_rhs_only() == -1

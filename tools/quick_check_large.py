@@ -16,8 +16,11 @@ shapes = [(16, 4, 2, 2), (16, 4, 4, 2), (16, 4, 8, 3), (16, 16, 128, 3), (32, 8,
           # blocks that do not fill their tiles (zero-padded in LDS)
           (20, 20, 16, 2), (7, 9, 16, 3), (3, 1, 2, 2), (1, 1, 4, 2), (5, 3, 32, 3), (24, 6, 32, 2), (17, 3, 16, 2),
           (33, 5, 8, 2), (50, 10, 64, 2), (64, 15, 16, 2), (63, 1, 16, 2), (15, 2, 256, 2),
-          # beyond 64 states: the knot-based runtime-sized kernels
-          (72, 8, 8, 1)]
+          # beyond 64 states: five / six tile columns
+          (72, 8, 8, 1), (80, 16, 16, 2), (96, 16, 32, 2), (90, 6, 8, 1), (65, 3, 4, 1), (96, 32, 4, 1),
+          (112, 16, 8, 1), (128, 16, 16, 2), (128, 8, 4, 1), (100, 4, 4, 1), (120, 10, 8, 1), (97, 3, 4, 1), (113, 7, 4, 1),
+          # inputs wider than a workgroup: the knot-based runtime-sized kernels
+          (16, 300, 4, 1)]
 for (n, m, N, batch) in shapes:
     bs = R.BatchSolver(n, m, N, batch)
     bs.initialize_synthetic(11)
