@@ -78,7 +78,6 @@ struct NdlqrHipCtx {
   double* ytop; // [batch][N/8][n] multipliers of the separators of level >= 3 (rb_backsub_top -> rb_backsub)
   double* red;  // accumulators of the separator-only schedules: [batch][N/4][slot] (size-specialised shapes, allocated with the context) or [batch][N/2][4 n^2 + 2 n] (runtime-sized schedule, on its first solve)
   size_t red_bytes;
-  double* wfac;  // [batch][N][reduced_wfac_doubles(np)] Cholesky factor of every separator (runtime-sized separator-only schedule with NDLQR_FLAG_KEEP_RECORDS; allocated on the first such solve)
   int rowbcast;  // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom): NDLQR_ROWBCAST=1 always, 0 never (bottom_reduced_mc), unset (-1): by block size
   int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
   int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; zero between solves (reset by the root's wavefront)

@@ -54,7 +54,6 @@ __host__ __device__ constexpr int reduced_y_pitch(const int n) { return n % 32 =
 //   first holds the staged [A_s | B_s] (n rows of reduced_stage_pitch(w)), then S-bar / L (n rows of reduced_s_pitch(n)),
 //   then the solved panel halves Y_a, Y_b (n rows of reduced_y_pitch(n)) for the pushes.
 // LEVEL0: the launch of tree level 0 (couplings from the problem data, pushes are stores). PAD: see below.
-// wfac != nullptr: NDLQR_FLAG_KEEP_RECORDS.
 // NTHR = 64 NB ("two rounds"): every wavefront solves column tile c of r_a AND of r_bb; the pushes run in two rounds on
 // ONE panel array in LDS (Y_a, then Y_b, both from the registers of phase B) -- 45 KB at (64,16): THREE workgroups
 // share a CU. NTHR = 128 NB (inputs too wide for the lanes of 64 NB threads): Y_b in its own array.
@@ -74,10 +73,6 @@ __host__ __device__ constexpr int reduced_y_pitch(const int n) { return n % 32 =
 // Written for memory-level parallelism: loads are unconditional on clamped indices and requested as early as
 // their address is known, LDS stores likewise (a store under a lane predicate makes the compiler sink its load
 // behind the predicate, and the loads then complete one after the other).
-
-// what a separator keeps for the record-based re-solve: S as it stands in LDS behind the Cholesky (L below the
-// diagonal blocks, the inverses of the diagonal blocks of L in their place); n = padded block size
-__host__ __device__ constexpr int reduced_wfac_doubles(const int n) { return n * reduced_s_pitch(n); }
 
 // two_round: one wavefront per tile column (NTHR = 64 NB): r_a and r_bb take turns in ONE array over the dead
 // S-bar / W (no separate r_bb array)
@@ -266,8 +261,7 @@ template <int NB, int NTHR, bool LEVEL0, bool PAD>
 __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_reduced_mfma(Dims d, int l, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
                                                                   const double* __restrict__ rhs, double* red,
-                                                                  double* __restrict__ rec, int* __restrict__ info,
-                                                                  double* __restrict__ wfac) {
+                                                                  double* __restrict__ rec, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int n = 16 * NB, ns = reduced_s_pitch(n);
   constexpr int NW = NTHR / 64;
@@ -526,11 +520,6 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
         else rfk[m][kb][q] = LEVEL0 ? ab1[(size_t)j * w + k] : myslot[3 * nnl + k * nl + j];
       }
   }
-  if (wfac) {  // NDLQR_FLAG_KEEP_RECORDS: the factor as it stands in S, for rhs-only re-solves
-    constexpr int WF = reduced_wfac_doubles(n);
-    double* wf = wfac + ((size_t)b * N + s) * WF;
-    for (int e = tid; e < WF; e += NTHR) wf[e] = S[e];
-  }
   SEG(54);
   // ================================================================================================= phase B
   // Column tile gt of the panel: [0, NB) columns of r_a, [NB, 2 NB) of r_bb. Y = L^-1 R by block forward
@@ -733,20 +722,19 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
 
 
 // ------------------------------------------------------------------------------------- rhs-only re-solve
-// New q, r, d, x0 against the factorisation of a separator_reduced_mfma sweep that ran with
-// NDLQR_FLAG_KEEP_RECORDS: per level, vector work only --
-//     b~ = leafb - gL - gR,   z_sep = W'(W b~)  -> record,   gR[A] (+)= r_a' z_sep,   gL[B] (+)= r_bb' z_sep
-// with W from `wfac`, r_a = -CA, r_bb = -CB from the slots the factorisation left behind (level 0: from the
-// problem data); f_a, f_bb of the records stay. The back-substitution then runs as after a full solve.
+// New q, r, d, x0 against the factorisation a separator_reduced_mfma sweep left behind (the solver
+// keeps it when NDLQR_FLAG_KEEP_RECORDS is set): per level, vector work only --
+//     b~ = leafb - gL - gR,   y~ = L^-1 b~  -> record,   z_sep = L^-T y~,   gR[A] (+)= r_a' z_sep,   gL[B] (+)= r_bb' z_sep
+// with L (packed, the inverses of its diagonal blocks in their place) from the separator's compact record, r_a = -CA,
+// r_bb = -CB from the slots (level 0: from the problem data). The back-substitution then runs as after a full solve.
 // Runtime-sized; np = padded block size of the factorisation.
-//   grid (N >> (l+1), batch), block 256, dynamic LDS = 2 (n + m) + n + 3 np + 256 + reduced_wfac_doubles(np) doubles.
+//   grid (N >> (l+1), batch), block 256, dynamic LDS = 2 (n + m) + n + 3 np + 256 + n (n + 1) / 2 doubles.
 static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l, int np, const double* __restrict__ AB,
                                                                   const double* __restrict__ QR,
                                                                   const double* __restrict__ rhs, double* red,
-                                                                  double* __restrict__ rec,
-                                                                  const double* __restrict__ wfac) {
+                                                                  double* __restrict__ rec) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int nl = d.n, nnl = nl * nl, w = d.w, N = d.N, rows = d.rows, ns = reduced_s_pitch(np);
+  const int nl = d.n, nnl = nl * nl, w = d.w, N = d.N, rows = d.rows;
   const int b = blockIdx.y;
   const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
   const bool hasA = base > 0, hasB = base + T < N, first = s == 0, level0 = l == 0;
@@ -766,23 +754,21 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
   double* slotA = reduced_slot(red, d, b, hasA ? base - 1 : 1);
   double* slotB = reduced_slot(red, d, b, hasB ? base + T - 1 : 1);
   double* myrec = rec + ((size_t)b * N + s) * (2 * (size_t)nnl + nl);
-  const double* wf = wfac + ((size_t)b * N + s) * reduced_wfac_doubles(np);
-  double* Sl = part + 256;  // the separator's factor, staged: L (pitch reduced_s_pitch(np)), the inverses of its diagonal blocks in their place
-  auto Lo = [&](const int r, const int c) -> double { return Sl[r * ns + c]; };
-  auto Di = Lo;
+  double* Lp = part + 256;  // the separator's factor from its compact record: packed lower triangle, staged
+  auto P = [&](const int r, const int c) -> double { return Lp[r * (r + 1) / 2 + c]; };
   auto wave_sum = [](double v) -> double {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
   };
   {  // the factor: every load in flight before the first LDS store
-    const int WF = reduced_wfac_doubles(np);
+    const int WF = nl * (nl + 1) / 2;
     for (int e0 = 0; e0 < WF; e0 += 8 * 256) {
       double t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; t[u] = wf[e < WF ? e : WF - 1]; }
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; t[u] = myrec[e < WF ? e : WF - 1]; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; if (e < WF) Sl[e] = t[u]; }
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; if (e < WF) Lp[e] = t[u]; }
     }
   }
 
@@ -812,13 +798,14 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
   __syncthreads();
   // y~ = L^-1 b~ -> record, and z_sep = L^-T y~ for the pushes (block substitutions, first wavefront)
   if (wave == 0) {
-    for (int ib = 0; ib < np / 16; ++ib) tri_forward_block(ib, np, bz, yv, lane, Lo, Di);
+    const int nblk = (nl + 15) >> 4;
+    for (int ib = 0; ib < nblk; ++ib) tri_forward_block(ib, nl, bz, yv, lane, P, P);
     for (int i = lane; i < np; i += 64) {
       if (i < nl) myrec[2 * nnl + i] = bz[i];
-      zs[i] = bz[i];
+      zs[i] = i < nl ? bz[i] : 0.0;
     }
     wave_lds_order();
-    for (int ib = np / 16 - 1; ib >= 0; --ib) tri_backward_block(ib, np, zs, yv, lane, Lo, Di);
+    for (int ib = nblk - 1; ib >= 0; --ib) tri_backward_block(ib, nl, zs, yv, lane, P, P);
   }
   __syncthreads();
   // column sums sum_k f(k, j): thread (j, seg) takes k = seg, seg + nseg, ..; consecutive threads read consecutive

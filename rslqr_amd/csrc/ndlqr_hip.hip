@@ -95,7 +95,6 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->pad_stage = nullptr; c->pad_stage_cap = 0;
   c->device = device; c->flags = 0; c->stream = nullptr; c->own_stream = true;
   c->red_bytes = 0;
-  c->wfac = nullptr;
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
   c->pipeline = getenv("NDLQR_PIPELINE") ? atoi(getenv("NDLQR_PIPELINE")) : 2;
   c->solve_count = 0; c->in_alt = false; c->z_latest = nullptr; c->stream_latest = nullptr; c->h_fail_other = nullptr;
@@ -162,7 +161,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
-  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->wfac); (void)hipFree(c->xfer); (void)hipFree(c->pad_stage);
+  (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->xfer); (void)hipFree(c->pad_stage);
   for (double* h : c->h_stage) if (h) (void)hipHostFree(h);
   if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
   for (hipEvent_t ev : c->ev_step) if (ev) (void)hipEventDestroy(ev);
@@ -456,16 +455,6 @@ static size_t bytes_red_generic(const ndlqr::Dims& d) {
 // solve that takes it, for both buffer sets of the pipeline. Never zeroed: the level-0 launch stores
 // every accumulator block. Must run outside stream capture.
 static int ensure_red_generic(NdlqrHipCtx* c) {
-  if ((c->flags & NDLQR_FLAG_KEEP_RECORDS) && !c->wfac) {
-    const int np = (c->d.n + 15) / 16 * 16;
-    const size_t bytes = sizeof(double) * (size_t)c->d.batch * c->d.N * ndlqr::reduced_wfac_doubles(np);
-    if (hipMalloc(&c->wfac, bytes) != hipSuccess) {
-      c->wfac = nullptr;
-      (void)hipGetLastError();
-      g_last_error = "separator factors of NDLQR_FLAG_KEEP_RECORDS do not fit on the device";
-      return NDLQR_ERR_INVALID;
-    }
-  }
   if (c->d.N < 4) return NDLQR_OK;  // a single separator: no slots
   const size_t need = bytes_red_generic(c->d);
   for (int which = 0; which < 2; ++which) {
@@ -520,7 +509,7 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
     const dim3 grid(d.N >> (l + 1), d.batch);
 #define NDLQR_LAUNCH_SEP2(NB_, NT_, L0_, PAD_)                                                                     \
   hipLaunchKernelGGL((ndlqr::separator_reduced_mfma<NB_, NT_, L0_, PAD_>), grid, dim3(NT_), p.lds, c->stream, d, l, \
-                     c->AB, c->QR, c->rhs, c->red, c->rec, c->info, p.keep ? c->wfac : (double*)nullptr)
+                     c->AB, c->QR, c->rhs, c->red, c->rec, c->info)
 #define NDLQR_LAUNCH_SEP(NB_, NT_)                                          \
   do {                                                                      \
     if (l == 0 && p.pad) NDLQR_LAUNCH_SEP2(NB_, NT_, true, true);           \
@@ -569,11 +558,11 @@ static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
 static void launch_rhs_reduced_generic(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   const int np = (d.n + 15) / 16 * 16;
-  const size_t lds = sizeof(double) * (2 * (size_t)d.w + d.n + 3 * (size_t)np + 256 + (size_t)ndlqr::reduced_wfac_doubles(np));
+  const size_t lds = sizeof(double) * (2 * (size_t)d.w + d.n + 3 * (size_t)np + 256 + (size_t)d.n * (d.n + 1) / 2);
   for (int l = 0; l < d.K; ++l) {
     ScopedSlot t(c, SLOT_SEP);
     hipLaunchKernelGGL(ndlqr::rhs_reduced_generic, dim3(d.N >> (l + 1), d.batch), dim3(256), lds, c->stream, d, l, np,
-                       c->AB, c->QR, c->rhs, c->red, c->rec, c->wfac);
+                       c->AB, c->QR, c->rhs, c->red, c->rec);
   }
   launch_backsub_reduced_generic(c);
 }
@@ -997,7 +986,7 @@ static bool try_launch_rhs_records(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   if (!c->rec_complete || (c->flags & NDLQR_FLAG_STRICT_FP)) return false;
   if (!pick_small(c)) {  // runtime-sized separator-only schedule: records + slots + W of every separator
-    if (!plan_reduced_generic(c).ok || !c->wfac) return false;
+    if (!plan_reduced_generic(c).ok) return false;
     launch_rhs_reduced_generic(c);
     return true;
   }

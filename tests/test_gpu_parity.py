@@ -258,7 +258,7 @@ def test_non_spd_block_is_reported(ndlqr):
 
 
 @pytest.mark.parametrize("n,m,N", [(12, 4, 64), (12, 4, 256), (6, 3, 32), (13, 4, 16), (4, 1, 8), (10, 4, 128),
-                                   # runtime-sized separator-only schedule: records + slots + W of every separator
+                                   # runtime-sized separator-only schedule: the compact records (factors) + slots of every separator
                                    (16, 4, 16), (20, 20, 16), (64, 16, 32), (7, 9, 8), (16, 4, 2), (33, 5, 4), (48, 16, 64),
                                    (80, 16, 8), (90, 5, 4), (128, 8, 4), (100, 4, 4)])
 def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
