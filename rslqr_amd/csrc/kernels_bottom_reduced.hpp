@@ -361,14 +361,16 @@ __device__ __forceinline__ void push_mc(const int lane, const bool hasA, const b
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = lk + 4 * g;
-      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) put(li < NX ? sa.DR() + r * NX + li : sa.gR() + r, g00[g] + pa[g]);
+      // (the lower triangle of the symmetric block alone, packed; column NX: gR)
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX) && (li <= r || li == NX))
+        put(li < NX ? sa.DR() + r * (r + 1) / 2 + li : sa.gR() + r, g00[g] + pa[g]);
     }
   }
   if (hasB && li < NX) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = lk + 4 * g;
-      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX)) put(sb.DL() + r * NX + li, g11[g] + pb11[g]);
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX) && li <= r) put(sb.DL() + r * (r + 1) / 2 + li, g11[g] + pb11[g]);
     }
     if (lk == NX % 4) put(sb.gL() + li, g01[NX / 4] + pb01[NX / 4]);  // row NX of g01: y_z' Y_bb
     if (hasA) {
@@ -527,8 +529,9 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
     for (int it = 0; it < IR; ++it) { const int e = lane + 64 * it, ec = e < NR ? e : NR - 1; zs[ec] = tr[it]; }
   }
   wave_lds_sync();
-  const double *DL = slot, *DR = slot + NN, *CA = slot + 2 * NN, *CB = slot + 3 * NN;
-  const double *gL = slot + 4 * NN, *gR = slot + 4 * NN + NX;
+  constexpr int TRI = RedSlot<NX>::TRI;
+  const double *DL = slot, *DR = slot + TRI, *CA = slot + 2 * TRI, *CB = slot + 2 * TRI + NN;
+  const double *gL = slot + 2 * TRI + 2 * NN, *gR = slot + 2 * TRI + 2 * NN + NX;
 
   // [S-bar | b~] = leaf tile - DL - DR | - gL - gR
   double ra[KSN], rb[KSN];
@@ -541,7 +544,8 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
   }
   const acc4_t c0 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_, rq, rq + W, zs, zs + NX + W, [&](int g) {
     const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
-    const double dd = DL[ic * NX + ri] + DR[ic * NX + ri], gg = gL[ic] + gR[ic];
+    const int tix = RedSlot<NX>::tri(ic, ri);
+    const double dd = DL[tix] + DR[tix], gg = gL[ic] + gR[ic];
     return -(li == NX ? gg : dd);
   });
   wave_lds_sync();  // last read of the staged operands

@@ -327,7 +327,9 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
     rb_mul<NX, NX, true>(Rt, Xa, G);                       // r_a' S^-1 r_a
     const double gv = rb_mulv<NX>(Rt, xz);                 // r_a' S^-1 b~
     if (hasA && rowlane) {
-      store_row<NX>(sA.DR() + i * NX, G);
+#pragma unroll
+      for (int c = 0; c < NX; ++c)  // (row i of the symmetric block: its lower-triangle part, packed)
+        if (c <= i) sA.DR()[i * (i + 1) / 2 + c] = G[c];
       sA.gR()[i] = gv;
     }
     rb_mul<NX, NX, true, true>(Rt, Xb, RaTt);              // -(r_a' S^-1 r_bb)(i, c) = r_a(t)(c, i)
@@ -350,7 +352,9 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
     rb_mul<NX, NX, true>(Rt, Xb, G);                       // r_bb' S^-1 r_bb -> DL of separator k0 + 3
     const double gv = rb_mulv<NX>(Rt, xz);
     if (hasB && rowlane) {
-      store_row<NX>(sB.DL() + i * NX, G);
+#pragma unroll
+      for (int c = 0; c < NX; ++c)
+        if (c <= i) sB.DL()[i * (i + 1) / 2 + c] = G[c];
       sB.gL()[i] = gv;
     }
     rb_mul<NX, NX, true, true>(Rt, Xa, RbTt);              // -(r_bb' S^-1 r_a)(i, c) = r_bb(t)(c, i)
@@ -381,16 +385,16 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
       r[2 * NN + i] = xz;
     }
     const bool leftchild = (k0 & 4) == 0;
-    // DR / DL are symmetric (up to rounding): the atomic adds write element (i, c) into [c * NX + i], so
-    // that the twelve lanes of a row hit one 96-byte run instead of twelve different 64-byte
-    // segments (the memory-side atomic units take one request per segment: the row-major form
-    // made this kernel 3.6x slower than its instruction count)
+    // DR / DL are symmetric (up to rounding) and kept as packed lower triangles: lane i adds its entries (c, i), c >= i,
+    // into row c of the triangle, so that the lanes of a row hit one contiguous run (the memory-side atomic units take
+    // one request per 64-byte segment)
     double G[NX];
     rb_mul<NX, NX, true>(RaTt, Xa, G);
     double gv = rb_mulv<NX>(RaTt, xz);
     if (hasA && rowlane) {
 #pragma unroll
-      for (int c = 0; c < NX; ++c) atomicAdd(sA.DR() + c * NX + i, G[c]);
+      for (int c = 0; c < NX; ++c)
+        if (c >= i) atomicAdd(sA.DR() + c * (c + 1) / 2 + i, G[c]);
       atomicAdd(sA.gR() + i, gv);
     }
     rb_mul<NX, NX, true>(RaTt, Xb, G);  // coupling of the parent to its other neighbour: CA[B] = (r_a' S^-1 r_bb)' or CB[A] = r_a' S^-1 r_bb
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
     gv = rb_mulv<NX>(RbTt, xz);
     if (hasB && rowlane) {
 #pragma unroll
-      for (int c = 0; c < NX; ++c) atomicAdd(sB.DL() + c * NX + i, G[c]);
+      for (int c = 0; c < NX; ++c)
+        if (c >= i) atomicAdd(sB.DL() + c * (c + 1) / 2 + i, G[c]);
       atomicAdd(sB.gL() + i, gv);
     }
   }

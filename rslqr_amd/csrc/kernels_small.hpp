@@ -404,15 +404,19 @@ __device__ __forceinline__ double leaf_rhs_entry(const Dims& d, const int b, con
 template <int NX>
 struct RedSlot {
   // USED doubles of a slot; slots are padded to whole 128-byte lines (SIZE), so that a wavefront
-  // that reads its slot never pulls bytes of a neighbouring slot into its caches (tree schedule)
-  static constexpr int NN = NX * NX, USED = 4 * NN + 2 * NX, SIZE = (USED + 15) / 16 * 16;
+  // that reads its slot never pulls bytes of a neighbouring slot into its caches (tree schedule).
+  // DL and DR are symmetric: their lower triangles alone, packed by rows (entry (r, c), c <= r, at r (r + 1) / 2 + c) --
+  // the upper levels run at the rate the HBM delivers their slots and takes their pushes, and this is a fifth of it.
+  static constexpr int NN = NX * NX, TRI = NX * (NX + 1) / 2, USED = 2 * TRI + 2 * NN + 2 * NX, SIZE = (USED + 15) / 16 * 16;
   double* p;
   __device__ __forceinline__ double* DL() const { return p; }
-  __device__ __forceinline__ double* DR() const { return p + NN; }
-  __device__ __forceinline__ double* CA() const { return p + 2 * NN; }
-  __device__ __forceinline__ double* CB() const { return p + 3 * NN; }
-  __device__ __forceinline__ double* gL() const { return p + 4 * NN; }
-  __device__ __forceinline__ double* gR() const { return p + 4 * NN + NX; }
+  __device__ __forceinline__ double* DR() const { return p + TRI; }
+  __device__ __forceinline__ double* CA() const { return p + 2 * TRI; }
+  __device__ __forceinline__ double* CB() const { return p + 2 * TRI + NN; }
+  __device__ __forceinline__ double* gL() const { return p + 2 * TRI + 2 * NN; }
+  __device__ __forceinline__ double* gR() const { return p + 2 * TRI + 2 * NN + NX; }
+  // entry (r, c) of a packed symmetric block
+  __host__ __device__ static constexpr int tri(const int r, const int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 };
 template <int NX>
 __device__ __forceinline__ RedSlot<NX> red_slot(double* red, const Dims& d, const int b, const int t) {

@@ -121,8 +121,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
             hipHostMalloc((void**)&c->h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (ok) *c->h_fail = 0;
   if (ok && nhorizon >= 8 && has_small_instance(d.n, d.m)) {
-    // slot = DL | DR | CA | CB | gL | gR, padded to whole 128-byte lines (RedSlot<NX>::SIZE)
-    const size_t slot_doubles = (4 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
+    // slot = DL | DR (packed lower triangles) | CA | CB | gL | gR, padded to whole 128-byte lines (RedSlot<NX>::SIZE)
+    const size_t slot_doubles = ((size_t)d.n * (d.n + 1) + 2 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
     const size_t red_bytes = sizeof(double) * (size_t)batch * (nhorizon / 4) * slot_doubles;
     ok = hipMalloc(&c->red, red_bytes) == hipSuccess && hipMemsetAsync(c->red, 0, red_bytes, c->stream) == hipSuccess;
     if (ok) c->red_bytes = red_bytes;
@@ -206,7 +206,7 @@ static bool ensure_alt(NdlqrHipCtx* c) {
   NdlqrAltSlot& a = c->alt;
   if (a.ready) return true;
   const ndlqr::Dims& d = c->d;
-  const size_t slot_doubles = (4 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
+  const size_t slot_doubles = ((size_t)d.n * (d.n + 1) + 2 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;  // RedSlot<NX>::SIZE
   const size_t red_bytes = sizeof(double) * (size_t)d.batch * (d.N / 4) * slot_doubles;
   const size_t cnt_bytes = sizeof(int) * (size_t)d.batch * (d.N / 4);
   // The second set's stream gets another priority than the first's: streams of one priority share a few hardware
@@ -1366,7 +1366,7 @@ extern "C" long ndlqr_hip_debug_download(NdlqrHipCtx* c, int which, double* host
   if (!c || !host) return -1;
   const ndlqr::Dims& d = c->d;
   const double* src = which == 0 ? c->rec : c->red;
-  const size_t slot_doubles = (4 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;
+  const size_t slot_doubles = ((size_t)d.n * (d.n + 1) + 2 * (size_t)d.n * d.n + 2 * d.n + 15) / 16 * 16;  // RedSlot<NX>::SIZE
   const size_t have = which == 0 ? (size_t)d.batch * d.N * (2 * d.n * d.n + d.n) : (size_t)d.batch * (d.N / 4) * slot_doubles;
   if (!src) return -1;
   const size_t n = (size_t)count < have ? (size_t)count : have;
