@@ -57,8 +57,9 @@ def reduced_model(n, m, N, compact_level0=False):
     {slot: {"bytes": per solve, "flops": per solve, "launches": per solve}}."""
     K = int(math.log2(N))
     w, rows = n + m, 2 * n + m
-    push = 3 * n * n + 2 * n      # what one four-knot group / one upper separator pushes to its neighbours
-    slot = 4 * n * n + 2 * n      # DL | DR | CA | CB | gL | gR of one separator of level >= 2
+    tri = n * (n + 1) // 2        # DL, DR are symmetric: packed lower triangles (round 3)
+    push = 2 * tri + n * n + 2 * n      # what one four-knot group / one upper separator pushes to its neighbours
+    slot = 2 * tri + 2 * n * n + 2 * n  # DL | DR | CA | CB | gL | gR of one separator of level >= 2
     rec0 = record_doubles(n, 0, compact_level0)
     rec = record_doubles(n, 1)
     fs = separator_flops(n, w)
