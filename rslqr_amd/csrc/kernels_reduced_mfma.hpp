@@ -692,7 +692,7 @@ __global__ __launch_bounds__(NTHR, reduced_min_waves(NB, NTHR)) void separator_r
         }
       }
     }
-    // vector pushes gR[A] += r_a' z_sep (first wavefront) / gL[B] += r_bb' z_sep (last): a column of r per lane
+    // vector pushes gR[A] += Y_a' y~ (first wavefront) / gL[B] += Y_b' y~ (last): a column of Y per lane
     if (with_ra ? (wave == 0 && hasA) : (wave == NW - 1 && hasB)) {
       double* dst = with_ra ? slotA + 4 * nnl + nl : slotB + 4 * nnl;
       for (int j0 = 0; j0 < nl; j0 += 64) {
@@ -933,8 +933,8 @@ static __global__ __launch_bounds__(256) void backsub_multipliers_compact(Dims d
 // ------------------------------------------------------------------------------------- back-substitution, level 0
 // The last step of the back-substitution of the separator-only schedule above, one workgroup per level-0
 // separator s = 2 j, i.e. per pair of knots (s, s + 1): its multiplier from the compact record
-//     y_s = z_sep - W'W (r_a y_{s-1} + r_bb y_{s+1}),   r_a = -A_s Q_s^-1,  r_bb = -Q_{s+1}^-1 A_{s+1}'
-// (the multipliers next to it are final: levels >= 1 ran before, backsub_multipliers_generic), then the states
+//     y_s = L^-T (y~ - L^-1 (r_a y_{s-1} + r_bb y_{s+1})),   r_a = -A_s Q_s^-1,  r_bb = -Q_{s+1}^-1 A_{s+1}'
+// (the multipliers next to it are final: levels >= 1 ran before, backsub_multipliers_compact), then the states
 // and inputs of both knots (the arithmetic of backsub_states_generic) -- [A | B] of the two knots comes from HBM
 // once for both, and level 0's f_a | f_bb never exist in memory.
 //   grid (N / 2, batch), block 64 / 128 / 256 (by block size), dynamic LDS = n (n + 1) / 2 + 5 n + 4 (n + m) +
@@ -948,12 +948,12 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
   const int n = d.n, w = d.w, N = d.N, rows = d.rows, nn = n * n;
   const int b = blockIdx.y, s = 2 * blockIdx.x;
   const bool hasA = s > 0, hasB = s + 2 < N;
-  double* Wp = sm;                      // W, packed lower triangle
+  double* Wp = sm;                      // L (the inverses of its diagonal blocks in their place), packed lower triangle
   double* yA = Wp + n * (n + 1) / 2;    // y_{s-1}, then y_{s-1} / Q_s
   double* yB = yA + n;                  // y_{s+1}
   double* ys = yB + n;                  // y_s
-  double* tv = ys + n;                  // r_a y_A + r_bb y_B, then W t
-  double* zs = tv + n;                  // z_sep
+  double* tv = ys + n;                  // r_a y_A + r_bb y_B, then the substitutions
+  double* zs = tv + n;                  // y~ of the record
   double* d0 = zs + n;                  // [A_s | B_s]' y_s
   double* d1 = d0 + w;                  // [A_{s+1} | B_{s+1}]' y_{s+1}
   double* qv = d1 + w;                  // [Q | R] of knots s, s + 1
