@@ -23,7 +23,7 @@ Matrix NewMatrix(int rows, int cols) {
   Matrix mat;
   mat.rows = rows;
   mat.cols = cols;
-  mat.data = (double*)malloc(sizeof(double) * (size_t)rows * (size_t)cols);
+  mat.data = (rows > 0 && cols > 0) ? (double*)malloc(sizeof(double) * (size_t)rows * (size_t)cols) : NULL;
   return mat;
 }
 
@@ -31,8 +31,8 @@ int MatrixNumElements(const Matrix* mat) { return mat ? mat->rows * mat->cols : 
 
 int MatrixSetConst(Matrix* mat, double val) {
   if (!mat) return -1;
-  const int count = mat->rows * mat->cols;
-  for (int e = 0; e < count; ++e) mat->data[e] = val;
+  const size_t count = (size_t)mat->rows * (size_t)mat->cols;
+  for (size_t e = 0; e < count; ++e) mat->data[e] = val;
   return 0;
 }
 
@@ -73,7 +73,7 @@ int MatrixCopy(Matrix* dest, Matrix* src) {
     fprintf(stderr, "Can't copy matrices of different sizes.\n");
     return -1;
   }
-  memcpy(dest->data, src->data, sizeof(double) * (size_t)(dest->rows * dest->cols));
+  memcpy(dest->data, src->data, sizeof(double) * (size_t)dest->rows * (size_t)dest->cols);
   return 0;
 }
 
@@ -85,14 +85,15 @@ int MatrixCopyTranspose(Matrix* dest, Matrix* src) {
     return -1;
   }
   for (int c = 0; c < dest->cols; ++c)
-    for (int r = 0; r < dest->rows; ++r) dest->data[r + dest->rows * c] = src->data[c + src->rows * r];
+    for (int r = 0; r < dest->rows; ++r)
+      dest->data[r + (size_t)dest->rows * c] = src->data[c + (size_t)src->rows * r];
   return 0;
 }
 
 int MatrixScaleByConst(Matrix* mat, double alpha) {
   if (!mat) return -1;
-  const int count = mat->rows * mat->cols;
-  for (int e = 0; e < count; ++e) mat->data[e] *= alpha;
+  const size_t count = (size_t)mat->rows * (size_t)mat->cols;
+  for (size_t e = 0; e < count; ++e) mat->data[e] *= alpha;
   return 0;
 }
 
@@ -104,8 +105,8 @@ double MatrixNormedDifference(Matrix* A, Matrix* B) {
     return INFINITY;
   }
   double sumsq = 0.0;
-  const int count = A->rows * A->cols;
-  for (int e = 0; e < count; ++e) {
+  const size_t count = (size_t)A->rows * (size_t)A->cols;
+  for (size_t e = 0; e < count; ++e) {
     const double delta = A->data[e] - B->data[e];
     sumsq += delta * delta;
   }
@@ -162,6 +163,11 @@ int ReadFile(const char* filename, char** out, int* len) {
   if (fseek(fp, 0L, SEEK_END) != 0) { fclose(fp); return -1; }
   const long size = ftell(fp);
   rewind(fp);
+  if (size < 0 || size >= 0x7fffffffL) { /* (the length goes back as an int, like utils.c:17-49) */
+    fclose(fp);
+    fprintf(stderr, "File too large (or unseekable).\n");
+    return -1;
+  }
   char* buf = (char*)malloc((size_t)size + 1);
   if (!buf) {
     fclose(fp);
@@ -183,11 +189,23 @@ int ReadFile(const char* filename, char** out, int* len) {
 
 /* ======================================================================= LQRData */
 
-static int lqrdata_doubles(int n, int m) { return 2 * n + 2 * m + 1 + n * n + n * m + n; }
+/* doubles in the slab of one knot; size_t arithmetic: n * n overflows int beyond 46 340 states */
+static size_t lqrdata_doubles(int n, int m) {
+  const size_t sn = (size_t)n, sm = (size_t)m;
+  return 2 * sn + 2 * sm + 1 + sn * sn + sn * sm + sn;
+}
+
+/* block sizes a knot can be allocated for: positive, and small enough that the slab size is far from wrapping */
+#define NDLQR_MAX_BLOCK 32768
 
 LQRData* ndlqr_NewLQRData(int nstates, int ninputs) {
   const int n = nstates, m = ninputs;
-  double* slab = (double*)malloc(sizeof(double) * (size_t)lqrdata_doubles(n, m));
+  if (n <= 0 || m <= 0 || n > NDLQR_MAX_BLOCK || m > NDLQR_MAX_BLOCK) {
+    fprintf(stderr, "ERROR: LQRData dimensions out of range: (%d,%d).\n", n, m);
+    return NULL;
+  }
+  /* zeroed: a knot the caller (or a JSON file) never fills holds zeros, not heap contents */
+  double* slab = (double*)calloc(lqrdata_doubles(n, m), sizeof(double));
   LQRData* l = (LQRData*)malloc(sizeof(LQRData));
   if (!slab || !l) { free(slab); free(l); return NULL; }
   l->nstates = n;
@@ -199,8 +217,8 @@ LQRData* ndlqr_NewLQRData(int nstates, int ninputs) {
   l->q = cur; cur += n;
   l->r = cur; cur += m;
   l->c = cur; cur += 1;
-  l->A = cur; cur += n * n;
-  l->B = cur; cur += n * m;
+  l->A = cur; cur += (size_t)n * (size_t)n;
+  l->B = cur; cur += (size_t)n * (size_t)m;
   l->d = cur;
   return l;
 }
@@ -228,12 +246,13 @@ int ndlqr_InitializeLQRData(LQRData* lqrdata, double* Q, double* R, double* q, d
 }
 
 int ndlqr_CopyLQRData(LQRData* dest, LQRData* src) {
+  if (!dest || !src) return -1;
   if (dest->nstates != src->nstates || dest->ninputs != src->ninputs) {
     fprintf(stderr, "Can't copy LQRData of different sizes: (%d,%d) and (%d,%d).\n",
             dest->nstates, dest->ninputs, src->nstates, src->ninputs);
     return -1;
   }
-  memcpy(dest->Q, src->Q, sizeof(double) * (size_t)lqrdata_doubles(dest->nstates, dest->ninputs));
+  memcpy(dest->Q, src->Q, sizeof(double) * lqrdata_doubles(dest->nstates, dest->ninputs));
   return 0;
 }
 
@@ -277,24 +296,36 @@ LQRProblem* ndlqr_NewLQRProblem(int nstates, int ninputs, int nhorizon) {
     fprintf(stderr, "ERROR: Horizon must be positive.\n");
     return NULL;
   }
+  if (nstates <= 0 || ninputs <= 0 || nstates > NDLQR_MAX_BLOCK || ninputs > NDLQR_MAX_BLOCK) {
+    fprintf(stderr, "ERROR: LQRProblem dimensions out of range: (%d,%d).\n", nstates, ninputs);
+    return NULL;
+  }
   LQRProblem* p = (LQRProblem*)malloc(sizeof(LQRProblem));
-  LQRData** knots = (LQRData**)malloc(sizeof(LQRData*) * (size_t)nhorizon);
-  double* x0 = (double*)malloc(sizeof(double) * (size_t)nstates);
+  LQRData** knots = (LQRData**)calloc((size_t)nhorizon, sizeof(LQRData*));
+  double* x0 = (double*)calloc((size_t)nstates, sizeof(double));
   if (!p || !knots || !x0) {
     fprintf(stderr, "ERROR: Couldn't allocate memory for LQRProblem.\n");
     free(p); free(knots); free(x0);
     return NULL;
   }
-  for (int k = 0; k < nhorizon; ++k) knots[k] = ndlqr_NewLQRData(nstates, ninputs);
   p->nhorizon = nhorizon;
   p->x0 = x0;
   p->lqrdata = knots;
+  for (int k = 0; k < nhorizon; ++k) {
+    knots[k] = ndlqr_NewLQRData(nstates, ninputs);
+    if (!knots[k]) { /* (the knots allocated so far go with the problem; the rest are NULL: Free skips them) */
+      fprintf(stderr, "ERROR: Couldn't allocate memory for knot %d of the LQRProblem.\n", k);
+      ndlqr_FreeLQRProblem(p);
+      return NULL;
+    }
+  }
   return p;
 }
 
 int ndlqr_InitializeLQRProblem(LQRProblem* lqrproblem, double* x0, LQRData** lqrdata) {
-  if (!lqrproblem) return -1;
-  for (int k = 0; k < lqrproblem->nhorizon; ++k) ndlqr_CopyLQRData(lqrproblem->lqrdata[k], lqrdata[k]);
+  if (!lqrproblem || !x0 || !lqrdata) return -1;
+  for (int k = 0; k < lqrproblem->nhorizon; ++k)
+    if (ndlqr_CopyLQRData(lqrproblem->lqrdata[k], lqrdata[k]) != 0) return -1;
   memcpy(lqrproblem->x0, x0, sizeof(double) * (size_t)lqrproblem->lqrdata[0]->nstates);
   return 0;
 }
@@ -443,6 +474,7 @@ int ndlqr_FreeNdData(NdData* nddata) {
 }
 
 int ndlqr_GetNdFactor(NdData* nddata, int index, int level, NdFactor** factor) {
+  if (!nddata || !factor) return -1;
   if (index < 0 || index > nddata->nsegments) {
     fprintf(stderr, "Invalid index. Must be between %d and %d, got %d.\n", 0, nddata->nsegments,
             index);
@@ -453,7 +485,7 @@ int ndlqr_GetNdFactor(NdData* nddata, int index, int level, NdFactor** factor) {
             level);
     return -1;
   }
-  *factor = nddata->factors + (index + (nddata->nsegments + 1) * level);
+  *factor = nddata->factors + ((size_t)index + (size_t)(nddata->nsegments + 1) * (size_t)level);
   return 0;
 }
 

@@ -54,6 +54,7 @@ static char* parse_string_raw(JParser* ps) {
   ++ps->p;
   size_t cap = 16, len = 0;
   char* out = (char*)malloc(cap);
+  if (!out) { ps->ok = 0; return NULL; }
   while (ps->p < ps->end && *ps->p != '"') {
     char ch = *ps->p++;
     if (ch == '\\' && ps->p < ps->end) {
@@ -71,7 +72,12 @@ static char* parse_string_raw(JParser* ps) {
         default: ch = esc; break;
       }
     }
-    if (len + 2 > cap) { cap *= 2; out = (char*)realloc(out, cap); }
+    if (len + 2 > cap) {
+      char* grown = (char*)realloc(out, cap * 2);
+      if (!grown) { free(out); ps->ok = 0; return NULL; }
+      out = grown;
+      cap *= 2;
+    }
     out[len++] = ch;
   }
   if (ps->p >= ps->end) { ps->ok = 0; free(out); return NULL; }
@@ -84,6 +90,7 @@ static JNode* parse_value(JParser* ps, int depth);
 
 static JNode* parse_container(JParser* ps, int depth, int is_obj) {
   JNode* nd = (JNode*)calloc(1, sizeof(JNode));
+  if (!nd) { ps->ok = 0; return NULL; }
   nd->type = is_obj ? J_OBJ : J_ARR;
   const char close = is_obj ? '}' : ']';
   ++ps->p; /* opening bracket */
@@ -122,6 +129,7 @@ static JNode* parse_value(JParser* ps, int depth) {
   if (ch == '{') return parse_container(ps, depth, 1);
   if (ch == '[') return parse_container(ps, depth, 0);
   JNode* nd = (JNode*)calloc(1, sizeof(JNode));
+  if (!nd) { ps->ok = 0; return NULL; }
   if (ch == '"') {
     nd->type = J_STR;
     nd->str = parse_string_raw(ps);
@@ -165,7 +173,9 @@ static const JNode* member(const JNode* obj, const char* name) {
 
 static int member_int(const JNode* obj, const char* name, int fallback) {
   const JNode* it = member(obj, name);
-  return (it && it->type == J_NUM) ? (int)it->num : fallback;
+  /* (a number outside the int range -- or NaN -- is not a dimension / index: the conversion would be undefined) */
+  if (!it || it->type != J_NUM || !(it->num > -2147483648.0 && it->num < 2147483648.0)) return fallback;
+  return (int)it->num;
 }
 
 /* 1-D array of exactly `len` numbers */
@@ -181,8 +191,13 @@ static int read_vector(const JNode* obj, const char* name, double* out, int len)
     return -1;
   }
   int i = 0;
-  for (const JNode* it = arr->child; it; it = it->next, ++i)
-    if (it->type == J_NUM) out[i] = it->num;
+  for (const JNode* it = arr->child; it && i < len; it = it->next, ++i) {
+    if (it->type != J_NUM) {
+      fprintf(stderr, "JSON array %s holds something that is not a number at position %d.\n", name, i);
+      return -1;
+    }
+    out[i] = it->num;
+  }
   return 0;
 }
 
@@ -202,8 +217,10 @@ static int read_columns(const JNode* obj, const char* name, double* out, int row
       status = -1;
     }
     int i = 0;
-    for (const JNode* it = col->child; it && i < rows; it = it->next, ++i)
+    for (const JNode* it = col->child; it && i < rows; it = it->next, ++i) {
       if (it->type == J_NUM) out[i + (size_t)rows * j] = it->num;
+      else status = -1;
+    }
     ++j;
   }
   if (j != cols) {
@@ -262,6 +279,11 @@ LQRData* ndlqr_ReadLQRDataJSONFile(const char* filename) {
   return knot;
 }
 
+/* Bounds on what a problem file may ask for (the reference trusts the file, src/json_utils.c:186-259): block sizes
+ * the containers accept, and a horizon no longer than the number of knot objects the file actually holds -- every
+ * knot 0 .. N-1 has to be there exactly once, so a file cannot make the reader allocate more than it carries. */
+#define NDLQR_JSON_MAX_BLOCK 32768
+
 LQRProblem* ndlqr_ReadLQRProblemJSONFile(const char* filename) {
   JNode* root = parse_file(filename);
   if (!root) {
@@ -270,21 +292,55 @@ LQRProblem* ndlqr_ReadLQRProblemJSONFile(const char* filename) {
   }
   const int N = member_int(root, "nhorizon", 0);
   const JNode* knots = member(root, "lqrdata");
-  if (N <= 0 || !knots || knots->type != J_ARR || !knots->child) { jfree(root); return NULL; }
+  if (N <= 0 || !knots || knots->type != J_ARR || !knots->child) {
+    fprintf(stderr, "ERROR: LQR Problem file without a positive nhorizon / an lqrdata array: %s\n", filename);
+    jfree(root);
+    return NULL;
+  }
+  if (knots->count < N) {
+    fprintf(stderr, "ERROR: nhorizon is %d but the file holds %d knots: %s\n", N, knots->count, filename);
+    jfree(root);
+    return NULL;
+  }
   const int n = member_int(knots->child, "nstates", 0), m = member_int(knots->child, "ninputs", 0);
-  if (n <= 0 || m <= 0) { jfree(root); return NULL; }
+  if (n <= 0 || m <= 0 || n > NDLQR_JSON_MAX_BLOCK || m > NDLQR_JSON_MAX_BLOCK) {
+    fprintf(stderr, "ERROR: state / input dimensions out of range (%d,%d): %s\n", n, m, filename);
+    jfree(root);
+    return NULL;
+  }
+  /* the first knot's arrays must really have those sizes before N knots of that size are allocated */
+  {
+    const JNode* A0 = member(knots->child, "A");
+    const JNode* Q0 = member(knots->child, "Q");
+    if (!A0 || A0->type != J_ARR || A0->count != n || !Q0 || Q0->type != J_ARR || Q0->count != n) {
+      fprintf(stderr, "ERROR: nstates is %d but the first knot's A / Q do not have that size: %s\n", n, filename);
+      jfree(root);
+      return NULL;
+    }
+  }
   LQRProblem* prob = ndlqr_NewLQRProblem(n, m, N);
   if (!prob) { jfree(root); return NULL; }
-  for (const JNode* kn = knots->child; kn; kn = kn->next) {
+  char* seen = (char*)calloc((size_t)N, 1);
+  int status = seen ? 0 : -1;
+  for (const JNode* kn = knots->child; kn && status == 0; kn = kn->next) {
     const int index = member_int(kn, "index", 0) - 1; /* 1-based in the file */
     if (index < 0 || index >= N) {
       fprintf(stderr, "WARNING: LQR JSON data with out-of-range index %d skipped\n", index + 1);
       continue;
     }
-    if (read_knot(kn, prob->lqrdata[index]) != 0)
-      fprintf(stderr, "WARNING: Failed to parse the LQR JSON data at index %d\n", index);
+    if (read_knot(kn, prob->lqrdata[index]) != 0) {
+      fprintf(stderr, "ERROR: Failed to parse the LQR JSON data at index %d\n", index);
+      status = -1;
+    }
+    seen[index] = 1;
   }
-  const int status = read_vector(root, "x0", prob->x0, n);
+  for (int k = 0; k < N && status == 0; ++k)
+    if (!seen[k]) {
+      fprintf(stderr, "ERROR: no LQR JSON data for knot %d (index %d) in %s\n", k, k + 1, filename);
+      status = -1;
+    }
+  free(seen);
+  if (status == 0) status = read_vector(root, "x0", prob->x0, n);
   jfree(root);
   if (status != 0) {
     ndlqr_FreeLQRProblem(prob);

@@ -258,3 +258,46 @@ class RefSolver:
 
     def soln(self):
         return np.ctypeslib.as_array(self.L.ref_soln(self.h), (self._ns,))
+
+
+def kkt_residual_ld(prob, z):
+    """b - K z of the reference's KKT system (src/solver.c:122-194) in extended precision (numpy longdouble: the
+    80-bit x87 format on the hosts used here), for a solution z in the reference's [lambda x u] order. Returns
+    (r_lam [N, n], r_x [N, n], r_u [N, m]) -- the residual rows of each knot. Test infrastructure."""
+    ld = np.longdouble
+    n, m, N = prob.n, prob.m, prob.N
+    zb = 2 * n + m
+    full = np.zeros(N * zb, dtype=ld)
+    full[: z.size] = z
+    Z = full.reshape(N, zb)
+    lam, x, u = Z[:, :n], Z[:, n:2 * n], Z[:, 2 * n:]
+    A = prob.A.astype(ld).reshape(N, n, n).transpose(0, 2, 1)  # column-major storage -> A[k][i, j]
+    B = prob.B.astype(ld).reshape(N, m, n).transpose(0, 2, 1)
+    Q, R = prob.Q.astype(ld), prob.R.astype(ld)
+    q, r, d, x0 = prob.q.astype(ld), prob.r.astype(ld), prob.d.astype(ld), prob.x0.astype(ld)
+    r_lam = np.zeros((N, n), dtype=ld)
+    r_x = np.zeros((N, n), dtype=ld)
+    r_u = np.zeros((N, m), dtype=ld)
+    r_lam[0] = -x0 - (-x[0])
+    for k in range(N):
+        nxt = A[k].T @ lam[k + 1] if k < N - 1 else 0
+        r_x[k] = -q[k] - (Q[k] * x[k] - lam[k] + nxt)
+        if k < N - 1:
+            r_u[k] = -r[k] - (R[k] * u[k] + B[k].T @ lam[k + 1])
+            r_lam[k + 1] = -d[k] - (A[k] @ x[k] + B[k] @ u[k] - x[k + 1])
+    return r_lam, r_x, r_u
+
+
+def refined_solution(oracle, prob, iters=3):
+    """The oracle's solution taken through `iters` steps of iterative refinement with the residual evaluated in
+    extended precision: accurate to about double rounding even where the system is ill-conditioned. The yardstick
+    for what "as accurate as the reference" means on hard inputs (the oracle's own error against it is the bar)."""
+    z = oracle.solve(prob, 8)[0][: prob.nvars].astype(np.longdouble)
+    for _ in range(iters):
+        r_lam, r_x, r_u = kkt_residual_ld(prob, z)
+        # K dz = res  <=>  a problem with the same A, B, Q, R and right-hand side (x0, q, r, d) = -(res rows)
+        corr = Problem(prob.n, prob.m, prob.N, prob.A, prob.B, prob.Q, prob.R, (-r_x).astype(np.float64),
+                       (-r_u).astype(np.float64), (-r_lam[1:]).astype(np.float64).tolist() + [[0.0] * prob.n],
+                       (-r_lam[0]).astype(np.float64))
+        z = z + oracle.solve(corr, 8)[0][: prob.nvars]
+    return z.astype(np.float64)

@@ -322,6 +322,59 @@ def test_harder_problem_families(ndlqr, oracle, n, m, N, a_scale, q_scale):
         bs.close()
 
 
+def hard_problem(ndlqr, n, m, N, seed, a_scale, q_scale, r_scale):
+    g = ndlqr.generate_synthetic(n, m, N, seed)
+    g["A"] = g["A"] * a_scale
+    g["Q"] = g["Q"] * q_scale
+    g["R"] = g["R"] * r_scale
+    return g, Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+
+
+HARD_FAMILIES = [(1.15, 1.0, 1.0), (1.0, 1e-4, 1.0), (1.3, 1e-3, 1.0), (1.0, 1.0, 1e-4)]
+# (n, m, N, batch, schedule the fast mode must take): the large-block separator-only schedule at one to eight tile
+# columns (explicit inverses of the 16 x 16 diagonal blocks, Gram-form pushes), one PAD instance, the zero-padded
+# buckets, and the level-per-launch `reduced` schedule at a batch that selects it
+HARD_SHAPES = [(64, 16, 64, 1, "generic-reduced"), (32, 8, 128, 1, "generic-reduced"), (96, 16, 16, 1, "generic-reduced"),
+               (128, 16, 8, 1, "generic-reduced"), (50, 10, 64, 1, "generic-reduced"), (7, 9, 64, 1, None),
+               (11, 3, 64, 1, None), (12, 4, 256, 40, "reduced"), (8, 4, 256, 40, "reduced")]
+
+
+@pytest.mark.parametrize("n,m,N,batch,want", HARD_SHAPES)
+@pytest.mark.parametrize("a_scale,q_scale,r_scale", HARD_FAMILIES)
+def test_harder_families_large_and_padded_paths(ndlqr, oracle, n, m, N, batch, want, a_scale, q_scale, r_scale):
+    """The ill-conditioned families of test_harder_problem_families (plus weak input costs) on the paths that only
+    ever saw the benign benchmark family: fast mode <= 1e-9 relative against the oracle (the reference's algorithm in
+    the reference's operation order) and a KKT residual within 10x the oracle's own; strict mode, where the shape has
+    it at this size, bit-exact. Bar of the reference's own test: test/nested_dissection_test.c:277."""
+    gs, probs = zip(*[hard_problem(ndlqr, n, m, N, 11 + p, a_scale, q_scale, r_scale) for p in range(batch)])
+    sample = sorted(set([0, batch // 2, batch - 1]))
+    refs = {p: oracle.solve(probs[p], 8)[0][: probs[p].nvars] for p in sample}
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0
+    if want:
+        assert bs.schedule() == want, bs.schedule()
+    sol = bs.solutions()
+    kres, kbn = bs.kkt_residuals()
+    worst_o = 0.0
+    for p in sample:
+        ores, obn = oracle.kkt_residual(probs[p], refs[p])
+        worst_o = max(worst_o, ores / max(1.0, obn))
+        rel = np.linalg.norm(sol[p] - refs[p]) / np.linalg.norm(refs[p])
+        assert rel <= REL_TOL, (p, rel)
+        res, bn = oracle.kkt_residual(probs[p], sol[p])
+        assert res / max(1.0, bn) <= 10.0 * ores / max(1.0, obn) + 1e-12, (p, res, bn, ores, obn)
+    # every member, on the device, against its raw data
+    assert float((kres / np.maximum(1.0, kbn)).max()) <= 10.0 * worst_o + 1e-11
+    bs.close()
+    if n <= 64:  # strict mode: where the knot-based kernels reach (include/ndlqr.h, NDLQR_FLAG_STRICT_FP)
+        bs = ndlqr.BatchSolver(n, m, N, 1, flags=ndlqr.FLAG_STRICT_FP)
+        bs.initialize_flat(*[gs[0][k][None] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+        assert bs.solve() == 0
+        assert np.array_equal(bs.solutions()[0], refs[0])
+        bs.close()
+
+
 def _solve_in_subprocess(n, m, N, batch, seed, env):
     """Solutions of a fresh process with `env` added to the environment (the tuning variables are
     read once, at context creation)."""
