@@ -30,117 +30,171 @@ namespace ndlqr {
 typedef double acc4_t __attribute__((ext_vector_type(4)));
 
 // ===================================================================================== matrix-core core
-// The separator core of bottom_reduced_mc / reduced_level_mc: only the
-// Cholesky of S-bar and the inverse W = L^-1 of its factor run on the vector ALU (row / column per
-// lane, v_readlane broadcasts; step j broadcasts row j of L once and uses it for both); the rest is
-// a chain of 16x16x4 matrix-core products through the accumulator registers
-//     S-bar^-1 = W'W        X = S-bar^-1 [r_a | b~ | r_bb]        Schur blocks R'X
-// Component q of lane (li, lk) of a v_mfma_f64_16x16x4_f64 result is element (4 q + lk, li) --
-// exactly the element that lane supplies in k-step q when the tile is the B operand of the next
-// product, and (S-bar^-1 being symmetric) also when it is the A operand; the panel fragments R
-// serve as B operand of S-bar^-1 R and as A operand of R'X unchanged. No panel in LDS, no
-// re-filing; LDS only transposes S-bar (accumulator layout -> one row per lane) and W (one column
-// per lane -> operand layout). Per separator 156 v_readlane + 132 FMAs instead of 420 + 235, and
-// 18 MFMAs (3 + 6 + 9).
-// Everything is written branch-free: loads are unconditional with clamped indices, the tiles are
-// padded to 16 x 16 in LDS (pad rows / columns of W are zero, so padding never reaches a result),
-// conditions only select values.
+// The separator core of bottom_reduced_mc / reduced_level_mc. Only the Cholesky of S-bar and the forward substitutions
+// that ride on it run on the vector ALU (rb_chol_inv, kernels_dpp.hpp: one row of S-bar per lane of every 16-lane DPP
+// row, one right-hand-side column per lane); the rest is a chain of 16x16x4 matrix-core products through the
+// accumulator registers. Component q of lane (li, lk) of a v_mfma_f64_16x16x4_f64 result is element (4 q + lk, li) --
+// exactly the element that lane supplies in k-step q when the tile is the B operand of the next product and, read
+// as the transposed tile, its A operand.
+//
+// Numerics (round 4). S-bar^-1 is never formed: with S-bar = L L', W = L^-1 and the solved panel
+// Y = L^-1 [r_a | b~ | r_bb], the record is X = W'Y and everything pushed to other separators is a Gram product of Y.
+// Round 3 formed S-bar^-1 = W'W and X = S-bar^-1 R; on problems with weak input costs (R ~ 1e-6: S-bar carries
+// B R^-1 B' ~ 1e4 beside O(1) blocks) the rounding of the explicit inverse is not confined to the directions in which
+// S-bar^-1 is small, and u = R^-1 (-r - B'y) amplified it to 5e-8 relative where the reference's substitutions
+// give 5e-12 (tools/reduced_model.py reproduces both; tests: test_harder_families_large_and_padded_paths).
+// Everything is written branch-free: loads are unconditional with clamped indices, the tiles are padded to 16 x 16
+// in LDS (pad rows / columns of W are zero, so padding never reaches a result), conditions only select values.
 template <int NX>
-struct alignas(16) McScratch {
-  static constexpr int SP = 18, WP = 17;
-  double scr[16 * SP];  // S-bar tile, row i at scr + i * SP
-  double W[16 * WP];    // W = L^-1, zero outside the leading NX x NX block
-  // rows NX..15 of W are zeroed once; the core only rewrites rows < NX
-  __device__ __forceinline__ void init(const int lane) {
-#pragma unroll
-    for (int e0 = 0; e0 < (16 - NX) * WP; e0 += 64) {
-      const int e = e0 + lane;
-      if (e < (16 - NX) * WP) W[NX * WP + e] = 0.0;
-    }
-  }
+struct McPitch {
+  static constexpr int SP = 18, WP = 17;  // row pitch of the S-bar tile / of W in LDS
 };
 
-// c: [S-bar | b~] tile (column NX = rhs). ra / rb: B-operand fragments of r_a / r_bb, i.e.
-// ra[q] = r_a(4 q + lk, li) (any finite value outside the block). On return X0 = [f_a | z_sep],
-// X1 = [f_bb] in accumulator layout. hook(R0, R1, X0, X1) sees the panel fragments and the solution.
-// Second half of the core: everything behind the Cholesky. Wm: W = L^-1 in LDS (row pitch McScratch::WP, zero outside
-// the leading NX x NX block). c: the separator's [S-bar | b~] tile (only its rhs column NX is read here).
+// Tail of a separator whose W = L^-1 lies in LDS (Wm: row pitch McPitch::WP, zero outside the leading NX x NX block)
+// and whose panel is still raw: c = the separator's [S-bar | b~] tile (only its rhs column NX is read here), ra / rb =
+// B-operand fragments of r_a / r_bb, i.e. ra[q] = r_a(4 q + lk, li) (any finite value outside the block).
+//   Y = W [r_a | b~ | r_bb]     X = W'Y
+// On return X0 = [f_a | z_sep], X1 = [f_bb] in accumulator layout. hook(Y0, Y1, Y0, Y1) sees the solved panel in both
+// operand roles (the fragment arrays and the accumulator tiles hold the same numbers): Gram products Y'Y.
+// (The level-0 separators of the schedules that keep full records: tree schedule, KEEP_RECORDS.)
 template <int NX, class Hook>
 __device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
                                                const double (&rb)[(NX + 3) / 4], const double* Wm, acc4_t& X0,
                                                acc4_t& X1, Hook hook) {
-  constexpr int KS = (NX + 3) / 4, WP = McScratch<NX>::WP;
+  constexpr int KS = (NX + 3) / 4, WP = McPitch<NX>::WP;
   int lane_o = lane;  // (opaque: the lane predicates of one core are recomputed, not kept in scalar registers)
   asm volatile("" : "+v"(lane_o));
   const int li = lane_o & 15, lk = lane_o >> 4;
-  // S-bar^-1 = W'W as one tile; being symmetric, its accumulator components are at once its
-  // A-operand fragments: X = S-bar^-1 [r_a | b~ | r_bb] needs no further data movement
-  double wt[KS], b0[KS];
+  double wt[KS], wa[KS], b0[KS];
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
-    wt[q] = Wm[(4 * q + lk) * WP + li];  // W(k, li): A operand of W'(i, k) and B operand of W(k, j)
+    wt[q] = Wm[(4 * q + lk) * WP + li];  // W(k, li): A operand of W'(i, k)
+    wa[q] = Wm[li * WP + 4 * q + lk];    // W(li, k): A operand of W(i, k)
     // columns beyond the blocks carry finite don't-cares: they only reach tile elements nobody reads
     b0[q] = li == NX ? c[q] : ra[q];
   }
   const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-  acc4_t Si = zero;
-#pragma unroll
-  for (int q = 0; q < KS; ++q) Si = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], wt[q], Si, 0, 0, 0);
-  X0 = zero; X1 = zero;
+  acc4_t Y0 = zero, Y1 = zero;
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
-    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], b0[q], X0, 0, 0, 0);
-    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Si[q], rb[q], X1, 0, 0, 0);
+    Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], b0[q], Y0, 0, 0, 0);
+    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], rb[q], Y1, 0, 0, 0);
   }
-  hook(b0, rb, X0, X1);
+  X0 = zero; X1 = zero;
+  double y0[KS], y1[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    y0[q] = Y0[q]; y1[q] = Y1[q];
+    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y0[q], X0, 0, 0, 0);
+    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y1[q], X1, 0, 0, 0);
+  }
+  hook(y0, y1, Y0, Y1);
 }
 
-template <int NX, class Hook>
-__device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t& c, const double (&ra)[(NX + 3) / 4],
-                                                const double (&rb)[(NX + 3) / 4], McScratch<NX>& m,
-                                                double* lstore, acc4_t& X0, acc4_t& X1, Hook hook) {
-  constexpr int SP = McScratch<NX>::SP, WP = McScratch<NX>::WP;
-  // the lane id is made opaque here so that the lane predicates of one core are recomputed (one
-  // v_cmp) instead of being kept in scalar registers across the whole kernel (spills)
+// The pass of ONE separator whose record keeps X = S-bar^-1 R (every level >= 1): the paired pass (chol_pair_y_mc
+// below) with both halves on the SAME tile. DPP rows 0-1 (lanes 0..31) carry the panel, one column per lane --
+// h = lane & 31: h < NX column h of r_a, h == NX the rhs column b~ (taken from the tile here), NX < h <= 2 NX column
+// h - NX - 1 of r_bb -- and leave the pass with Y = L^-1 [r_a | b~ | r_bb]; rows 2-3 carry the unit vectors and leave
+// with W = L^-1. The forward substitution of a column costs the same FMAs whatever the column is, and the recurrence
+// is per 16-lane row: with one separator per wavefront the rows would otherwise repeat each other's work.
+//   w: in = this lane's panel column (lanes < 32 other than the b~ lane; the rest: anything finite), clobbered.
+// LDS: the S-bar tile at buf[0, 16 SP); then, over it, the tiles Y0 = L^-1 [r_a | b~], Y1 = L^-1 r_bb (rows = k,
+// pitch YP, 4 KS rows) and W (pitch WP, 16 rows; zero outside the leading NX x NX block).
+template <int NX>
+struct McWyLayout {
+  static constexpr int SP = McPitch<NX>::SP, WP = McPitch<NX>::WP, KS = (NX + 3) / 4, YP = 17, TILE = 4 * KS * YP;
+  static constexpr int Y0 = 0, Y1 = TILE, W = 2 * TILE;
+  static constexpr int SIZE = 2 * TILE + 16 * WP > 16 * SP ? 2 * TILE + 16 * WP : 16 * SP;
+  static_assert(2 * NX + 1 <= 32, "the panel fits the lanes of two DPP rows");
+};
+template <int NX>
+__device__ __forceinline__ bool chol_wy_mc(const int lane_in, const acc4_t& c, double* buf, double (&w)[NX],
+                                           double* lstore) {
+  using P = McWyLayout<NX>;
+  constexpr int SP = P::SP, YP = P::YP, KS = P::KS;
+  static_assert(P::YP == P::WP, "one store stride for both kinds of lanes");
   int lane = lane_in;
   asm volatile("" : "+v"(lane));
-  const int li = lane & 15, lk = lane >> 4;
+  const int li = lane & 15, lk = lane >> 4, h = lane & 31;
   const int ri = li < NX ? li : NX - 1;  // lanes NX..15 of a 16-lane row are padding: they repeat row NX - 1
-  SEG_INIT();
 #pragma unroll
-  for (int g = 0; g < 4; ++g) m.scr[(lk + 4 * g) * SP + li] = c[g];
+  for (int g = 0; g < 4; ++g) buf[(lk + 4 * g) * SP + li] = c[g];
   wave_lds_sync();
-  double acc[NX], w[NX];
+  double acc[NX];
   if constexpr (NX % 2 == 0) {
 #pragma unroll
     for (int j = 0; j < NX; j += 2) {
-      const double2 t = *reinterpret_cast<const double2*>(&m.scr[ri * SP + j]);
+      const double2 t = *reinterpret_cast<const double2*>(&buf[ri * SP + j]);
       acc[j] = t.x; acc[j + 1] = t.y;
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < NX; ++j) acc[j] = m.scr[ri * SP + j];
+    for (int j = 0; j < NX; ++j) acc[j] = buf[ri * SP + j];
   }
-  // Left-looking Cholesky, one row per lane of every 16-lane DPP row (the four rows of the wavefront
-  // repeat it), fused with the forward substitution of the unit vectors (lane c < NX: column c of
-  // W = L^-1): step j takes row j of L from lane j inside the FMAs (v_fmac_f64_dpp row_newbcast,
-  // kernels_dpp.hpp) -- 132 FMAs + 12 broadcasts per separator where the v_readlane form of round 1
-  // needed 156 broadcast pairs + 132 FMAs. 1 / sqrt(pivot): hardware estimate (v_rsq_f64, ~2^-26) + one
-  // Newton step, within a few ulp; a non-positive pivot turns into NaN and stays NaN through every later
-  // pivot, so ONE test after the last step flags the separator.
-  const bool bad = rb_chol_inv<NX>(li, acc, w);
-  SEG(30);
-  {  // every lane stores its column (the four DPP rows hold identical copies: benign duplicates, no select, and no
-     // store under a lane predicate, which would make the compiler sink the whole W recurrence behind it)
+  if (lk >= 2) {  // (plain selects / loads under lane predicates: no cross-lane operation inside)
 #pragma unroll
-    for (int r = 0; r < NX; ++r) m.W[r * WP + li] = w[r];
+    for (int k = 0; k < NX; ++k) w[k] = (k == li) ? 1.0 : 0.0;
+  } else if (h == NX) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) w[k] = buf[k * SP + NX];
+  }
+  const bool bad = rb_chol_inv<NX, false>(li, acc, w);
+  wave_lds_sync();  // (every lane has its row of S-bar and the rhs column: the tiles may overwrite the S-bar tile)
+  {
+    // rows 0-1: column h of Y0 (h <= NX), column h - NX - 1 of Y1 (h <= 2 NX), the idle lanes dump into the pad column
+    // of Y1; rows 2-3: column li of W (twice the same values: benign duplicates; lanes li >= NX hold zeros).
+    // Unconditional stores: a store under a lane predicate makes the compiler sink the recurrence behind it.
+    const int ycol = h <= NX ? P::Y0 + h : P::Y1 + (h <= 2 * NX ? h - NX - 1 : YP - 1);
+    double* dst = buf + (lk < 2 ? ycol : P::W + li);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) dst[k * YP] = w[k];
+    // rows NX .. 4 KS - 1 of the Y tiles (read by the last k-step) and rows NX .. 15 of W: zero
+    if constexpr (4 * KS > NX) {
+#pragma unroll
+      for (int e0 = 0; e0 < (4 * KS - NX) * YP; e0 += 32) {
+        const int e = e0 + h;
+        if (e < (4 * KS - NX) * YP && lk < 2) {
+          buf[P::Y0 + NX * YP + e] = 0.0;
+          buf[P::Y1 + NX * YP + e] = 0.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int e0 = 0; e0 < (16 - NX) * P::WP; e0 += 32) {
+      const int e = e0 + h;
+      if (e < (16 - NX) * P::WP && lk >= 2) buf[P::W + NX * P::WP + e] = 0.0;
+    }
   }
   if (lstore && lane < NX) store_row<NX>(lstore + li * NX, acc);
   wave_lds_sync();
-  SEG(31);
-  factor_tail_mc<NX>(lane, c, ra, rb, m.W, X0, X1, hook);
-  SEG(33);
   return bad;
+}
+
+// ... and its matrix-core tail: X = W'Y (the record), hook(Y0, Y1, Y0, Y1) for the Gram products.
+template <int NX, class Hook>
+__device__ __forceinline__ void tail_wy_mc(const int lane, const double* buf, acc4_t& X0, acc4_t& X1, Hook hook) {
+  using P = McWyLayout<NX>;
+  constexpr int KS = P::KS;
+  int lane_o = lane;
+  asm volatile("" : "+v"(lane_o));
+  const int li = lane_o & 15, lk = lane_o >> 4;
+  double wt[KS], y0[KS], y1[KS];
+  acc4_t Z0 = {0.0, 0.0, 0.0, 0.0}, Z1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    wt[q] = buf[P::W + (4 * q + lk) * P::WP + li];  // W(k, li): A operand of W'(i, k)
+    y0[q] = buf[P::Y0 + (4 * q + lk) * P::YP + li];
+    y1[q] = buf[P::Y1 + (4 * q + lk) * P::YP + li];
+    Z0[q] = y0[q]; Z1[q] = y1[q];
+  }
+  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+  X0 = zero; X1 = zero;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y0[q], X0, 0, 0, 0);
+    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y1[q], X1, 0, 0, 0);
+  }
+  hook(y0, y1, Z0, Z1);
 }
 
 // The Cholesky + inverse of TWO independent separators in one pass: DPP rows 0-1 (lanes 0..31) work on tile cA,
@@ -151,7 +205,7 @@ __device__ __forceinline__ bool factor_solve_mc(const int lane_in, const acc4_t&
 // Returns per lane: the separator of this lane's DPP row had a non-positive pivot.
 template <int NX>
 struct McPairLayout {
-  static constexpr int SP = McScratch<NX>::SP, WP = McScratch<NX>::WP;
+  static constexpr int SP = McPitch<NX>::SP, WP = McPitch<NX>::WP;
   static constexpr int SCR_A = 0, SCR_B = 16 * SP, W_A = 32 * SP, W_B = 0, SIZE = 32 * SP + 16 * WP;
   static_assert(16 * WP <= 16 * SP, "W_B fits over the S-bar tile of A");
 };
@@ -212,7 +266,7 @@ __device__ __forceinline__ bool chol_pair_mc(const int lane_in, const acc4_t& cA
 // LDS: S-bar tiles A | B at buf[0, 576); then the four Y tiles of 4 KS rows over them.
 template <int NX>
 struct McPairYLayout {
-  static constexpr int SP = McScratch<NX>::SP, KS = (NX + 3) / 4, YP = 17, TILE = 4 * KS * YP;
+  static constexpr int SP = McPitch<NX>::SP, KS = (NX + 3) / 4, YP = 17, TILE = 4 * KS * YP;
   static constexpr int SCR_A = 0, SCR_B = 16 * SP;
   static constexpr int SIZE = 4 * TILE > 32 * SP ? 4 * TILE : 32 * SP;
   // tile t of separator x (x: 0 = A, 1 = B; t: 0 = Y0, 1 = Y1)
@@ -437,7 +491,7 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
 template <int NX, int NU>
 struct alignas(16) ReducedLds {
   static constexpr int W = NX + NU, ROWS = 2 * NX + NU, WP = (W % 2 == 0) ? W + 2 : W;
-  static constexpr int SLOT = RedSlot<NX>::SIZE, NSC = (int)(sizeof(McScratch<NX>) / 8);
+  static constexpr int SLOT = RedSlot<NX>::SIZE, NSC = McWyLayout<NX>::SIZE;  // the pass of a separator of level >= 1
   static constexpr int NB0 = 4 * NX * WP, NB1 = SLOT + NX * WP;
   static constexpr int NB2 = McPairLayout<NX>::SIZE;  // the paired Cholesky of the bottom levels
   static constexpr int NB3 = McPairYLayout<NX>::SIZE;  // ... and its compact-record form (Y tiles)
@@ -447,7 +501,6 @@ struct alignas(16) ReducedLds {
   double buf[NBUF];
   double rq[4 * W];
   double rh[4 * ROWS];
-  __device__ __forceinline__ McScratch<NX>& scratch() { return *reinterpret_cast<McScratch<NX>*>(buf); }
 };
 
 // One separator of an upper level (l >= 2) of the separator-only schedule on the matrix-core core
@@ -463,11 +516,10 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
                                                      const int store_l, ReducedLds<NX, NU>& lds) {
   constexpr int W = NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
   constexpr int WP = ReducedLds<NX, NU>::WP, SLOT = RedSlot<NX>::SIZE;
-  // slot and [A | B] are dead once the tile and the coupling fragments are in registers: the
-  // core's scratch lies over them
+  // slot and [A | B] are dead once the tile and the panel columns are in registers: the tiles of the
+  // pass (McWyLayout) lie over them
   double* slot = lds.buf;          // DL | DR | CA | CB | gL | gR of this separator
   double* abs_ = lds.buf + SLOT;   // [A_s | B_s]
-  McScratch<NX>& m = lds.scratch();
   double* rq = lds.rq;             // 1 / [Q_s | R_s], 1 / Q_{s+1}
   double* zs = lds.rh;             // rhs(s), rhs(s+1).lambda | x
   static_assert(4 * W >= W + NX && 4 * (2 * NX + NU) >= NX + W + 2 * NX, "shared arrays of the bottom levels are large enough");
@@ -534,39 +586,41 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
   const double *gL = slot + 2 * TRI + 2 * NN, *gR = slot + 2 * TRI + 2 * NN + NX;
 
   // [S-bar | b~] = leaf tile - DL - DR | - gL - gR
-  double ra[KSN], rb[KSN];
-#pragma unroll
-  for (int q = 0; q < KSN; ++q) {
-    const int kq = 4 * q + lk, i = kq < NX ? kq : NX - 1;
-    const double ca = CA[i * NX + ri], cb = CB[i * NX + ri];
-    ra[q] = hasA ? -ca : 0.0;
-    rb[q] = hasB ? -cb : 0.0;
-  }
   const acc4_t c0 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_, rq, rq + W, zs, zs + NX + W, [&](int g) {
     const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
     const int tix = RedSlot<NX>::tri(ic, ri);
     const double dd = DL[tix] + DR[tix], gg = gL[ic] + gR[ic];
     return -(li == NX ? gg : dd);
   });
+  // the panel, one column per lane of DPP rows 0-1 (chol_wy_mc): r_a = -CA, r_bb = -CB, straight from the staged slot
+  double wcol[NX];
+  {
+    const int h = lane & 31;
+    const bool is_a = h < NX, is_b = h > NX && h <= 2 * NX;
+    const double* src = is_a ? CA + h : CB + (is_b ? h - NX - 1 : 0);
+    const double sign = ((is_a && hasA) || (is_b && hasB)) ? -1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) wcol[k] = src[k * NX] * sign;
+  }
   wave_lds_sync();  // last read of the staged operands
-  m.init(lane);
   SEG(9);
 
   acc4_t X0, X1, unused;
-  if (factor_solve_mc<NX>(lane, c0, ra, rb, m, store_l ? Fblk(F, d, b, l, s + 1) : nullptr, X0, X1,
-                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-                            acc4_t g00, g01, g11;
-                            gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
-                            const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-                            if constexpr (TREE)
-                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
-                                          StoreThrough());
-                            else
-                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
-                                          StorePlain());
-                          }) &&
-      lane == 0)
+  if (chol_wy_mc<NX>(lane, c0, lds.buf, wcol, store_l ? Fblk(F, d, b, l, s + 1) : nullptr) && lane == 0)
     flag_failure(info, d, b);
+  SEG(31);
+  tail_wy_mc<NX>(lane, lds.buf, X0, X1,
+                 [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+                   acc4_t g00, g01, g11;
+                   gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
+                   const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+                   if constexpr (TREE)
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
+                                 StoreThrough());
+                   else
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
+                                 StorePlain());
+                 });
   SEG(13);
   store_record_mc<NX>(rec + ((size_t)b * N + s) * (2 * NN + NX), lane, hasA, hasB, X0, X1);
 #ifdef NDLQR_SEGTIME
@@ -655,7 +709,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   // core's scratch lies over it
   __shared__ ReducedLds<NX, NU> lds;
   double* abs_ = lds.buf;            // [A | B] of the four knots
-  McScratch<NX>& m = lds.scratch();
   double* rq = lds.rq;               // 1 / [Q | R] of the four knots
   double* rh = lds.rh;               // their raw right-hand sides
   const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = blockIdx.x * 4;
@@ -803,29 +856,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   store_record_mc<NX>(myrec + 2 * REC, lane, true, hasB, X0, X1);
   SEG(35);
   }
-  m.init(lane);  // the scratch of t: the pair's tiles lay over the zero rows of its W
-
-  // ---- t = k0 + 1 (level 1): r_a = -CA[t] = -Y_bb'Y_a of s0, r_bb = -CB[t] = -Y_a'Y_bb of s2;
-  //      pushes of the whole group to the separators k0 - 1 (A) and k0 + 3 (B)
-  double rat[KSN], rbt[KSN];
+  // ---- t = k0 + 1 (level 1): r_a = -CA[t] = -Y_bb'Y_a of s0, r_bb = -CB[t] = -Y_a'Y_bb of s2: the two coupling tiles
+  //      go from the accumulators through LDS (over the dead tiles of the pair) to one panel column per lane
+  //      (chol_wy_mc); pushes of the whole group to the separators k0 - 1 (A) and k0 + 3 (B)
+  double wcol[NX];
+  {
+    constexpr int TP = 17;
+    static_assert(2 * 16 * TP <= ReducedLds<NX, NU>::NBUF, "both coupling tiles fit the buffer");
+    double* ta = lds.buf;
+    double* tb = lds.buf + 16 * TP;
+    wave_lds_sync();  // (the operands of the level-0 tails are in registers)
 #pragma unroll
-  for (int q = 0; q < KSN; ++q) { rat[q] = -ca_t[q]; rbt[q] = -cb_t[q]; }
+    for (int g = 0; g < 4; ++g) {
+      ta[(lk + 4 * g) * TP + li] = -ca_t[g];
+      tb[(lk + 4 * g) * TP + li] = -cb_t[g];
+    }
+    wave_lds_sync();
+    const int h = lane & 31;
+    const bool is_a = h < NX, is_b = h > NX && h <= 2 * NX;
+    const double* src = is_a ? ta + h : tb + (is_b ? h - NX - 1 : 0);  // (the lanes without a column: finite don't-cares)
+#pragma unroll
+    for (int k = 0; k < NX; ++k) wcol[k] = src[k * TP];
+    wave_lds_sync();  // the S-bar tile of the pass goes over the coupling tiles
+  }
   const bool leftchild = (k0 & 4) == 0;
   const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
   const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
-  if (factor_solve_mc<NX>(lane, c_t, rat, rbt, m, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr, X0, X1,
-                          [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
-                            acc4_t g00, g01, g11;
-                            gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
-                            if constexpr (TREE)
-                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
-                                          StoreThrough(), StoreThrough());
-                            else
-                              push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
-                                          StorePlain(), StorePlain());
-                          }) &&
-      lane == 0)
+  if (chol_wy_mc<NX>(lane, c_t, lds.buf, wcol, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr) && lane == 0)
     flag_failure(info, d, b);
+  tail_wy_mc<NX>(lane, lds.buf, X0, X1,
+                 [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
+                   acc4_t g00, g01, g11;
+                   gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
+                   if constexpr (TREE)
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
+                                 StoreThrough(), StoreThrough());
+                   else
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
+                                 StorePlain(), StorePlain());
+                 });
   SEG(34);
   store_record_mc<NX>(myrec + REC, lane, hasA, hasB, X0, X1);
 #ifdef NDLQR_SEGTIME

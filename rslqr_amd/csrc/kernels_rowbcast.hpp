@@ -19,9 +19,9 @@
 //   rb_bottom       leaf phase + tree levels 0, 1: a wavefront owns 16 knots = four groups of four, one
 //                   group per DPP row; three passes (s0 = k0, s2 = k0 + 2, t = k0 + 1 of every group)
 //   rb_backsub_top  multipliers of the separators of level >= 3, one workgroup per problem
-//   rb_backsub      back-substitution of eight knots per workgroup; level-0 separators keep only
-//                   S-bar^-1 (packed lower triangle, n (n + 1) / 2 doubles instead of 2 n^2 + n): their
-//                   f_a, f_bb, z_sep follow from the problem data the kernel reads anyway
+//   rb_backsub      back-substitution of eight knots per workgroup; level-0 separators keep only the
+//                   Cholesky factor of S-bar (packed lower triangle, n (n + 1) / 2 doubles instead of
+//                   2 n^2 + n): their f_a, f_bb, z_sep follow from the problem data the kernel reads anyway
 // The upper levels stay on reduced_level_mc (kernels_bottom_reduced.hpp): a four-separators-per-
 // wavefront level kernel in this form was measured slower at every level (127 vs 108 us at level 2,
 // 13 vs 6.5 us at the root: 32 KB of staged slots per wavefront leave five wavefronts per CU).
@@ -97,18 +97,34 @@ __device__ __forceinline__ double rb_mulv_sub(const double (&A)[NA], double b, d
 }
 
 // ------------------------------------------------------------------------------------- separator core (rb_chol_inv: kernels_dpp.hpp)
-// Row i of S-bar^-1 = W'W from the columns of W: Si(i, c) = sum_{k >= c} W(k, i) W(k, c)
-// (terms with k < i vanish by themselves: w[k] = 0 there).
+// X = S-bar^-1 R without ever forming S-bar^-1 (round 4; DESIGN.md section 3.2 "numerics"): after rb_chol_inv lane i
+// holds row i of L and column i of W = L^-1.
+//   rb_solve_prep   dk = 1 / L(k, k) (= W(k, k), from lane k), m[k] = L(i, k) dk[k] for k < i (else 0),
+//                   wt[k] = W(k, i) dk[k]
+//   rb_fsub         Z <- D L^-1 Z in place, rows in lanes (right-looking forward substitution: step k subtracts
+//                   m[k] times row k -- final by then, taken from lane k inside the FMA -- from every row below it;
+//                   the scaling by 1 / L(k, k) is folded into m and wt, so no step rescales anything)
+//   X = rb_mul(wt, Z)   = W' D^-1 (D L^-1 R) = L^-T L^-1 R
+// n (2n + 1) more row-broadcast FMAs per separator than X = (W'W) R, minus the n (n + 1) / 2 of W'W.
 template <int NX>
-__device__ __forceinline__ void rb_sinv(const double (&w)[NX], double (&Si)[NX]) {
-  sfor<NX>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    double s = 0.0;
-    sfor<NX - c>([&](auto kc) {
-      constexpr int k = c + decltype(kc)::value;
-      fmac_bc<c>(s, w[k], w[k]);
-    });
-    Si[c] = s;
+__device__ __forceinline__ void rb_solve_prep(const int i, const double (&Lrow)[NX], double (&w)[NX], double (&m)[NX],
+                                              double (&wt)[NX]) {
+  dpp_fence(w);
+  sfor<NX>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double dk = row_bc<k>(w[k]);
+    m[k] = (k < i) ? Lrow[k] * dk : 0.0;
+    wt[k] = w[k] * dk;
+  });
+}
+template <int KD, int NC, int NA, int NB>
+__device__ __forceinline__ void rb_fsub(const double (&m)[NA], double (&Z)[NB]) {
+  static_assert(KD <= NA && NC <= NB && NC >= 4, "shapes; a column is read by a DPP instruction at least NC instructions after it was written");
+  dpp_fence(Z);
+  sfor<KD>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) fnmac_bc<k>(Z[c], Z[c], m[k]);
   });
 }
 
@@ -283,11 +299,12 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
   const RedSlot<NX> sA = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
   const RedSlot<NX> sB = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
 
-  // Elimination of one level-0 separator (knot s in slot sl): S-bar^-1 goes to its record (row i, lower
-  // triangle packed: entry (i, c), c <= i, at i (i + 1) / 2 + c); returns X = S-bar^-1 [r_a | b~ | r_bb].
+  // Elimination of one level-0 separator (knot s in slot sl): its Cholesky factor L goes to the record (row i, lower
+  // triangle packed: entry (i, c), c <= i, at i (i + 1) / 2 + c; rb_backsub substitutes with it); returns
+  // X = S-bar^-1 [r_a | b~ | r_bb] = L^-T L^-1 [..] (Xa[NX] = the rhs column).
   auto eliminate0 = [&](const int sl, const int kn, const bool fst, const bool ha, const bool hb, double* const r,
-                        double (&Xa)[NX], double& xz, double (&Xb)[NX]) {
-    double Si[NX], bz;
+                        double (&Xa)[NX + 1], double (&Xb)[NX]) {
+    double m[NX], wt[NX], bz;
     {
       double S[NX], w[NX];
       {
@@ -296,19 +313,31 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
         rb_leaf<NX, W>(i, abrow, T, tz, lds.rq[kn + 1][ic], lds.rh[kn + 1][ic], lds.rh[kn + 1][NX + ic], S, bz);
       }
       if (rb_chol_inv<NX>(i, S, w) && i == 0) flag_failure(info, d, b);
-      rb_sinv<NX>(w, Si);
-    }
-    if (rowlane) {
+      if (rowlane) {
 #pragma unroll
-      for (int c = 0; c < NX; ++c)
-        if (c <= i) r[i * (i + 1) / 2 + c] = Si[c];
+        for (int c = 0; c < NX; ++c)
+          if (c <= i) r[i * (i + 1) / 2 + c] = S[c];
+      }
+      rb_solve_prep<NX>(i, S, w, m, wt);
     }
-    double R[NX];
-    load_Ra(sl, kn, ha, R);
-    rb_mul<NX, NX, true>(Si, R, Xa);
-    xz = rb_mulv<NX>(Si, bz);
-    load_Rb(sl, kn, hb, R);
-    rb_mul<NX, NX, true>(Si, R, Xb);
+    {
+      double Z[NX + 1];
+      {
+        double R[NX];
+        load_Ra(sl, kn, ha, R);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Z[c] = R[c];
+      }
+      Z[NX] = bz;
+      rb_fsub<NX, NX + 1>(m, Z);
+      rb_mul<NX, NX + 1, true>(wt, Z, Xa);
+    }
+    {
+      double Z[NX];
+      load_Rb(sl, kn, hb, Z);
+      rb_fsub<NX, NX>(m, Z);
+      rb_mul<NX, NX, true>(wt, Z, Xb);
+    }
   };
 
   // ================================================================ pass 1: s0 = k0 (knots k0, k0 + 1)
@@ -319,8 +348,9 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
     rb_leaf<NX, W>(i, abrow, T, tz, lds.rq[4 * g + 2][ic], lds.rh[4 * g + 2][ic], lds.rh[4 * g + 2][NX + ic], St, bzt);
   }
   {
-    double Xa[NX], Xb[NX], xz;
-    eliminate0(2 * g, 4 * g, first, hasA, true, myrec, Xa, xz, Xb);
+    double Xa[NX + 1], Xb[NX];
+    eliminate0(2 * g, 4 * g, first, hasA, true, myrec, Xa, Xb);
+    const double xz = Xa[NX];
     double Rt[NX], G[NX];
     load_RaT(2 * g, 4 * g, hasA, Rt);
     // to separator k0 - 1 (DR, gR: plain stores, they start this solve's accumulators) ...
@@ -345,8 +375,9 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
   rb_stage_ab<NX, NU>(lane, 1, abm, lds.ab);
   wave_lds_sync();
   {
-    double Xa[NX], Xb[NX], xz;
-    eliminate0(2 * g, 4 * g + 2, false, true, hasB, myrec + 2 * REC, Xa, xz, Xb);
+    double Xa[NX + 1], Xb[NX];
+    eliminate0(2 * g, 4 * g + 2, false, true, hasB, myrec + 2 * REC, Xa, Xb);
+    const double xz = Xa[NX];
     double Rt[NX], G[NX];
     load_RbT(2 * g, 4 * g + 2, hasB, Rt);
     rb_mul<NX, NX, true>(Rt, Xb, G);                       // r_bb' S^-1 r_bb -> DL of separator k0 + 3
@@ -366,21 +397,29 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
 
   // ================================================================ pass 3: t = k0 + 1
   {
-    double Xa[NX], Xb[NX], xz;
+    double Xa[NX + 1], Xb[NX];
     {
-      double Si[NX];
+      double m[NX], wt[NX];
       {
         double w[NX];
         if (rb_chol_inv<NX>(i, St, w) && i == 0) flag_failure(info, d, b);
-        rb_sinv<NX>(w, Si);
+        rb_solve_prep<NX>(i, St, w, m, wt);
       }
-      rb_mul<NX, NX, true>(Si, Rat, Xa);
-      xz = rb_mulv<NX>(Si, bzt);
-      rb_mul<NX, NX, true>(Si, Rbt, Xb);
+      {
+        double Z[NX + 1];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Z[c] = Rat[c];
+        Z[NX] = bzt;
+        rb_fsub<NX, NX + 1>(m, Z);
+        rb_mul<NX, NX + 1, true>(wt, Z, Xa);
+      }
+      rb_fsub<NX, NX>(m, Rbt);
+      rb_mul<NX, NX, true>(wt, Rbt, Xb);
     }
+    const double xz = Xa[NX];
     if (rowlane) {  // record f_a | f_bb | z_sep
       double* r = myrec + REC;
-      if (hasA) store_row<NX>(r + i * NX, Xa);
+      if (hasA) store_row<NX>(r + i * NX, reinterpret_cast<const double (&)[NX]>(Xa));
       if (hasB) store_row<NX>(r + NN + i * NX, Xb);
       r[2 * NN + i] = xz;
     }
@@ -424,9 +463,9 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
 // rb_backsub: one workgroup per eight knots = one level-2 subtree. It needs only the two multipliers
 // next to it from ytop (backsub_small fetched the K - 3 records on its path to the root instead and
 // resolved them again in every workgroup), resolves its level-2 and level-1 separators from their
-// records and its four level-0 separators from the problem data and the compact record S-bar^-1 of
-// rb_bottom (their neighbours s - 1, s + 1 are known by then):
-//   v = [A_s | B_s] z-hat(s) - r_a y_{s-1} - r_bb y_{s+1} - z(s+1).lambda - z(s+1).x / Q_{s+1},   y_s = S-bar^-1 v
+// records and its four level-0 separators from the problem data and their compact record, the Cholesky factor L
+// of S-bar (their neighbours s - 1, s + 1 are known by then):
+//   v = [A_s | B_s] z-hat(s) - r_a y_{s-1} - r_bb y_{s+1} - z(s+1).lambda - z(s+1).x / Q_{s+1},   y_s = L^-T L^-1 v
 //   r_a y = -A_s (y / Q_s),   r_bb y = -(A_{s+1}' y) / Q_{s+1}
 // (A_{s+1}' y_{s+1} is the dot product the state rows of knot s + 1 need anyway); then states and
 // inputs from the stationarity rows (src/solve.c:137-182 produces the same quantities level by level):
@@ -487,7 +526,7 @@ struct alignas(16) RbBacksubLds {
   static constexpr int R0P = (R0 + 1) / 2 * 2;      // compact record, padded to whole 16-byte words
   static constexpr int WP = RbKnot<NX, NU>::WP;
   double ab[8][NX * WP];
-  double rec0[4][R0P];    // level-0 separators first + 0, 2, 4, 6: S-bar^-1, packed lower triangle
+  double rec0[4][R0P];    // level-0 separators first + 0, 2, 4, 6: Cholesky factor of S-bar, packed lower triangle
   double rec1[3][REC + (REC & 1)];  // separators first + 1, first + 3, first + 5: f_a | f_bb | z_sep
   double ys[9][NX];       // [0..6]: separators first .. first + 6; [7]: first - 1; [8]: first + 7
   double qs[8][W];        // 1 / [Q | R]
@@ -499,9 +538,7 @@ struct alignas(16) RbBacksubLds {
 template <int NX, int NU>
 __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                                                   const double* __restrict__ rhs, const double* __restrict__ recs,
-                                                  const double* __restrict__ ytop, double* __restrict__ z,
-                                                  const int rec0_l) {
-  // rec0_l: the compact level-0 records hold the Cholesky factor L of S-bar (bottom_reduced_mc) instead of S-bar^-1 (rb_bottom)
+                                                  const double* __restrict__ ytop, double* __restrict__ z) {
   using Lds = RbBacksubLds<NX, NU>;
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP;
   constexpr int R0 = Lds::R0;
@@ -626,7 +663,7 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
     lds.dots[kn][rr - NX] = dot;
   }
   __syncthreads();
-  // ---- level-0 separators: v, then y = S-bar^-1 v
+  // ---- level-0 separators: v, then y = L^-T L^-1 v
   if (sep_thread && l == 0) {
     const int k = s - first;  // even knot of the workgroup
     const bool fst = s == 0;
@@ -645,45 +682,37 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
     lds.vs[k >> 1][r] = v;
   }
   __syncthreads();
-  if (rec0_l) {  // (uniform) the records hold the Cholesky factor L of S-bar (packed rows): y = L^-T (L^-1 v)
-    if (t < 64) {
-      // wavefront 0: the four level-0 separators of the tile in its four DPP rows, row r of L per lane; both
-      // substitutions broadcast the freshly resolved entry inside the row (v_mov_b64_dpp row_newbcast): no LDS
-      // round trip and no barrier per step. (All 64 lanes run it -- DPP needs them active --, lanes r >= NX idle.)
-      const int j = t >> 4, r15 = t & 15, rc = r15 < NX ? r15 : NX - 1;
-      const double* Lp = lds.rec0[j];
-      const double dinv = 1.0 / Lp[rc * (rc + 1) / 2 + rc];
-      double lrow[NX], lcol[NX];
+  // the compact records hold the Cholesky factor L of S-bar (packed rows): y = L^-T (L^-1 v)
+  if (t < 64) {
+    // wavefront 0: the four level-0 separators of the tile in its four DPP rows, row r of L per lane; both
+    // substitutions broadcast the freshly resolved entry inside the row (v_mov_b64_dpp row_newbcast): no LDS
+    // round trip and no barrier per step. (All 64 lanes run it -- DPP needs them active --, lanes r >= NX idle.)
+    const int j = t >> 4, r15 = t & 15, rc = r15 < NX ? r15 : NX - 1;
+    const double* Lp = lds.rec0[j];
+    const double dinv = 1.0 / Lp[rc * (rc + 1) / 2 + rc];
+    double lrow[NX], lcol[NX];
 #pragma unroll
-      for (int c = 0; c < NX; ++c) {
-        const double lo = Lp[rc * (rc + 1) / 2 + (c < rc ? c : rc)];  // L(r, c), c < r
-        const double up = Lp[(c > rc ? c : rc) * ((c > rc ? c : rc) + 1) / 2 + rc];  // L(c, r), c > r
-        lrow[c] = (c < r15 && r15 < NX) ? lo : 0.0;
-        lcol[c] = (c > r15 && r15 < NX) ? up : 0.0;
-      }
-      double x = lds.vs[j][rc];
-      sfor<NX>([&](auto cc) {  // forward: t_c = x_c / L(c, c) is final when step c starts
-        constexpr int c = decltype(cc)::value;
-        double xs = x * dinv;
-        dpp_fence(xs);
-        x = fma(-lrow[c], row_bc<c>(xs), x);
-      });
-      x = x * dinv;  // t_r
-      sfor<NX>([&](auto cc) {  // backward, c descending: y_c is final when its step starts
-        constexpr int c = NX - 1 - decltype(cc)::value;
-        double xs = x * dinv;
-        dpp_fence(xs);
-        x = fma(-lcol[c], row_bc<c>(xs), x);
-      });
-      if (r15 < NX) lds.ys[2 * j][r15] = x * dinv;
+    for (int c = 0; c < NX; ++c) {
+      const double lo = Lp[rc * (rc + 1) / 2 + (c < rc ? c : rc)];  // L(r, c), c < r
+      const double up = Lp[(c > rc ? c : rc) * ((c > rc ? c : rc) + 1) / 2 + rc];  // L(c, r), c > r
+      lrow[c] = (c < r15 && r15 < NX) ? lo : 0.0;
+      lcol[c] = (c > r15 && r15 < NX) ? up : 0.0;
     }
-  } else if (sep_thread && l == 0) {
-    const double* v = lds.vs[(s - first) >> 1];
-    const double* si = lds.rec0[(s - first) >> 1];  // symmetric: row r from the packed lower triangle
-    double a = 0.0;
-#pragma unroll
-    for (int c = 0; c < NX; ++c) a = fma(c <= r ? si[r * (r + 1) / 2 + c] : si[c * (c + 1) / 2 + r], v[c], a);
-    lds.ys[q][r] = a;
+    double x = lds.vs[j][rc];
+    sfor<NX>([&](auto cc) {  // forward: t_c = x_c / L(c, c) is final when step c starts
+      constexpr int c = decltype(cc)::value;
+      double xs = x * dinv;
+      dpp_fence(xs);
+      x = fma(-lrow[c], row_bc<c>(xs), x);
+    });
+    x = x * dinv;  // t_r
+    sfor<NX>([&](auto cc) {  // backward, c descending: y_c is final when its step starts
+      constexpr int c = NX - 1 - decltype(cc)::value;
+      double xs = x * dinv;
+      dpp_fence(xs);
+      x = fma(-lcol[c], row_bc<c>(xs), x);
+    });
+    if (r15 < NX) lds.ys[2 * j][r15] = x * dinv;
   }
   __syncthreads();
 

@@ -82,7 +82,6 @@ static int launch_small(NdlqrHipCtx* c) {
       // records have to serve a record-based re-solve (KEEP_RECORDS) or the tree schedule runs
       const bool compact = plan.compact;
       c->schedule = tree ? "reduced-tree" : (compact ? "reduced" : "reduced-records");
-      bool launched_rb = false;  // the row-broadcast bottom kernel ran (its compact records hold S-bar^-1, the matrix-core kernel's W)
       {
         ScopedSlot t(c, SLOT_BOTTOM);
         bool launched = false;
@@ -91,7 +90,6 @@ static int launch_small(NdlqrHipCtx* c) {
             hipLaunchKernelGGL((ndlqr::rb_bottom<NX, NU>), dim3(d.N >> 4, d.batch), dim3(64), 0, c->stream, d, c->AB,
                                c->QR, c->rhs, c->red, c->rec, c->info);
             launched = true;
-            launched_rb = true;
           }
         }
         if (launched) {
@@ -125,7 +123,7 @@ static int launch_small(NdlqrHipCtx* c) {
           hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256),
                              sizeof(double) * (size_t)(d.N >> 3) * NX, c->stream, d, c->rec, c->ytop);
         hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
-                           c->QR, c->rhs, c->rec, c->ytop, c->z, launched_rb ? 0 : 1);
+                           c->QR, c->rhs, c->rec, c->ytop, c->z);
       } else {
         hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
                            c->QR, c->rhs, c->rec, c->z);

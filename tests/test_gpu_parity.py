@@ -336,7 +336,9 @@ HARD_FAMILIES = [(1.15, 1.0, 1.0), (1.0, 1e-4, 1.0), (1.3, 1e-3, 1.0), (1.0, 1.0
 # buckets, and the level-per-launch `reduced` schedule at a batch that selects it
 HARD_SHAPES = [(64, 16, 64, 1, "generic-reduced"), (32, 8, 128, 1, "generic-reduced"), (96, 16, 16, 1, "generic-reduced"),
                (128, 16, 8, 1, "generic-reduced"), (50, 10, 64, 1, "generic-reduced"), (7, 9, 64, 1, None),
-               (11, 3, 64, 1, None), (12, 4, 256, 40, "reduced"), (8, 4, 256, 40, "reduced")]
+               (11, 3, 64, 1, None), (12, 4, 256, 40, "reduced"), (8, 4, 256, 40, "reduced"), (6, 3, 256, 48, "reduced"),
+               (13, 4, 128, 80, "reduced"), (12, 4, 256, 1, "reduced-tree"), (6, 3, 64, 2, "reduced-tree"),
+               (4, 2, 128, 3, "knot-lean"), (5, 2, 64, 3, "knot-lean"), (2, 1, 64, 3, "knot-lean")]
 
 
 @pytest.mark.parametrize("n,m,N,batch,want", HARD_SHAPES)
