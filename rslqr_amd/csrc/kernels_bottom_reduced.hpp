@@ -485,35 +485,38 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
 }
 
 // LDS of one wavefront working on the reduced system: a buffer that first holds the staged inputs
-// and then, once the tiles and coupling fragments are in registers, the core's scratch; plus the
-// reciprocal weights and right-hand sides of the knots involved. Sized for both users: four knots
-// of the bottom levels, or slot + one knot of an upper level.
-template <int NX, int NU>
+// and then, once the tiles and the panel columns are in registers, the tiles of the pass; plus the
+// reciprocal weights and right-hand sides of the knots involved. BOTTOM: sized for the four knots of the
+// bottom levels (whose wavefront may go on to upper levels under the tree schedule: the larger of the two);
+// else for slot + one knot of an upper level alone (reduced_level_mc, reduced_top_mc: 6.8 instead of 8.1 KB
+// at (12,4), so that the LDS no longer caps those launches at 19 wavefronts per CU).
+template <int NX, int NU, bool BOTTOM = true>
 struct alignas(16) ReducedLds {
   static constexpr int W = NX + NU, ROWS = 2 * NX + NU, WP = (W % 2 == 0) ? W + 2 : W;
   static constexpr int SLOT = RedSlot<NX>::SIZE, NSC = McWyLayout<NX>::SIZE;  // the pass of a separator of level >= 1
-  static constexpr int NB0 = 4 * NX * WP, NB1 = SLOT + NX * WP;
-  static constexpr int NB2 = McPairLayout<NX>::SIZE;  // the paired Cholesky of the bottom levels
-  static constexpr int NB3 = McPairYLayout<NX>::SIZE;  // ... and its compact-record form (Y tiles)
+  static constexpr int NB0 = BOTTOM ? 4 * NX * WP : 0, NB1 = SLOT + NX * WP;
+  static constexpr int NB2 = BOTTOM ? McPairLayout<NX>::SIZE : 0;   // the paired Cholesky of the bottom levels
+  static constexpr int NB3 = BOTTOM ? McPairYLayout<NX>::SIZE : 0;  // ... and its compact-record form (Y tiles)
   static constexpr int NB01 = (NB0 > NB1 ? NB0 : NB1) > NSC ? (NB0 > NB1 ? NB0 : NB1) : NSC;
   static constexpr int NB23 = NB2 > NB3 ? NB2 : NB3;
   static constexpr int NBUF = NB01 > NB23 ? NB01 : NB23;
+  static constexpr int NRQ = BOTTOM ? 4 * W : (W + NX + 1) / 2 * 2, NRH = BOTTOM ? 4 * ROWS : (NX + W + 2 * NX + 1) / 2 * 2;
   double buf[NBUF];
-  double rq[4 * W];
-  double rh[4 * ROWS];
+  double rq[NRQ];
+  double rh[NRH];
 };
 
 // One separator of an upper level (l >= 2) of the separator-only schedule on the matrix-core core
 // (see reduced_level): subtree [base, base + 2^(l+1)) of problem b, by one wavefront.
 // TREE: called from the tree schedule -- the slot was written by wavefronts of this launch, possibly
 // on another XCD: it is read with L1-bypassing (`sc1`) loads and the couplings are stored through.
-template <int NX, int NU, bool TREE>
+template <int NX, int NU, bool TREE, class LdsT>
 __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l, const int base, const int b,
                                                      const int lane, const double* __restrict__ AB,
                                                      const double* __restrict__ QR,
                                                      const double* __restrict__ rhs, double* red,
                                                      double* __restrict__ rec, double* F, int* __restrict__ info,
-                                                     const int store_l, ReducedLds<NX, NU>& lds) {
+                                                     const int store_l, LdsT& lds) {
   constexpr int W = NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
   constexpr int WP = ReducedLds<NX, NU>::WP, SLOT = RedSlot<NX>::SIZE;
   // slot and [A | B] are dead once the tile and the panel columns are in registers: the tiles of the
@@ -522,7 +525,7 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
   double* abs_ = lds.buf + SLOT;   // [A_s | B_s]
   double* rq = lds.rq;             // 1 / [Q_s | R_s], 1 / Q_{s+1}
   double* zs = lds.rh;             // rhs(s), rhs(s+1).lambda | x
-  static_assert(4 * W >= W + NX && 4 * (2 * NX + NU) >= NX + W + 2 * NX, "shared arrays of the bottom levels are large enough");
+  static_assert(LdsT::NRQ >= W + NX && LdsT::NRH >= NX + W + 2 * NX, "the shared arrays are large enough for a level");
   const int N = d.N;
   const int T = 2 << l, s = base + (1 << l) - 1;
   const bool hasA = base > 0, hasB = base + T < N;
@@ -634,7 +637,7 @@ template <int NX, int NU>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void reduced_level_mc(
     Dims d, int l, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
     double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l) {
-  __shared__ ReducedLds<NX, NU> lds;
+  __shared__ ReducedLds<NX, NU, false> lds;
   reduced_separator_mc<NX, NU, false>(d, l, blockIdx.x * (2 << l), blockIdx.y, threadIdx.x, AB, QR, rhs, red, rec, F,
                                       info, store_l, lds);
 }
@@ -655,12 +658,12 @@ __device__ __forceinline__ void backsub_top_body(const Dims& d, const int b, con
                                                  const double* __restrict__ recs, double* __restrict__ ytop,
                                                  double* ytop_lds);
 template <int NX, int NU>
-__global__ __launch_bounds__(256) void reduced_top_mc(Dims d, const int l0, const double* __restrict__ AB,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void reduced_top_mc(Dims d, const int l0, const double* __restrict__ AB,
                                                       const double* __restrict__ QR, const double* __restrict__ rhs,
                                                       double* red, double* __restrict__ rec, double* F,
                                                       int* __restrict__ info, const int store_l,
                                                       double* __restrict__ ytop) {
-  __shared__ ReducedLds<NX, NU> lds[4];
+  __shared__ ReducedLds<NX, NU, false> lds[4];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.x;
   for (int l = l0; l < d.K; ++l) {
     int lane = threadIdx.x & 63;

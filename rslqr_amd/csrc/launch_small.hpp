@@ -111,7 +111,7 @@ static int launch_small(NdlqrHipCtx* c) {
       // ... which also runs the top-down sweep over the records of level >= 3 when the back-substitution is the
       // two-launch form and its array fits the workgroup's LDS
       const bool top_sweeps = !tree && ltop < d.K && compact &&
-                              sizeof(double) * (size_t)(d.N >> 3) * NX <= 4 * sizeof(ndlqr::ReducedLds<NX, NU>);
+                              sizeof(double) * (size_t)(d.N >> 3) * NX <= 4 * sizeof(ndlqr::ReducedLds<NX, NU, false>);
       if (!tree && ltop < d.K) {
         ScopedSlot t(c, SLOT_TOP);  // (a profile slot of its own: one kernel name per slot, like rocprofv3's per-kernel averages)
         hipLaunchKernelGGL((ndlqr::reduced_top_mc<NX, NU>), dim3(d.batch), dim3(256), 0, c->stream, d, ltop, c->AB,
