@@ -238,9 +238,10 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         q[p], r[p], d[p], x0[p] = g["q"], g["r"], g["d"], g["x0"]
     outs = [rslqr_amd.pinned_empty((batch, bs.nvars)) for _ in range(2)]
 
-    def run(k, full):
+    def run(k, full, dst=None):
+        dst = dst or outs
         for i in range(k):
-            err = bs.step_async(q, r, d, x0, outs[i & 1]) if full else bs.step_async(None, None, None, x0, outs[i & 1])
+            err = bs.step_async(q, r, d, x0, dst[i & 1]) if full else bs.step_async(None, None, None, x0, dst[i & 1])
             if err != 0:
                 raise RuntimeError("ndlqr_BatchStepAsync failed")
             if i >= 1:
@@ -250,7 +251,9 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
     end_to_end = {"steps": steps, "d2h_bytes_per_step": 8 * batch * bs.nvars,
                   "note": "ndlqr_BatchStepAsync, pinned host arrays, two steps in flight, rank 0; not part of `value`. "
                           "full_rhs: q, r, d, x0 read over the host link by the pack kernel, factor + solve, pack kernel, "
-                          "solutions down; x0_only: the same with x0 alone replaced (the usual MPC iteration)"}
+                          "solutions down; x0_only: the same with x0 alone replaced (the usual MPC iteration); "
+                          "x0_only_u0: x0 up, and of the solutions only u of knot 0 down (ndlqr_BatchSetStepSelection: what "
+                          "an MPC loop applies; [batch][m] doubles)"}
     for name, full in (("full_rhs", True), ("x0_only", False)):
         run(4, full)
         t0 = time.perf_counter()
@@ -259,6 +262,18 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         end_to_end[name] = {"ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e,
                             "h2d_bytes_per_step": 8 * batch * ((N * rows if full else 0) + n),
                             "equals_resident_solution": bool(np.array_equal(outs[(steps - 1) & 1], sol))}
+    # what an MPC loop consumes: u of knot 0 (the full vector stays resident: ndlqr_CopyBatchSolutionSlices / Solutions)
+    bs.set_step_selection(0, 1, rslqr_amd.SOLN_INPUT)
+    u0 = [rslqr_amd.pinned_empty((batch, 1, m)) for _ in range(2)]
+    run(4, False, u0)
+    t0 = time.perf_counter()
+    run(steps, False, u0)
+    e2e = (time.perf_counter() - t0) / steps
+    end_to_end["x0_only_u0"] = {"ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 8 * batch * n,
+                                "d2h_bytes_per_step": 8 * batch * m,
+                                "equals_resident_solution": bool(np.array_equal(
+                                    u0[(steps - 1) & 1][:, 0, :], sol[:, 2 * n:2 * n + m]))}
+    bs.set_step_selection()
     end_to_end["ms_per_step"] = end_to_end["full_rhs"]["ms_per_step"]
     end_to_end["solves_per_s"] = end_to_end["full_rhs"]["solves_per_s"]
     # H2D of the packed inputs (a fresh solver: the upload replaces the inputs)

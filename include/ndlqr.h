@@ -338,7 +338,14 @@ typedef struct NdLqrBatchSolver NdLqrBatchSolver;
                                      records + Cholesky factors, ~3.5 KB per knot at (12,4)) without
                                      materialising the factor array: ndlqr_SolveBatchRhsOnly works,
                                      ndlqr_CopyBatchFactors does not. Size-specialised shapes and every
-                                     other one up to 128 states (beyond: NDLQR_FLAG_KEEP_FACT). */
+                                     other one up to 128 states. */
+/* Reach of the modes by block size (runtime-sized kernels; the size-specialised instances of
+ * rslqr_amd/csrc/small_instances.def support every mode): the default fast mode and NDLQR_FLAG_KEEP_RECORDS work up
+ * to 128 states (n + m + 4 staged columns within the 160 KB of LDS: (128,32) is refused). NDLQR_FLAG_STRICT_FP and
+ * NDLQR_FLAG_KEEP_FACT run the knot-based kernels, whose separator kernel stages S-bar and the whole right-hand-side
+ * panel: up to about 82 states, and tile-filling block sizes (n a multiple of 16) up to 112; beyond that a solve
+ * returns NDLQR_ERR_INVALID with ndlqr_hip_last_error() = "nstates too large for ...". So does ndlqr_SyncFactorsToHost
+ * and the factor-based rhs-only re-solve there; the record-based one (NDLQR_FLAG_KEEP_RECORDS) is the way beyond. */
 
 NdLqrBatchSolver* ndlqr_NewBatchSolver(int nstates, int ninputs, int nhorizon, int batch,
                                        int device);
@@ -369,8 +376,9 @@ int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs); /* enqueue on the solver's stre
 int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
 /* One MPC step, asynchronous: new q, r, d, x0 (flat host layout as above) up, factor + solve against the resident
  * A, B, Q, R, the solutions [batch][nvars] down into `soln` (the array ndlqr_CopyBatchSolutions fills); q, r, d may each
- * be NULL (kept as ndlqr_InitializeBatch* / ndlqr_BatchSetRhsFlat left them: an MPC iteration often replaces x0 alone;
- * do not mix with steps that pass them -- those replace them in one of the two buffer sets only). Consecutive
+ * be NULL: that part of the right-hand side stays what its most recent writer -- ndlqr_InitializeBatch*,
+ * ndlqr_BatchSetRhsFlat or an earlier step -- left (an MPC iteration often replaces x0 alone; full steps and x0-only
+ * steps may be mixed freely: the library keeps track of which buffer set's copy is behind in what). Consecutive
  * steps alternate between the two buffer sets of the solve pipeline, so the transfers of one step run beside the
  * kernels of the other; `soln` of a step is complete after ndlqr_BatchSynchronize, or -- one step behind --
  * ndlqr_BatchSynchronizePrevious. Host arrays from ndlqr_HostAlloc (pinned) keep the copies asynchronous;
@@ -378,7 +386,20 @@ int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
  * ndlqr_InitializeWithLQRProblem + ndlqr_Solve + ndlqr_CopySolution (src/solve.h:20-32). */
 int ndlqr_BatchStepAsync(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
                          const double* x0, double* soln);
+/* Waits for the step before the most recent one; NDLQR_ERR_NOT_SPD when a Cholesky pivot of that step (or an earlier,
+ * unreported one) was not positive -- its `soln` is then not a solution. */
 int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs);
+/* What a step brings down: knots [knot0, knot0 + nknots) of every problem, of each knot the blocks of `blocks`, in
+ * the reference's order lambda, state, input -> soln = [batch][nknots][width], width = n per NDLQR_SOLN_LAMBDA /
+ * NDLQR_SOLN_STATE + m for NDLQR_SOLN_INPUT. nknots = 0: back to every solution [batch][nvars] (the default; what
+ * ndlqr_CopySolution hands back, src/solve.c:192-201). An MPC loop that applies u_0 asks for (0, 1, NDLQR_SOLN_INPUT):
+ * 32 KB instead of 59 MB per 1024 problems of (12,4,256). ndlqr_CopyBatchSolutionSlices: the same slice of the most
+ * recent solve, synchronously. */
+#define NDLQR_SOLN_LAMBDA 1u
+#define NDLQR_SOLN_STATE 2u
+#define NDLQR_SOLN_INPUT 4u
+int ndlqr_BatchSetStepSelection(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks);
+int ndlqr_CopyBatchSolutionSlices(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out);
 void* ndlqr_HostAlloc(size_t bytes); /* pinned host memory (NULL: no device / no memory) */
 void ndlqr_HostFree(void* p);
 int ndlqr_BatchNumVars(const NdLqrBatchSolver* bs);

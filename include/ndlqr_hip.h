@@ -37,6 +37,12 @@ const char* ndlqr_hip_last_error(void);
 
 /* replaces the allocation half of ndlqr_NewNdLqrSolver (src/solver.c:61-96) for a batch */
 NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch, int device);
+/* ... with creation options: NDLQR_CREATE_NO_PAD keeps the caller's block size on the device (a block size without
+ * a size-specialised instance otherwise runs zero-padded inside one, with another array layout: raw device pointers
+ * -- ndlqr_hip_device_pointers -- need the caller's own). The environment variable NDLQR_NO_PAD=1 does the same for
+ * every context of the process. */
+#define NDLQR_CREATE_NO_PAD 1u
+NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int batch, int device, unsigned create_flags);
 void ndlqr_hip_destroy(NdlqrHipCtx* ctx);
 int ndlqr_hip_set_flags(NdlqrHipCtx* ctx, unsigned flags); /* NDLQR_FLAG_* of ndlqr.h */
 unsigned ndlqr_hip_get_flags(const NdlqrHipCtx* ctx);
@@ -87,17 +93,22 @@ double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
  * [batch][N][n], r [batch][N][m], x0 [batch][n] -- what ndlqr_InitializeWithLQRProblem reads from the problem,
  * src/solver.c:141-190), packed and negated by a kernel, factor + solve, the solutions [batch][nvars] (the layout of
  * ndlqr_hip_download_solutions, src/solve.c:192-201) down into `soln`. q, r, d may each be NULL: that part of the
- * right-hand side stays as it is IN THE STEP'S BUFFER SET (an MPC iteration often replaces x0 alone; the two sets
- * alternate, and ndlqr_hip_upload_inputs / _upload_rhs / _pack_flat_device write both, so set q, r, d with one of those
- * and then step with x0 alone). Everything is ordered on the stream of the
+ * right-hand side stays what its most recent writer left -- an upload, the device-side packing or an earlier step (an
+ * MPC iteration often replaces x0 alone). There is ONE logical right-hand side; each buffer set of the pipeline has a
+ * copy, and a solve or step that lands on a set whose copy is behind in a part it does not itself replace first
+ * copies that part over (only a change of flow does: full steps followed by x0-only steps, a plain solve behind
+ * steps). Everything is ordered on the stream of the
  * step's buffer set, so with the two-deep pipeline the copies of one step run beside the kernels of the other. Give
  * pinned host memory (ndlqr_hip_host_alloc): copies from / to pageable memory are staged by the runtime and block.
  * `soln` of a step is complete after ndlqr_hip_synchronize (every step) or, one step behind,
- * ndlqr_hip_synchronize_previous (the step before the most recent one). The step replaces the right-hand side of
- * ITS buffer set only; ndlqr_hip_upload_inputs / _upload_rhs / _pack_flat_device set it for both again. */
+ * ndlqr_hip_synchronize_previous (the step before the most recent one; NDLQR_ERR_NOT_SPD when that step met a
+ * non-positive pivot). */
 int ndlqr_hip_step_async(NdlqrHipCtx* ctx, const double* q, const double* r, const double* d, const double* x0,
                          double* soln);
 int ndlqr_hip_synchronize_previous(NdlqrHipCtx* ctx);
+/* What a step brings down (ndlqr.h: ndlqr_BatchSetStepSelection) / the same slice of the latest solve, synchronously. */
+int ndlqr_hip_set_step_selection(NdlqrHipCtx* ctx, int knot0, int nknots, unsigned blocks);
+int ndlqr_hip_download_selection(NdlqrHipCtx* ctx, int knot0, int nknots, unsigned blocks, double* out);
 /* Pinned host memory for the transfer functions (hipHostMalloc): copies from / to it are asynchronous and run at the
  * rate of the host link. NULL when no device / no memory. */
 void* ndlqr_hip_host_alloc(size_t bytes);

@@ -18,6 +18,9 @@ from .api import (  # noqa: F401
     NdData,
     NdFactor,
     NdLqrSolver,
+    SOLN_INPUT,
+    SOLN_LAMBDA,
+    SOLN_STATE,
     device_count,
     exported_symbols,
     generate_synthetic,

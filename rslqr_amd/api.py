@@ -18,6 +18,7 @@ FLAG_GENERIC = 2
 FLAG_PROFILE = 4
 FLAG_KEEP_FACT = 8
 FLAG_KEEP_RECORDS = 16
+SOLN_LAMBDA, SOLN_STATE, SOLN_INPUT = 1, 2, 4
 
 ERR_INVALID = -1
 ERR_NO_DEVICE = -2
@@ -223,6 +224,8 @@ def lib():
     proto("ndlqr_SolveBatchAsync", ci, vp)
     proto("ndlqr_BatchStepAsync", ci, vp, dp, dp, dp, dp, dp)
     proto("ndlqr_BatchSynchronizePrevious", ci, vp)
+    proto("ndlqr_BatchSetStepSelection", ci, vp, ci, ci, C.c_uint)
+    proto("ndlqr_CopyBatchSolutionSlices", ci, vp, ci, ci, C.c_uint, dp)
     proto("ndlqr_HostAlloc", vp, C.c_size_t)
     proto("ndlqr_HostFree", None, vp)
     proto("ndlqr_BatchSynchronize", ci, vp)
@@ -302,13 +305,16 @@ class BatchSolver:
             raise RuntimeError("ndlqr_NewBatchSolver failed: %s" %
                                self.L.ndlqr_hip_last_error().decode())
         self.nvars = self.L.ndlqr_BatchNumVars(self.h)
+        self._sel = None          # (knot0, nknots, blocks) of set_step_selection
+        self._step_refs = []      # host arrays of the steps in flight (kept alive until they are synchronised)
         if flags:
             self.set_flags(flags)
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.ndlqr_FreeBatchSolver(self.h)
+            self.L.ndlqr_FreeBatchSolver(self.h)  # (waits for everything in flight)
             self.h = None
+        self._step_refs = []
 
     __del__ = close
 
@@ -361,22 +367,50 @@ class BatchSolver:
     def solve_async(self):
         return self.L.ndlqr_SolveBatchAsync(self.h)
 
+    def slice_width(self, blocks):
+        return (self.n if blocks & SOLN_LAMBDA else 0) + (self.n if blocks & SOLN_STATE else 0) + \
+               (self.m if blocks & SOLN_INPUT else 0)
+
+    def set_step_selection(self, knot0=0, nknots=0, blocks=7):
+        """ndlqr_BatchSetStepSelection: what step_async brings down -- knots [knot0, knot0 + nknots), blocks = SOLN_*
+        mask, packed [batch, nknots, width]; nknots = 0: every solution [batch, nvars] (default)."""
+        err = self.L.ndlqr_BatchSetStepSelection(self.h, knot0, nknots, blocks)
+        if err:
+            raise ValueError("ndlqr_BatchSetStepSelection(%d, %d, %d): %d" % (knot0, nknots, blocks, err))
+        self._sel = (knot0, nknots, blocks) if nknots else None
+
+    def solution_slices(self, knot0, nknots, blocks, out=None):
+        """ndlqr_CopyBatchSolutionSlices: [batch, nknots, width] of the latest solve."""
+        if out is None:
+            out = np.zeros((self.batch, nknots, self.slice_width(blocks)))
+        assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.size == self.batch * nknots * self.slice_width(blocks)
+        err = self.L.ndlqr_CopyBatchSolutionSlices(self.h, knot0, nknots, blocks, _ptr(out))
+        if err:
+            raise RuntimeError("ndlqr_CopyBatchSolutionSlices failed: %d" % err)
+        return out
+
     def step_async(self, q, r, d, x0, soln):
-        """ndlqr_BatchStepAsync: new right-hand side up, factor + solve, solutions down into `soln` ([batch, nvars]),
-        asynchronously. The arrays must stay alive and untouched until the step has been synchronised (use
-        pinned_empty() arrays; pageable ones make the call block)."""
+        """ndlqr_BatchStepAsync: new right-hand side up, factor + solve, solutions down into `soln` ([batch, nvars], or
+        the slice chosen with set_step_selection), asynchronously. Use pinned_empty() arrays (pageable ones make the
+        call block) and leave them untouched until the step has been synchronised; the solver holds references to the
+        arrays of the two steps that can be in flight, so that dropping one early does not free pinned memory the GPU
+        is still reading or writing."""
         n, m, N, bt = self.n, self.m, self.N, self.batch
-        for a, size in ((q, bt * N * n), (r, bt * N * m), (d, bt * N * n), (x0, bt * n), (soln, bt * self.nvars)):
+        out_size = bt * self.nvars if self._sel is None else bt * self._sel[1] * self.slice_width(self._sel[2])
+        for a, size in ((q, bt * N * n), (r, bt * N * m), (d, bt * N * n), (x0, bt * n), (soln, out_size)):
             assert a is None or (a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.size == size)
         assert x0 is not None and soln is not None  # q, r, d may be None: unchanged
         ptr = lambda a: None if a is None else _ptr(a)
+        self._step_refs = self._step_refs[-1:] + [(q, r, d, x0, soln)]
         return self.L.ndlqr_BatchStepAsync(self.h, ptr(q), ptr(r), ptr(d), ptr(x0), ptr(soln))
 
     def synchronize_previous(self):
         return self.L.ndlqr_BatchSynchronizePrevious(self.h)
 
     def synchronize(self):
-        return self.L.ndlqr_BatchSynchronize(self.h)
+        err = self.L.ndlqr_BatchSynchronize(self.h)
+        self._step_refs = []
+        return err
 
     def solve_ms(self):
         return self.L.ndlqr_BatchSolveTimeMs(self.h)

@@ -300,6 +300,12 @@ int ndlqr_BatchStepAsync(NdLqrBatchSolver* bs, const double* q, const double* r,
 int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs) {
   return bs ? ndlqr_hip_synchronize_previous(bs->ctx) : NDLQR_ERR_INVALID;
 }
+int ndlqr_BatchSetStepSelection(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks) {
+  return bs ? ndlqr_hip_set_step_selection(bs->ctx, knot0, nknots, blocks) : NDLQR_ERR_INVALID;
+}
+int ndlqr_CopyBatchSolutionSlices(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out) {
+  return bs ? ndlqr_hip_download_selection(bs->ctx, knot0, nknots, blocks, out) : NDLQR_ERR_INVALID;
+}
 void* ndlqr_HostAlloc(size_t bytes) { return ndlqr_hip_host_alloc(bytes); }
 void ndlqr_HostFree(void* p) { ndlqr_hip_host_free(p); }
 

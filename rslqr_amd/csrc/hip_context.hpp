@@ -106,6 +106,16 @@ struct NdlqrHipCtx {
   hipEvent_t ev_step[2];  // end of the steps of ndlqr_hip_step_async, alternating (ndlqr_hip_synchronize_previous)
   unsigned step_count;
   hipEvent_t ev_inputs;  // orders the other buffer set's stream behind a device-side replacement of the inputs
+  // One LOGICAL right-hand side, two physical copies (one per buffer set): generation counters per part -- 0: q,
+  // 1: r, 2: d, 3: x0 -- of the latest write and of each set's copy ([0] primary set, [1] alternate). Whoever writes
+  // (uploads, device packing, an MPC step) writes the CURRENT set and bumps its generations; a solve or step that
+  // lands on a set whose copy is behind in a part it does not replace copies that part over first (rhs_make_current).
+  unsigned long long rhs_latest[4];
+  unsigned long long rhs_gen[2][4];
+  // what an MPC step brings down (ndlqr_hip_set_step_selection): sel_nknots == 0: every solution, [batch][nvars]
+  int sel_knot0, sel_nknots;
+  unsigned sel_blocks;
+  int step_set[2];   // buffer set (0 primary, 1 alternate) of the steps behind ev_step[0 / 1]
   bool timing_pending;
   double last_ms;
   int last_failures;

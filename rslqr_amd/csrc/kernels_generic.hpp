@@ -441,6 +441,40 @@ static __global__ void pack_solutions_generic(Dims du, Dims d, const double* __r
         z[((size_t)b * d.N + k) * d.rows + (e < n ? e : (e < 2 * n ? d.n + (e - n) : 2 * d.n + (e - 2 * n)))];
 }
 
+// A slice of the solutions, packed for the host: knots [knot0, knot0 + nknots) of every problem, of each knot the
+// blocks selected by `blocks` (bit 0: lambda, 1: state, 2: input), in the reference's order -> [batch][nknots][width],
+// width = n * (bits 0, 1) + m * (bit 2). What an MPC loop consumes of a solve is u of knot 0 (32 KB per 1024
+// problems of (12,4) against 59 MB for every lambda, x, u). The input slot of the last knot is not part of the
+// solution (src/solver.c:64): it comes out as stored (zero). grid (nknots, batch).
+static __global__ void pack_selection_generic(Dims du, Dims d, const int knot0, const int nknots, const unsigned blocks,
+                                              const double* __restrict__ z, double* __restrict__ dst) {
+  const int kk = blockIdx.x, b = blockIdx.y, n = du.n, m = du.m;
+  const int nl = (blocks & 1u) ? n : 0, nxs = (blocks & 2u) ? n : 0, nu = (blocks & 4u) ? m : 0;
+  const int width = nl + nxs + nu;
+  const double* zk = z + ((size_t)b * d.N + knot0 + kk) * d.rows;
+  double* out = dst + ((size_t)b * nknots + kk) * width;
+  for (int e = threadIdx.x; e < width; e += blockDim.x) {
+    int src;
+    if (e < nl) src = e;
+    else if (e < nl + nxs) src = d.n + (e - nl);
+    else src = 2 * d.n + (e - nl - nxs);
+    out[e] = zk[src];
+  }
+}
+
+// The right-hand side exists once per buffer set of the solve pipeline (ndlqr_hip_step_async replaces it per step):
+// copies the parts of `mask` -- bit 0: q (state rows), 1: r (input rows), 2: d (lambda rows of the knots >= 1),
+// 3: x0 (lambda rows of knot 0) -- from one set's copy to the other's. grid (N, batch).
+static __global__ void copy_rhs_parts_generic(Dims d, const unsigned mask, const double* __restrict__ src,
+                                              double* __restrict__ dst) {
+  const int k = blockIdx.x;
+  const size_t base = ((size_t)blockIdx.y * d.N + k) * d.rows;
+  for (int e = threadIdx.x; e < d.rows; e += blockDim.x) {
+    const unsigned bit = e < d.n ? (k == 0 ? 8u : 4u) : (e < 2 * d.n ? 1u : 2u);
+    if (mask & bit) dst[base + e] = src[base + e];
+  }
+}
+
 // ------------------------------------------------------------------------------------- rhs-only sweep
 // Factor / solve split (the reference cannot separate them, docs/rslqr_usage.dox):
 // with the complete factor array kept on the device (NDLQR_FLAG_KEEP_FACT) a new right-hand side

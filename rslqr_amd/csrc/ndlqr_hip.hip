@@ -51,6 +51,10 @@ static size_t bytes_rec(const ndlqr::Dims& d) { return sizeof(double) * (size_t)
 static size_t bytes_F(const ndlqr::Dims& d) { return sizeof(double) * (size_t)d.batch * d.K * d.N * d.fb; }
 
 NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch, int device) {
+  return ndlqr_hip_create_ex(nstates, ninputs, nhorizon, batch, device, 0u);
+}
+
+NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int batch, int device, unsigned create_flags) {
   if (nstates <= 0 || ninputs <= 0 || batch <= 0 || nhorizon < 2 || (nhorizon & (nhorizon - 1))) {
     g_last_error = "invalid dimensions";
     return nullptr;
@@ -88,7 +92,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   // real variables see the same arithmetic plus exact zeros) instead of the runtime-sized kernels, which are 3-4x
   // slower below 16 states. NDLQR_NO_PAD=1 keeps the caller's block size (A/B, tests).
   int pn = nstates, pm = ninputs;
-  if (!has_small_instance(nstates, ninputs) && nhorizon >= 8 && !getenv("NDLQR_NO_PAD"))
+  if (!has_small_instance(nstates, ninputs) && nhorizon >= 8 && !getenv("NDLQR_NO_PAD") &&
+      !(create_flags & NDLQR_CREATE_NO_PAD))
     pick_pad_instance(nstates, ninputs, &pn, &pm);
   set_dims(d, pn, pm);
   c->padded = pn != nstates || pm != ninputs;
@@ -106,6 +111,8 @@ NdlqrHipCtx* ndlqr_hip_create(int nstates, int ninputs, int nhorizon, int batch,
   c->no_top = getenv("NDLQR_NO_TOP") != nullptr;
   c->sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS")) : 0;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
+  memset(c->rhs_latest, 0, sizeof(c->rhs_latest)); memset(c->rhs_gen, 0, sizeof(c->rhs_gen));
+  c->sel_knot0 = 0; c->sel_nknots = 0; c->sel_blocks = 7u; c->step_set[0] = c->step_set[1] = 0;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
@@ -222,7 +229,7 @@ static bool ensure_alt(NdlqrHipCtx* c) {
             hipMalloc(&a.rhs, bytes_z(d)) == hipSuccess &&
             hipHostMalloc((void**)&a.h_fail, sizeof(int), hipHostMallocDefault) == hipSuccess;
   // this set's own copy of the right-hand side (a step of ndlqr_hip_step_async replaces the right-hand side of
-  // ITS buffer set only; whatever replaces the inputs of the context writes both copies: mirror_rhs)
+  // ITS buffer set only; rhs_gen / rhs_make_current keep track of which copy is behind in what)
   ok = ok && hipStreamSynchronize(c->stream) == hipSuccess &&
        hipMemcpyAsync(a.rhs, c->rhs, bytes_z(d), hipMemcpyDeviceToDevice, a.stream) == hipSuccess;
   if (ok && c->tree_cnt)  // size-specialised shapes (the runtime-sized schedule's slots: ensure_red_generic)
@@ -239,6 +246,10 @@ static bool ensure_alt(NdlqrHipCtx* c) {
   }
   *a.h_fail = *c->h_fail;
   a.ready = true;
+  {  // (the new set's copy of the right-hand side was taken from the current one)
+    const int cur = c->in_alt ? 1 : 0;
+    for (int p = 0; p < 4; ++p) c->rhs_gen[1 - cur][p] = c->rhs_gen[cur][p];
+  }
   return true;
 }
 
@@ -249,15 +260,20 @@ static hipError_t sync_all(NdlqrHipCtx* c) {
   return e;
 }
 
+static int rhs_make_current(NdlqrHipCtx* c, unsigned need);  // below
+
 int ndlqr_hip_set_pipeline_depth(NdlqrHipCtx* c, int depth) {
   if (!c || depth < 1) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
   if (c->in_alt) {  // keep the latest solution where the single-slot code expects it
     swap_slot(c);
+    {  // (the right-hand side the latest solution belongs to: after ndlqr_hip_step_async the two sets may differ)
+      const int merr = rhs_make_current(c, 0xFu);
+      if (merr) return merr;
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     if (c->alt.z && c->z_latest == c->alt.z) {
-      // (and the right-hand side it belongs to: after ndlqr_hip_step_async the two sets hold different ones)
-      HIP_TRY(hipMemcpy(c->rhs, c->alt.rhs, bytes_z(c->d), hipMemcpyDeviceToDevice));
       HIP_TRY(hipMemcpy(c->z, c->alt.z, bytes_z(c->d), hipMemcpyDeviceToDevice));
       HIP_TRY(hipDeviceSynchronize());  // (a device-to-device copy on the null stream need not be finished on return;
                                         //  the solver's streams do not wait for the null stream)
@@ -317,12 +333,32 @@ int ndlqr_hip_set_stream(NdlqrHipCtx* c, void* hip_stream) {
 }
 void* ndlqr_hip_get_stream(NdlqrHipCtx* c) { return c ? (void*)c->stream : nullptr; }
 
-// The right-hand side exists once per buffer set of the pipeline: after `count` doubles at `offset` of the current
-// set's copy have been (re)written on the current stream, the other set's copy follows (same stream: the caller
-// synchronises it or orders the other stream behind it with other_stream_waits).
-static hipError_t mirror_rhs(NdlqrHipCtx* c, size_t offset, size_t count) {
-  if (!c->alt.rhs) return hipSuccess;
-  return hipMemcpyAsync(c->alt.rhs + offset, c->rhs + offset, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream);
+// The right-hand side exists once per buffer set of the pipeline (hip_context.hpp: rhs_latest / rhs_gen).
+// rhs_written_cur: the parts of `mask` of the CURRENT set's copy have just been (re)written.
+static void rhs_written_cur(NdlqrHipCtx* c, unsigned mask) {
+  const int cur = c->in_alt ? 1 : 0;
+  for (int p = 0; p < 4; ++p)
+    if (mask & (1u << p)) c->rhs_gen[cur][p] = ++c->rhs_latest[p];
+}
+// rhs_make_current: the current set's copy is brought up to date in the parts of `need` before a solve reads it. Only a
+// change of flow gets here with something to do (full MPC steps followed by x0-only steps, a plain solve behind steps,
+// the first solve on the other set after an upload): everything in flight is waited for, the stale parts are copied
+// from the other set on this set's stream, and the other set's stream waits for that copy before it may rewrite its own.
+static int rhs_make_current(NdlqrHipCtx* c, unsigned need) {
+  const int cur = c->in_alt ? 1 : 0;
+  unsigned stale = 0;
+  for (int p = 0; p < 4; ++p)
+    if ((need & (1u << p)) && c->rhs_gen[cur][p] < c->rhs_latest[p]) stale |= 1u << p;
+  if (!stale || !c->alt.rhs) return NDLQR_OK;
+  HIP_TRY(sync_all(c));
+  hipLaunchKernelGGL(ndlqr::copy_rhs_parts_generic, dim3(c->d.N, c->d.batch), dim3(64), 0, c->stream, c->d, stale,
+                     (const double*)c->alt.rhs, c->rhs);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_inputs, c->stream));
+  if (c->alt.stream) HIP_TRY(hipStreamWaitEvent(c->alt.stream, c->ev_inputs, 0));
+  for (int p = 0; p < 4; ++p)
+    if (stale & (1u << p)) c->rhs_gen[cur][p] = c->rhs_latest[p];
+  return NDLQR_OK;
 }
 
 // the other buffer set's stream waits for everything enqueued on the current one so far
@@ -347,6 +383,10 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
+  {  // (a partial upload lands on a complete, current copy: the other set then takes the whole of it on its next use)
+    const int merr = rhs_make_current(c, 0xFu);
+    if (merr) return merr;
+  }
   if (c->padded) {  // the caller's layout goes to a staging array in HBM, a kernel files it into the padded arrays
     const ndlqr::Dims& u = c->du;
     const size_t uAB = (size_t)u.N * u.n * u.w * count, uQR = (size_t)u.N * u.w * count, uz = (size_t)u.N * u.rows * count;
@@ -359,9 +399,8 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
     hipLaunchKernelGGL(ndlqr::pad_inputs_generic, dim3(d.N, count), dim3(128), 0, c->stream, u, d, p0, s0, s0 + uAB,
                        s0 + uAB + uQR, c->AB, c->QR, c->rhs);
     HIP_TRY(hipGetLastError());
-    const size_t sz = (size_t)d.N * d.rows;
-    HIP_TRY(mirror_rhs(c, p0 * sz, sz * count));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    rhs_written_cur(c, 0xFu);
     c->fact_valid = false;
     c->rec_complete = false;
     return NDLQR_OK;
@@ -370,8 +409,8 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   HIP_TRY(hipMemcpyAsync(c->AB + p0 * sAB, AB, sizeof(double) * sAB * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->QR + p0 * sQR, QR, sizeof(double) * sQR * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(mirror_rhs(c, p0 * sz, sz * count));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host staging buffers are reused by the caller
+  rhs_written_cur(c, 0xFu);
   c->fact_valid = false;  // new A, B, Q, R: a cached factorisation no longer matches the inputs
   c->rec_complete = false;
   return NDLQR_OK;
@@ -386,7 +425,7 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q, R,
                      q, r, d, x0, c->AB, c->QR, c->rhs);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(mirror_rhs(c, 0, (size_t)c->d.batch * c->d.N * c->d.rows));
+  rhs_written_cur(c, 0xFu);        // (the whole batch: nothing of the older copies is needed any more)
   HIP_TRY(other_stream_waits(c));  // the next solve may run on the other buffer set's stream
   c->fact_valid = false;  // new A, B, Q, R: neither a cached factor array nor cached records match
   c->rec_complete = false;
@@ -842,6 +881,8 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   int err = prepare_solve(c, nullptr);
   if (err) return err;
+  err = rhs_make_current(c, 0xFu);  // (this buffer set's copy of the right-hand side may be behind: steps write one set)
+  if (err) return err;
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   err = launch_solve(c);
   if (err) return err;
@@ -878,6 +919,10 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   if (err) return err;
   err = ensure_xfer(c);  // (before anything is captured: allocation is not a stream operation)
   if (err) return err;
+  // the parts of the right-hand side this step does not replace: this buffer set's copy of them may be behind the other's
+  const unsigned written = (q ? 1u : 0u) | (r ? 2u : 0u) | (dd ? 4u : 0u) | 8u;
+  err = rhs_make_current(c, ~written & 0xFu);
+  if (err) return err;
   // Everything of this step is ordered on the stream of its buffer set. Right-hand side: a streaming kernel reads
   // pinned host arrays over the host link directly; pageable ones go through the staging first (the runtime stages
   // those copies itself and blocks). Solutions: pack kernel, then ONE copy-engine transfer. With the two-deep
@@ -902,15 +947,26 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   hipLaunchKernelGGL(ndlqr::pack_rhs_stream_generic, dim3(512), dim3(256), 0, st, u, d, view[0], view[1], view[2],
                      view[3], c->rhs);
   HIP_TRY(hipGetLastError());
+  rhs_written_cur(c, written);
   err = launch_solve(c);
   if (err) return err;
-  // (the staging has been consumed by the pack kernel: it now takes the packed solutions)
-  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, u, d, c->z, c->xfer);
-  HIP_TRY(hipGetLastError());
-  const size_t nvars = (size_t)u.rows * u.N - u.m;
-  HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * nvars * d.batch, hipMemcpyDeviceToHost, st));
+  // (the staging has been consumed by the pack kernel: it now takes the packed solutions -- all of them, or the slice
+  //  chosen with ndlqr_hip_set_step_selection)
+  if (c->sel_nknots > 0) {
+    const size_t width = ((c->sel_blocks & 1u) ? u.n : 0) + ((c->sel_blocks & 2u) ? u.n : 0) + ((c->sel_blocks & 4u) ? u.m : 0);
+    hipLaunchKernelGGL(ndlqr::pack_selection_generic, dim3(c->sel_nknots, d.batch), dim3(64), 0, st, u, d, c->sel_knot0,
+                       c->sel_nknots, c->sel_blocks, (const double*)c->z, c->xfer);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * width * c->sel_nknots * d.batch, hipMemcpyDeviceToHost, st));
+  } else {
+    hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, u, d, c->z, c->xfer);
+    HIP_TRY(hipGetLastError());
+    const size_t nvars = (size_t)u.rows * u.N - u.m;
+    HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * nvars * d.batch, hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(hipEventRecord(c->ev_stop, st));
   HIP_TRY(hipEventRecord(c->ev_step[c->step_count & 1u], st));
+  c->step_set[c->step_count & 1u] = c->in_alt ? 1 : 0;
   ++c->step_count;
   c->timing_pending = true;
   c->state_dirty = false;
@@ -921,7 +977,49 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
 int ndlqr_hip_synchronize_previous(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
-  if (c->step_count >= 2) HIP_TRY(hipEventSynchronize(c->ev_step[c->step_count & 1u]));  // step_count - 2
+  if (c->step_count < 2) return NDLQR_OK;
+  const unsigned slot = c->step_count & 1u;  // the step before the most recent one: step_count - 2
+  HIP_TRY(hipEventSynchronize(c->ev_step[slot]));
+  // The failure word of that step's buffer set holds the cumulative count of non-positive pivots as of the end of its
+  // solve: anything beyond what has been reported so far belongs to it (or to a step before it).
+  const bool cur_is_alt = c->in_alt;
+  const int* word = (c->step_set[slot] == (cur_is_alt ? 1 : 0)) ? c->h_fail : c->alt.h_fail;
+  if (word && *word > c->fail_base) {
+    c->last_failures = *word - c->fail_base;
+    c->fail_base = *word;
+    return NDLQR_ERR_NOT_SPD;
+  }
+  return NDLQR_OK;
+}
+
+// What a step of ndlqr_hip_step_async brings down: knots [knot0, knot0 + nknots) of every problem, of each knot the
+// blocks of `blocks` (NDLQR_SOLN_LAMBDA | NDLQR_SOLN_STATE | NDLQR_SOLN_INPUT), packed [batch][nknots][width].
+// nknots == 0: every solution, [batch][nvars] (the default). The reference hands back the whole vector
+// (src/solve.c:192-201); an MPC loop consumes u of knot 0.
+int ndlqr_hip_set_step_selection(NdlqrHipCtx* c, int knot0, int nknots, unsigned blocks) {
+  if (!c) return NDLQR_ERR_INVALID;
+  if (nknots == 0) { c->sel_knot0 = 0; c->sel_nknots = 0; c->sel_blocks = 7u; return NDLQR_OK; }
+  if (knot0 < 0 || nknots < 0 || knot0 + nknots > c->d.N || !(blocks & 7u) || (blocks & ~7u)) return NDLQR_ERR_INVALID;
+  c->sel_knot0 = knot0; c->sel_nknots = nknots; c->sel_blocks = blocks;
+  return NDLQR_OK;
+}
+
+// the same slice of the most recent solve, synchronously: out = [batch][nknots][width] doubles
+int ndlqr_hip_download_selection(NdlqrHipCtx* c, int knot0, int nknots, unsigned blocks, double* out) {
+  if (!c || !out || knot0 < 0 || nknots <= 0 || knot0 + nknots > c->d.N || !(blocks & 7u) || (blocks & ~7u))
+    return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  const ndlqr::Dims& u = c->du;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));
+  const int xerr = ensure_xfer(c);
+  if (xerr) return xerr;
+  const size_t width = ((blocks & 1u) ? u.n : 0) + ((blocks & 2u) ? u.n : 0) + ((blocks & 4u) ? u.m : 0);
+  hipLaunchKernelGGL(ndlqr::pack_selection_generic, dim3(nknots, d.batch), dim3(64), 0, c->stream, u, d, knot0, nknots,
+                     blocks, c->z_latest ? c->z_latest : (const double*)c->z, c->xfer);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, c->xfer, sizeof(double) * width * nknots * d.batch, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return NDLQR_OK;
 }
 
@@ -942,6 +1040,10 @@ int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
+  {
+    const int merr = rhs_make_current(c, 0xFu);
+    if (merr) return merr;
+  }
   const size_t sz = (size_t)d.N * d.rows;
   if (c->padded) {
     const size_t uz = (size_t)c->du.N * c->du.rows * count;
@@ -954,8 +1056,8 @@ int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
   } else {
     HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
   }
-  HIP_TRY(mirror_rhs(c, p0 * sz, sz * count));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  rhs_written_cur(c, 0xFu);
   return NDLQR_OK;
 }
 
@@ -1009,6 +1111,10 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
   if (c->in_alt) swap_slot(c);  // cached records / factors live in the primary set
+  {
+    const int merr = rhs_make_current(c, 0xFu);
+    if (merr) return merr;
+  }
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
   if (!try_launch_rhs_records(c)) {
     if (!c->fact_valid) {  // records only, but this shape / horizon has no record-based re-solve
@@ -1238,6 +1344,7 @@ struct DenseScratch {
   double* host = nullptr;
   size_t cap = 0;  // doubles
   hipStream_t stream = nullptr;
+  int device = -1;  // the device its stream and buffer live on: leased only to calls whose current device is this one
 };
 std::mutex g_dense_mu;
 std::vector<DenseScratch*> g_dense_pool;  // idle scratches; never freed (bounded by the peak concurrency)
@@ -1245,9 +1352,17 @@ std::vector<DenseScratch*> g_dense_pool;  // idle scratches; never freed (bounde
 struct DenseLease {
   DenseScratch* s = nullptr;
   DenseLease() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     std::lock_guard<std::mutex> lock(g_dense_mu);
-    if (!g_dense_pool.empty()) { s = g_dense_pool.back(); g_dense_pool.pop_back(); }
-    else s = new DenseScratch();
+    for (size_t i = g_dense_pool.size(); i-- > 0;)
+      if (g_dense_pool[i]->device == dev) {
+        s = g_dense_pool[i];
+        g_dense_pool.erase(g_dense_pool.begin() + (long)i);
+        return;
+      }
+    s = new DenseScratch();
+    s->device = dev;
   }
   ~DenseLease() {
     std::lock_guard<std::mutex> lock(g_dense_mu);

@@ -798,6 +798,106 @@ def test_step_async_transfers_and_solves(ndlqr, oracle, n, m, N, batch, flags):
     bs.close()
 
 
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 64, 300), (6, 3, 32, 5), (7, 9, 16, 3), (20, 6, 16, 40)])
+def test_step_flows_mix_freely(ndlqr, oracle, n, m, N, batch):
+    """There is ONE logical right-hand side; the two buffer sets of the pipeline each hold a copy and a step writes its
+    own set only. Full steps with a different q, r, d each, then x0-only steps, then a plain solve: every result is the
+    oracle's solve with the most recently written parts (round 3 solved set B's x0-only step against the q, r, d of
+    the full step before the last)."""
+    gens = [ndlqr.generate_synthetic(n, m, N, 900 + p) for p in range(batch)]
+    flat = {k: np.stack([g[k] for g in gens]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")}
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*[flat[k] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    rng = np.random.default_rng(3)
+    pin = lambda a: (lambda b: (b.__setitem__(Ellipsis, a), b)[1])(ndlqr.pinned_empty(a.shape))
+    outs = [ndlqr.pinned_empty((batch, bs.nvars)) for _ in range(8)]
+    cur = {k: flat[k] for k in ("q", "r", "d", "x0")}
+    want = []
+
+    def check(out, parts, label):
+        for p in sorted({0, batch - 1}):
+            prob = Problem(n, m, N, flat["A"][p], flat["B"][p], flat["Q"][p], flat["R"][p], parts["q"][p],
+                           parts["r"][p], parts["d"][p], parts["x0"][p])
+            ref = oracle.solve(prob, 1)[0][: prob.nvars]
+            assert np.linalg.norm(out[p] - ref) / np.linalg.norm(ref) <= REL_TOL, (label, p)
+
+    step = 0
+    for s in range(3):  # three full steps (sets A, B, A), each with its own q, r, d, x0
+        cur = {k: pin(flat[k] + 0.3 * (s + 1) * rng.standard_normal(flat[k].shape)) for k in ("q", "r", "d", "x0")}
+        assert bs.step_async(cur["q"], cur["r"], cur["d"], cur["x0"], outs[step]) == 0
+        want.append((outs[step], dict(cur), "full %d" % s)); step += 1
+    for s in range(3):  # x0-only steps: set B first, whose q, r, d are those of the full step before the last
+        cur = dict(cur); cur["x0"] = pin(flat["x0"] + 2.0 + s)
+        assert bs.step_async(None, None, None, cur["x0"], outs[step]) == 0
+        want.append((outs[step], dict(cur), "x0-only %d" % s)); step += 1
+    cur = dict(cur); cur["d"] = pin(flat["d"] * 0.5); cur["x0"] = pin(flat["x0"] - 1.0)  # d and x0 alone
+    assert bs.step_async(None, None, cur["d"], cur["x0"], outs[step]) == 0
+    want.append((outs[step], dict(cur), "d + x0")); step += 1
+    assert bs.synchronize() == 0
+    for out, parts, label in want:
+        check(out, parts, label)
+    # plain solves behind the steps (either buffer set) see the latest right-hand side
+    for _ in range(2):
+        assert bs.solve() == 0
+        check(bs.solutions(), cur, "plain solve")
+        res, bn = bs.kkt_residuals()
+        assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    # an upload of the right-hand side of SOME problems lands on the complete latest copy
+    bs.close()
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 64, 40), (6, 3, 32, 5), (7, 9, 16, 3), (20, 6, 16, 4)])
+def test_step_selection_and_slices(ndlqr, oracle, n, m, N, batch):
+    """ndlqr_BatchSetStepSelection / ndlqr_CopyBatchSolutionSlices: the slice a step brings down is that slice of the
+    full solution vector (src/solve.c:192-201 hands back all of it) -- u of knot 0, x and u of the first knots, every
+    block of a knot range in the middle."""
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_synthetic(77)
+    assert bs.solve() == 0
+    full = bs.solutions()
+    zb = 2 * n + m
+    padded = np.zeros((batch, N * zb)); padded[:, : bs.nvars] = full
+    Z = padded.reshape(batch, N, zb)
+
+    def expect(k0, nk, blocks):
+        cols = ([*range(0, n)] if blocks & ndlqr.SOLN_LAMBDA else []) + ([*range(n, 2 * n)] if blocks & ndlqr.SOLN_STATE else []) + \
+               ([*range(2 * n, zb)] if blocks & ndlqr.SOLN_INPUT else [])
+        return Z[:, k0:k0 + nk, :][:, :, cols]
+
+    cases = [(0, 1, ndlqr.SOLN_INPUT), (0, min(4, N), ndlqr.SOLN_STATE | ndlqr.SOLN_INPUT), (N // 2, N // 2, 7), (N - 1, 1, 3)]
+    for k0, nk, blocks in cases:
+        assert np.array_equal(bs.solution_slices(k0, nk, blocks), expect(k0, nk, blocks)), (k0, nk, blocks)
+    with pytest.raises(ValueError):
+        bs.set_step_selection(N - 1, 2, 7)
+    with pytest.raises(ValueError):
+        bs.set_step_selection(0, 1, 0)
+    # steps that bring down the slice alone, two in flight, x0 replaced per step
+    g = [ndlqr.generate_synthetic(n, m, N, 77 + p) for p in range(batch)]
+    x0 = np.stack([gg["x0"] for gg in g])
+    for k0, nk, blocks in cases[:2]:
+        bs.set_step_selection(k0, nk, blocks)
+        xs = [ndlqr.pinned_empty(x0.shape) for _ in range(3)]
+        outs = [ndlqr.pinned_empty((batch, nk, bs.slice_width(blocks))) for _ in range(3)]
+        for s in range(3):
+            xs[s][...] = x0 * (1.0 + s)
+            assert bs.step_async(None, None, None, xs[s], outs[s]) == 0
+        assert bs.synchronize() == 0
+        for s in range(3):
+            p = batch - 1
+            prob = Problem(n, m, N, g[p]["A"], g[p]["B"], g[p]["Q"], g[p]["R"], g[p]["q"], g[p]["r"], g[p]["d"], xs[s][p])
+            ref = np.zeros(N * zb); ref[: prob.nvars] = oracle.solve(prob, 1)[0][: prob.nvars]
+            cols = ([*range(n, 2 * n)] if blocks & 2 else []) + ([*range(2 * n, zb)] if blocks & 4 else [])
+            want = ref.reshape(N, zb)[k0:k0 + nk][:, cols]
+            assert np.linalg.norm(outs[s][p] - want) <= REL_TOL * max(1.0, np.linalg.norm(ref)), (s, blocks)
+        assert np.array_equal(outs[2], bs.solution_slices(k0, nk, blocks))
+    bs.set_step_selection()  # back to everything
+    out = ndlqr.pinned_empty((batch, bs.nvars))
+    x = ndlqr.pinned_empty(x0.shape); x[...] = x0
+    assert bs.step_async(None, None, None, x, out) == 0 and bs.synchronize() == 0
+    assert np.linalg.norm(out - full) <= 1e-12 * np.linalg.norm(full)
+    bs.close()
+
+
 def test_large_download_through_bounce_buffers(ndlqr):
     """ndlqr_CopyBatchSolutions into pageable memory goes through two pinned 8 MB bounce buffers in chunks: a
     download larger than several chunks equals the pinned (single-copy) one and the per-problem one."""
