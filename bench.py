@@ -468,6 +468,64 @@ def config_leg(rslqr_amd, n, m, N, batch, device, steps, seed0=1, json_path=None
         bs.close()
 
 
+def dropin_leg(rslqr_amd, json_path, reps=200, with_reference=True):
+    """The reference's own call sequence on one of its JSON fixtures, per call, host clock (what a caller of the drop-in
+    sees; src/solve.h:20-32, examples/importexample/main.c:5-27): ndlqr_InitializeWithLQRProblem + ndlqr_Solve +
+    ndlqr_CopySolution, steady state. `default`: the first solve of the solver is profiled, the timed ones replay one
+    captured graph (copies up, launch chain, copy down); `profiling_every_solve`: ndlqr_SetDeviceProfiling(solver, 1),
+    eager launches with an event pair per kernel (the reference's always-on profiler; round 3's default)."""
+    import ctypes as C
+    L = rslqr_amd.lib()
+    prob = L.ndlqr_ReadLQRProblemJSONFile(json_path.encode())
+    if not prob:
+        return {"error": "cannot read " + json_path}
+    n = prob.contents.lqrdata[0].contents.nstates
+    m = prob.contents.lqrdata[0].contents.ninputs
+    N = prob.contents.nhorizon
+    soln = np.asarray(json.load(open(json_path))["soln"], dtype=np.float64).reshape(-1)
+    out = {"workload": "%s (%d,%d,%d) x 1, ndlqr_InitializeWithLQRProblem + ndlqr_Solve + ndlqr_CopySolution per call"
+                       % (os.path.basename(json_path), n, m, N), "reps": reps}
+    x = np.zeros(soln.size)
+    xp = x.ctypes.data_as(C.POINTER(C.c_double))
+    for mode, prof in (("default", None), ("profiling_every_solve", 1)):
+        solver = L.ndlqr_NewNdLqrSolver(n, m, N)
+        if prof is not None:
+            L.ndlqr_SetDeviceProfiling(solver, prof)
+        t = np.zeros((reps + 5, 3))
+        rc = 0
+        for i in range(reps + 5):
+            t0 = time.perf_counter()
+            rc |= L.ndlqr_InitializeWithLQRProblem(prob, solver)
+            t1 = time.perf_counter()
+            rc |= L.ndlqr_Solve(solver)
+            t2 = time.perf_counter()
+            L.ndlqr_CopySolution(solver, xp)
+            t[i] = (t1 - t0, t2 - t1, time.perf_counter() - t2)
+        t = np.sort(t[5:] * 1e3, axis=0)
+        med = t[len(t) // 2]
+        out[mode] = {"initialize_ms": float(med[0]), "solve_ms": float(med[1]), "copy_ms": float(med[2]),
+                     "call_sequence_ms": float(med.sum()), "solve_ms_min": float(t[0][1]),
+                     "device_ms": float(solver.contents.solve_time_ms), "rc": int(rc),
+                     "err_vs_fixture_soln_l2": float(np.linalg.norm(x - soln))}
+        L.ndlqr_FreeNdLqrSolver(solver)
+    L.ndlqr_FreeLQRProblem(prob)
+    if with_reference:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import support
+        if support.have_reference():
+            ref = support.Reference()
+            p, _ = support.load_json_problem(json_path)
+            flat = [np.ascontiguousarray(a[None]) for a in p.arrays()]
+            args = [a.ctypes.data_as(support.dp) for a in flat]
+            cores = host_cores()
+            refms = {}
+            for thr in sorted({1, min(4, cores), cores}):
+                ref.L.ref_bench(p.n, p.m, p.N, 1, 3, *args, thr)
+                refms["%d_threads" % thr] = ref.L.ref_bench(p.n, p.m, p.N, 1, 20, *args, thr) / 20
+            out["reference_ndlqr_Solve_ms"] = refms  # the reference's ndlqr_Solve alone (oracle/_ref), same host
+    return out
+
+
 def time_mode(rslqr_amd, n, m, N, batch, device, seed0, flags, steps, rhs_only=False):
     """ms per step of one more mode of the same workload (own solver, same synthetic problems)."""
     bs = rslqr_amd.BatchSolver(n, m, N, batch, device=device, flags=flags)
@@ -762,9 +820,15 @@ def main():
             bs.close()
             fixture = os.path.join(ROOT, "tests", "golden", "lqr_prob_256.json")
             result["configs"] = {}
+            log("configs legs: the drop-in call sequence on lqr_prob.json and lqr_prob_256.json")
+            result["configs"]["config1: lqr_prob.json (6,3,8) x 1, drop-in ndlqr_Solve"] = \
+                {"dropin": dropin_leg(rslqr_amd, os.path.join(ROOT, "tests", "golden", "lqr_prob.json"),
+                                      with_reference=not args.no_cpu)}
+            dropin2 = dropin_leg(rslqr_amd, fixture, with_reference=not args.no_cpu)
             log("configs leg: lqr_prob_256.json x 1")
             result["configs"]["config2: lqr_prob_256.json (6,3,256) x 1"] = \
                 config_leg(rslqr_amd, 6, 3, 256, 1, local_rank, 50, json_path=fixture)
+            result["configs"]["config2: lqr_prob_256.json (6,3,256) x 1"]["dropin"] = dropin2
             log("configs leg: (12,4,1024) x 512")
             result["configs"]["config4 shard: (12,4,1024) x 512 (one GPU of the 8 x 512 = 4096 job)"] = \
                 config_leg(rslqr_amd, 12, 4, 1024, 512, local_rank, 20)

@@ -266,7 +266,9 @@ typedef struct {
   /* ---- appended (not in the reference) ---- */
   void* device_ctx;  /* opaque: batch-of-1 device solver */
   unsigned device_flags;     /* NDLQR_FLAG_* used by ndlqr_Solve (ndlqr_SetDeviceFlags; default 0) */
-  int device_profiling_off;  /* ndlqr_SetDeviceProfiling(solver, 0) */
+  int device_profiling;      /* ndlqr_SetDeviceProfiling: -1 (default) first solve only, 1 every solve, 0 never */
+  int device_profiled;       /* a profiled solve has filled the per-kernel buckets of `profile` */
+  NdLqrProfile device_split; /* ... which are kept here for the solves that replay the captured graph */
 } NdLqrSolver;
 
 NdLqrSolver* ndlqr_NewNdLqrSolver(int nstates, int ninputs, int nhorizon);
@@ -286,10 +288,11 @@ NdLqrProfile ndlqr_GetProfile(NdLqrSolver* solver);
 int ndlqr_Solve(NdLqrSolver* solver);
 Matrix ndlqr_GetSolution(NdLqrSolver* solver);
 int ndlqr_CopySolution(NdLqrSolver* solver, double* soln);
-/* additive: per-kernel HIP-event profiling of ndlqr_Solve (fills solver->profile like the
- * reference's always-on profiler; default on). Off: the launch sequence is replayed as a captured
- * hipGraph, which halves the latency of a single small solve; only t_total_ms / solve_time_ms are
- * filled then. */
+/* additive: per-kernel HIP-event profiling of ndlqr_Solve (fills the buckets of solver->profile like the
+ * reference's always-on profiler, src/solve.c:15-25,184-188). Default: the FIRST solve of a solver is profiled (eager
+ * launches, an event pair per kernel); every later one replays one captured hipGraph -- copies up, launch chain, copy
+ * down: a third of the wall time of a small solve -- and reports its own t_total_ms / solve_time_ms beside the
+ * per-kernel split of the last profiled solve. on = 1: profile every solve; on = 0: never (buckets stay 0). */
 int ndlqr_SetDeviceProfiling(NdLqrSolver* solver, int on);
 /* additive: NDLQR_FLAG_* bits ndlqr_Solve runs with (default 0 = fast mode, solution only; the same
  * launch sequence ndlqr_SolveBatch times). NDLQR_FLAG_STRICT_FP reproduces the reference's default

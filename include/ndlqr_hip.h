@@ -72,6 +72,14 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* ctx, void** out5);
  * context's stream; HIP events bracket the sequence. */
 int ndlqr_hip_solve_async(NdlqrHipCtx* ctx);
 int ndlqr_hip_synchronize(NdlqrHipCtx* ctx);
+/* One-shot solve from / into pinned host staging owned by the context -- what the drop-in ndlqr_Solve (host memory in,
+ * host memory out on every call, src/solve.c:38-201) runs: ndlqr_hip_staged_io hands out the staging (AB, QR, rhs in
+ * the packed layout above but in the CALLER's block size, z = [batch][N][2n+m] coming back), the caller packs into
+ * it, ndlqr_hip_solve_staged replays one captured graph -- the three copies up, the launch chain, the copy down --
+ * and waits for it: one launch and one synchronisation per call. Stream-ordered (pipeline depth 1 from the first
+ * call on). Returns like ndlqr_hip_synchronize; ndlqr_hip_cholesky_failures tells about pivots. */
+int ndlqr_hip_staged_io(NdlqrHipCtx* ctx, double** AB, double** QR, double** rhs, double** z);
+int ndlqr_hip_solve_staged(NdlqrHipCtx* ctx);
 /* Solve pipeline. Depth 2 (default; NDLQR_PIPELINE): consecutive ndlqr_hip_solve_async calls of one
  * context alternate between two sets of output buffers (records, accumulators, solution), each on its
  * own stream, so that a solve starts while the previous one is still in its thinly populated upper tree

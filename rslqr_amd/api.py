@@ -104,7 +104,8 @@ class NdLqrSolver(C.Structure):
                 ("cholfacts", C.POINTER(NdLqrCholeskyFactors)), ("solve_time_ms", C.c_double),
                 ("linalg_time_ms", C.c_double), ("profile", NdLqrProfile),
                 ("num_threads", C.c_int), ("device_ctx", C.c_void_p),
-                ("device_flags", C.c_uint), ("device_profiling_off", C.c_int)]
+                ("device_flags", C.c_uint), ("device_profiling", C.c_int), ("device_profiled", C.c_int),
+                ("device_split", NdLqrProfile)]
 
 
 _LIB = None

@@ -233,33 +233,6 @@ int ndlqr_InitializeBatchSynthetic(NdLqrBatchSolver* bs, uint64_t seed0) {
   return NDLQR_OK;
 }
 
-/* Single-problem path used by ndlqr_Solve: inputs come from the solver's host mirrors
- * (already in device row order: column j of the column-major A' block is row j of A). */
-int ndlqr_batch_upload_from_mirrors(NdLqrBatchSolver* bs, const NdData* data,
-                                    const Matrix* diagonals, const double* rhs) {
-  if (!bs || bs->batch != 1) return NDLQR_ERR_INVALID;
-  const int n = bs->n, m = bs->m, N = bs->N, w = n + m;
-  for (int k = 0; k < N; ++k) {
-    double* AB = bs->hAB + (size_t)k * n * w;
-    double* QR = bs->hQR + (size_t)k * w;
-    if (k < N - 1) {
-      int lvl = 0;
-      for (int t = k; t & 1; t >>= 1) ++lvl;
-      const NdFactor* C = data->factors + (k + N * lvl);
-      for (int i = 0; i < n; ++i) {
-        memcpy(AB + i * w, C->state.data + (size_t)n * i, sizeof(double) * n);
-        memcpy(AB + i * w + n, C->input.data + (size_t)m * i, sizeof(double) * m);
-      }
-    } else {
-      memset(AB, 0, sizeof(double) * n * w);
-    }
-    for (int i = 0; i < n; ++i) QR[i] = diagonals[2 * k].data[i + n * i];
-    for (int i = 0; i < m; ++i) QR[n + i] = (k < N - 1) ? diagonals[2 * k + 1].data[i + m * i] : 1.0;
-  }
-  memcpy(bs->hrhs, rhs, sizeof(double) * rhs_doubles(bs));
-  return flush(bs, 0, 1);
-}
-
 int ndlqr_BatchSetRhsFlat(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
                           const double* x0) {
   if (!bs || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;

@@ -116,6 +116,12 @@ struct NdlqrHipCtx {
   int sel_knot0, sel_nknots;
   unsigned sel_blocks;
   int step_set[2];   // buffer set (0 primary, 1 alternate) of the steps behind ev_step[0 / 1]
+  // One-shot solve of a small batch from / into pinned host staging (ndlqr_hip_solve_staged; the drop-in ndlqr_Solve):
+  // AB | QR | rhs going up, the solution blocks [batch][N][2n+m] coming down, all in the caller's block size; the whole
+  // sequence -- three copies up, the launch chain, the copy down -- is ONE captured graph.
+  double* h_io;            // pinned: AB | QR | rhs | z
+  hipGraphExec_t graph_staged;
+  unsigned graph_staged_flags;
   bool timing_pending;
   double last_ms;
   int last_failures;

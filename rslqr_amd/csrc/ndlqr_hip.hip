@@ -113,6 +113,7 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
   memset(c->rhs_latest, 0, sizeof(c->rhs_latest)); memset(c->rhs_gen, 0, sizeof(c->rhs_gen));
   c->sel_knot0 = 0; c->sel_nknots = 0; c->sel_blocks = 7u; c->step_set[0] = c->step_set[1] = 0;
+  c->h_io = nullptr; c->graph_staged = nullptr; c->graph_staged_flags = 0;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
@@ -164,6 +165,8 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   free_alt(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->graph_staged) (void)hipGraphExecDestroy(c->graph_staged);
+  if (c->h_io) (void)hipHostFree(c->h_io);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
@@ -372,6 +375,7 @@ static hipError_t other_stream_waits(NdlqrHipCtx* c) {
 static int ensure_pad_stage(NdlqrHipCtx* c, size_t doubles) {
   if (doubles <= c->pad_stage_cap) return NDLQR_OK;
   if (c->pad_stage) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->pad_stage); c->pad_stage = nullptr; c->pad_stage_cap = 0; }
+  if (c->graph_staged) { (void)hipGraphExecDestroy(c->graph_staged); c->graph_staged = nullptr; }  // (it holds the old address)
   HIP_TRY(hipMalloc(&c->pad_stage, sizeof(double) * doubles));
   c->pad_stage_cap = doubles;
   return NDLQR_OK;
@@ -890,6 +894,116 @@ int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   c->timing_pending = true;
   c->state_dirty = false;
   return NDLQR_OK;
+}
+
+// ------------------------------------------------------------------------------ one-shot solve from pinned staging
+// The drop-in ndlqr_Solve is a batch of one whose inputs come from the host and whose solution goes back to it on
+// every call (src/solve.c:38-201 works on host memory). Doing that with the batch functions costs three blocking
+// uploads, a launch, and a blocking download -- four host synchronisations around 40 us of kernels. Here the caller
+// packs straight into pinned staging (ndlqr_hip_staged_io), and ndlqr_hip_solve_staged replays ONE captured graph:
+// AB, QR, rhs up (copy nodes), the launch chain of the schedule, the solution blocks down; one launch, one
+// synchronisation. Stream-ordered on the primary buffer set (pipeline depth 1 from then on).
+static size_t staged_doubles(const ndlqr::Dims& u, size_t* oAB, size_t* oQR, size_t* orhs, size_t* oz) {
+  const size_t nAB = (size_t)u.batch * u.N * u.n * u.w, nQR = (size_t)u.batch * u.N * u.w, nz = (size_t)u.batch * u.N * u.rows;
+  *oAB = 0; *oQR = nAB; *orhs = nAB + nQR; *oz = nAB + nQR + nz;
+  return nAB + nQR + 2 * nz;
+}
+
+int ndlqr_hip_staged_io(NdlqrHipCtx* c, double** AB, double** QR, double** rhs, double** z) {
+  if (!c || !AB || !QR || !rhs || !z) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  size_t oAB, oQR, orhs, oz;
+  const size_t total = staged_doubles(c->du, &oAB, &oQR, &orhs, &oz);
+  if (!c->h_io) {
+    HIP_TRY(hipHostMalloc((void**)&c->h_io, sizeof(double) * total, hipHostMallocDefault));
+    if (c->padded) {  // (caller-layout staging in HBM for both directions; allocated outside any capture)
+      const int serr = ensure_pad_stage(c, total);
+      if (serr) return serr;
+    }
+    const int perr = ndlqr_hip_set_pipeline_depth(c, 1);
+    if (perr) return perr;
+  }
+  *AB = c->h_io + oAB; *QR = c->h_io + oQR; *rhs = c->h_io + orhs; *z = c->h_io + oz;
+  return NDLQR_OK;
+}
+
+// the copies around the launch chain, on the context's stream (captured, or eager under NDLQR_FLAG_PROFILE)
+static int enqueue_staged(NdlqrHipCtx* c) {
+  const ndlqr::Dims& d = c->d;
+  const ndlqr::Dims& u = c->du;
+  size_t oAB, oQR, orhs, oz;
+  (void)staged_doubles(u, &oAB, &oQR, &orhs, &oz);
+  const size_t nAB = oQR, nQR = orhs - oQR, nz = oz - orhs;
+  hipStream_t st = c->stream;
+  if (c->padded) {
+    double* s0 = c->pad_stage;
+    HIP_TRY(hipMemcpyAsync(s0, c->h_io, sizeof(double) * (nAB + nQR + nz), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ndlqr::pad_inputs_generic, dim3(d.N, d.batch), dim3(128), 0, st, u, d, 0, (const double*)s0,
+                       (const double*)(s0 + oQR), (const double*)(s0 + orhs), c->AB, c->QR, c->rhs);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->AB, c->h_io + oAB, sizeof(double) * nAB, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->QR, c->h_io + oQR, sizeof(double) * nQR, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->rhs, c->h_io + orhs, sizeof(double) * nz, hipMemcpyHostToDevice, st));
+  }
+  const int err = enqueue_solve(c);
+  if (err) return err;
+  if (c->padded) {
+    hipLaunchKernelGGL(ndlqr::unpad_blocks_generic, dim3(d.N * d.batch), dim3(64), 0, st, u, d, (const double*)c->z,
+                       c->pad_stage + oz);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_io + oz, c->pad_stage + oz, sizeof(double) * nz, hipMemcpyDeviceToHost, st));
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->h_io + oz, c->z, sizeof(double) * nz, hipMemcpyDeviceToHost, st));
+  }
+  return NDLQR_OK;
+}
+
+int ndlqr_hip_solve_staged(NdlqrHipCtx* c) {
+  if (!c || !c->h_io) return NDLQR_ERR_INVALID;
+  if (c->pipeline != 1) {
+    const int perr = ndlqr_hip_set_pipeline_depth(c, 1);
+    if (perr) return perr;
+  }
+  int err = prepare_solve(c, nullptr);  // (allocations, recovery from a failed solve; depth 1: the primary set)
+  if (err) return err;
+  rhs_written_cur(c, 0xFu);
+  c->fact_valid = false;  // new A, B, Q, R: neither a cached factor array nor cached records match
+  c->rec_complete = false;
+  HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  if (c->flags & NDLQR_FLAG_PROFILE) {
+    err = enqueue_staged(c);  // per-kernel events need eager launches
+    if (err) return err;
+  } else {
+    const bool stale = !c->graph_staged || c->graph_staged_flags != c->flags;
+    if (stale) {
+      if (c->graph_staged) { (void)hipGraphExecDestroy(c->graph_staged); c->graph_staged = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      err = enqueue_staged(c);
+      hipError_t e = hipStreamEndCapture(c->stream, &graph);
+      if (err) { if (graph) (void)hipGraphDestroy(graph); return err; }
+      if (e != hipSuccess) return fail("hipStreamEndCapture", e);
+      e = hipGraphInstantiate(&c->graph_staged, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) { c->graph_staged = nullptr; return fail("hipGraphInstantiate", e); }
+      c->graph_staged_flags = c->flags;
+      c->graph_rec_complete = c->rec_complete;
+      c->graph_schedule = c->schedule;
+    }
+    HIP_TRY(hipGraphLaunch(c->graph_staged, c->stream));
+    c->rec_complete = c->graph_rec_complete;
+    c->schedule = c->graph_schedule;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+  c->z_latest = c->z;
+  c->stream_latest = c->stream;
+  c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 ||
+                  ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
+  c->timing_pending = true;
+  c->state_dirty = false;
+  return ndlqr_hip_synchronize(c);
 }
 
 // transfer staging of the current buffer set: max(flat right-hand side, packed solutions) doubles

@@ -21,8 +21,6 @@
 #include "ndlqr.h"
 #include "ndlqr_hip.h"
 
-int ndlqr_batch_upload_from_mirrors(NdLqrBatchSolver* bs, const NdData* data,
-                                    const Matrix* diagonals, const double* rhs); /* batch.c */
 
 /* ======================================================================= profile */
 
@@ -102,7 +100,9 @@ NdLqrSolver* ndlqr_NewNdLqrSolver(int nstates, int ninputs, int nhorizon) {
   s->num_threads = 1;
   s->device_ctx = NULL;
   s->device_flags = 0u;
-  s->device_profiling_off = 0;
+  s->device_profiling = -1;
+  s->device_profiled = 0;
+  s->device_split = ndlqr_NewNdLqrProfile();
   if (!slab || !s->diagonals || !s->data || !s->fact || !s->soln || !s->cholfacts ||
       !s->tree.node_list) {
     free(slab);
@@ -231,6 +231,31 @@ static NdLqrBatchSolver* device_solver(NdLqrSolver* solver) {
   return (NdLqrBatchSolver*)solver->device_ctx;
 }
 
+/* [A | B] rows, diagonals and right-hand side of the host mirrors in the packed layout of ndlqr_hip.h (column j of the
+ * column-major A' block is row j of A: the mirrors already are in device row order) */
+static void pack_from_mirrors(const NdLqrSolver* solver, double* AB, double* QR, double* rhs) {
+  const int n = solver->nstates, m = solver->ninputs, N = solver->nhorizon, w = n + m;
+  const NdData* data = solver->data;
+  for (int k = 0; k < N; ++k) {
+    double* ab = AB + (size_t)k * n * w;
+    double* qr = QR + (size_t)k * w;
+    if (k < N - 1) {
+      int lvl = 0;
+      for (int t = k; t & 1; t >>= 1) ++lvl;
+      const NdFactor* C = data->factors + (k + N * lvl);
+      for (int i = 0; i < n; ++i) {
+        memcpy(ab + i * w, C->state.data + (size_t)n * i, sizeof(double) * n);
+        memcpy(ab + i * w + n, C->input.data + (size_t)m * i, sizeof(double) * m);
+      }
+    } else {
+      memset(ab, 0, sizeof(double) * n * w);
+    }
+    for (int i = 0; i < n; ++i) qr[i] = solver->diagonals[2 * k].data[i + n * i];
+    for (int i = 0; i < m; ++i) qr[n + i] = (k < N - 1) ? solver->diagonals[2 * k + 1].data[i + m * i] : 1.0;
+  }
+  memcpy(rhs, solver->soln->data, sizeof(double) * (size_t)N * (2 * n + m));
+}
+
 int ndlqr_Solve(NdLqrSolver* solver) {
   if (!solver) return NDLQR_ERR_INVALID;
   const double t0 = wall_ms();
@@ -243,18 +268,23 @@ int ndlqr_Solve(NdLqrSolver* solver) {
   NdlqrHipCtx* ctx = (NdlqrHipCtx*)ndlqr_BatchDeviceContext(bs);
   /* The same launch sequence as the batch API (default: fast mode, solution only). The
    * factorisation the reference leaves in solver->fact is produced on demand by
-   * ndlqr_SyncFactorsToHost; ndlqr_SetDeviceFlags selects strict mode / KEEP_FACT up front. */
+   * ndlqr_SyncFactorsToHost; ndlqr_SetDeviceFlags selects strict mode / KEEP_FACT up front.
+   * Per-kernel events (eager launches) on the first solve of the solver, or on every one when asked for; otherwise
+   * the whole call -- inputs up, launch chain, solution down -- is one captured graph (ndlqr_hip_solve_staged). */
+  const int profiled = solver->device_profiling > 0 || (solver->device_profiling < 0 && !solver->device_profiled);
   unsigned want = solver->device_flags & ~NDLQR_FLAG_PROFILE;
-  if (!solver->device_profiling_off) want |= NDLQR_FLAG_PROFILE;
+  if (profiled) want |= NDLQR_FLAG_PROFILE;
   ndlqr_hip_set_flags(ctx, want);
-  ndlqr_hip_profile_reset(ctx);
-  int err = ndlqr_batch_upload_from_mirrors(bs, solver->data, solver->diagonals, solver->soln->data);
+  if (profiled) ndlqr_hip_profile_reset(ctx);
+  double *hAB, *hQR, *hrhs, *hz;
+  int err = ndlqr_hip_staged_io(ctx, &hAB, &hQR, &hrhs, &hz);
   if (err) return err;
-  err = ndlqr_SolveBatch(bs);
-  if (err && err != NDLQR_ERR_NOT_SPD) return err;
+  pack_from_mirrors(solver, hAB, hQR, hrhs);
+  err = ndlqr_hip_solve_staged(ctx);
+  if (err) return err;
+  if (ndlqr_hip_cholesky_failures(ctx) > 0) err = NDLQR_ERR_NOT_SPD;
   /* full rhs blocks (N*(2n+m)) so the unused trailing u_N slot mirrors the device too */
-  int derr = ndlqr_hip_download_rhs_blocks(ctx, 0, solver->soln->data);
-  if (derr) return derr;
+  memcpy(solver->soln->data, hz, sizeof(double) * (size_t)solver->nhorizon * (2 * solver->nstates + solver->ninputs));
 
   solver->solve_time_ms = ndlqr_BatchSolveTimeMs(bs);
   solver->linalg_time_ms = 0.0; /* the reference's global LA timer is compiled out by default too */
@@ -265,16 +295,26 @@ int ndlqr_Solve(NdLqrSolver* solver) {
    *   t_products_ms  separator kernels (inner products + Cholesky + triangular solves in one kernel)
    *   t_shur_ms      Schur-update kernels and the solution sweep (apply / back-substitution)
    *   t_cholesky_ms, t_cholsolve_ms   always 0: never separate kernels on the device */
-  const int slots = ndlqr_hip_profile_slots(ctx);
-  for (int sl = 0; sl < slots; ++sl) {
-    char name[64];
-    double ms = 0;
-    int launches = 0;
-    if (ndlqr_hip_profile_get(ctx, sl, name, (int)sizeof(name), &ms, &launches) != 0) continue;
-    if (strncmp(name, "leaf", 4) == 0 || strncmp(name, "bottom", 6) == 0) solver->profile.t_leaves_ms += ms;
-    else if (strncmp(name, "separator", 9) == 0 || strncmp(name, "upper", 5) == 0 || strncmp(name, "top", 3) == 0)
-      solver->profile.t_products_ms += ms;
-    else solver->profile.t_shur_ms += ms;
+  if (profiled) {
+    NdLqrProfile split = ndlqr_NewNdLqrProfile();
+    const int slots = ndlqr_hip_profile_slots(ctx);
+    for (int sl = 0; sl < slots; ++sl) {
+      char name[64];
+      double ms = 0;
+      int launches = 0;
+      if (ndlqr_hip_profile_get(ctx, sl, name, (int)sizeof(name), &ms, &launches) != 0) continue;
+      if (strncmp(name, "leaf", 4) == 0 || strncmp(name, "bottom", 6) == 0) split.t_leaves_ms += ms;
+      else if (strncmp(name, "separator", 9) == 0 || strncmp(name, "upper", 5) == 0 || strncmp(name, "top", 3) == 0)
+        split.t_products_ms += ms;
+      else split.t_shur_ms += ms;
+    }
+    solver->device_split = split;
+    solver->device_profiled = 1;
+  }
+  if (solver->device_profiling != 0) { /* (the split of the last profiled solve; this call's own total) */
+    solver->profile.t_leaves_ms = solver->device_split.t_leaves_ms;
+    solver->profile.t_products_ms = solver->device_split.t_products_ms;
+    solver->profile.t_shur_ms = solver->device_split.t_shur_ms;
   }
   solver->profile.t_total_ms = wall_ms() - t0;
   solver->profile.num_threads = solver->num_threads;
@@ -294,7 +334,7 @@ int ndlqr_CopySolution(NdLqrSolver* solver, double* soln) {
 
 int ndlqr_SetDeviceProfiling(NdLqrSolver* solver, int on) {
   if (!solver) return -1;
-  solver->device_profiling_off = on ? 0 : 1;
+  solver->device_profiling = on ? 1 : 0;
   return 0;
 }
 
