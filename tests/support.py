@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+ORACLE_SO = os.environ.get("NDLQR_ORACLE_LIBRARY") or os.path.join(ORACLE_DIR, "liboracle.so")  # (the sanitizer run points at its own build)
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref.so")
 
 dp = C.POINTER(C.c_double)

@@ -213,3 +213,89 @@ def test_batch_limit_is_reported(ndlqr, L):
     with a clear message (not at the first launch, and not as 'no device')."""
     assert not L.ndlqr_NewBatchSolver(4, 1, 8, 70000, -1)
     assert b"65535" in L.ndlqr_hip_last_error()
+
+
+def _mutated_fixture(tmp_path, name, mutate):
+    import json
+    with open(os.path.join(GOLDEN, "lqr_prob.json")) as fh:
+        j = json.load(fh)
+    text = mutate(j)
+    p = tmp_path / name
+    p.write_text(text if isinstance(text, str) else json.dumps(j))
+    return str(p).encode()
+
+
+def test_malformed_problem_files_return_null(L, tmp_path):
+    """A problem file the reference would read out of bounds with (src/json_utils.c:186-259 trusts `nhorizon`,
+    `nstates` and `index`; src/lqr_data.c:24-49 allocates n * n in int arithmetic) comes back as NULL here --
+    truncated text, wrong dimensions, nstates = 60000, a knot index out of range, a knot missing, a horizon longer
+    than the file -- never as a crash or as a problem with uninitialised knots."""
+    import json
+    good = L.ndlqr_ReadLQRProblemJSONFile(LQRPROB)
+    assert good
+    L.ndlqr_FreeLQRProblem(good)
+
+    def truncated(j):
+        return json.dumps(j)[: len(json.dumps(j)) // 2]
+
+    def huge_states(j):
+        j["lqrdata"][0]["nstates"] = 60000
+
+    def wrong_dims(j):
+        j["lqrdata"][3]["nstates"] = 5
+
+    def short_A(j):
+        j["lqrdata"][2]["A"] = j["lqrdata"][2]["A"][:-1]
+
+    def index_out_of_range(j):
+        j["lqrdata"][4]["index"] = 1000
+
+    def negative_index(j):
+        j["lqrdata"][4]["index"] = -3
+
+    def duplicate_index(j):
+        j["lqrdata"][4]["index"] = j["lqrdata"][5]["index"]
+
+    def long_horizon(j):
+        j["nhorizon"] = 1 << 20
+
+    def huge_horizon(j):
+        j["nhorizon"] = 1e300
+
+    def zero_inputs(j):
+        for kd in j["lqrdata"]:
+            kd["ninputs"] = 0
+
+    def non_number(j):
+        j["lqrdata"][1]["Q"][2] = "x"
+
+    def short_x0(j):
+        j["x0"] = j["x0"][:-1]
+
+    def no_lqrdata(j):
+        del j["lqrdata"]
+
+    for mutate in (truncated, huge_states, wrong_dims, short_A, index_out_of_range, negative_index, duplicate_index,
+                   long_horizon, huge_horizon, zero_inputs, non_number, short_x0, no_lqrdata):
+        path = _mutated_fixture(tmp_path, mutate.__name__ + ".json", mutate)
+        prob = L.ndlqr_ReadLQRProblemJSONFile(path)
+        assert not prob, mutate.__name__
+    assert not L.ndlqr_ReadLQRProblemJSONFile(b"/nonexistent/file.json")
+    (tmp_path / "empty.json").write_text("")
+    assert not L.ndlqr_ReadLQRProblemJSONFile(str(tmp_path / "empty.json").encode())
+    (tmp_path / "deep.json").write_text("[" * 5000)
+    assert not L.ndlqr_ReadLQRProblemJSONFile(str(tmp_path / "deep.json").encode())
+
+
+def test_container_constructors_reject_bad_sizes(L):
+    """ndlqr_NewLQRData / ndlqr_NewLQRProblem (src/lqr_data.c:24-49, src/lqr_problem.c:7-30): non-positive or absurd
+    block sizes give NULL (the slab size is computed in size_t; 60 000 states would wrap an int)."""
+    for n, m in ((0, 3), (3, 0), (-1, 2), (60000, 60000), (1 << 30, 1)):
+        assert not L.ndlqr_NewLQRData(n, m), (n, m)
+    assert not L.ndlqr_NewLQRProblem(6, 3, 0)
+    assert not L.ndlqr_NewLQRProblem(0, 3, 8)
+    assert not L.ndlqr_NewLQRProblem(1 << 30, 3, 8)
+    big = L.ndlqr_NewLQRData(2000, 10)  # 32 MB: fine
+    assert big
+    assert big.contents.A[2000 * 2000 - 1] == 0.0  # zero-initialised slab, last entry of A addressable
+    L.ndlqr_FreeLQRData(big)
