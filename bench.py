@@ -526,6 +526,63 @@ def dropin_leg(rslqr_amd, json_path, reps=200, with_reference=True):
     return out
 
 
+def config4_leg(rslqr_amd, sharding, dist, torch, rank, world, device, backend, batch, steps, barrier):
+    """BASELINE config 4 in its real form, on EVERY rank of an N > 1 run: (12,4,1024) with `batch` problems per GPU
+    (512 x 8 = 4096 at --gpus 8), batch-sharded with global seeds, timed like the headline (barriers, MAX over ranks)
+    and once more with every shard's solutions gathered after each step. Returns the dict on rank 0, None elsewhere."""
+    n, m, N = 12, 4, 1024
+    tdev = "cuda" if backend == "nccl" else "cpu"
+    bs = rslqr_amd.BatchSolver(n, m, N, batch, device=device)
+    try:
+        bs.initialize_synthetic(sharding.shard_seed0(rank, batch))
+        for _ in range(3):
+            bs.solve_async()
+            bs.solve_async()
+            bs.synchronize()
+        elapsed = sharding.timed_region(bs, steps, 2, barrier)
+        fails = bs.cholesky_failures()
+        schedule = bs.schedule()
+        kres, kbn = bs.kkt_residuals()
+        kkt = float((kres / np.maximum(1.0, kbn)).max())
+        local = bs.solutions()
+        if backend == "nccl":
+            send = torch.empty((batch, bs.nvars), dtype=torch.float64, device="cuda")
+            recv = torch.empty((world * batch, bs.nvars), dtype=torch.float64, device="cuda")
+
+            def do_gather():
+                bs.solutions_to_device(send.data_ptr())
+                bs.synchronize()
+                dist.all_gather_into_tensor(recv, send)
+                torch.cuda.synchronize()
+                return recv
+        else:
+            def do_gather():
+                return sharding.gather_solutions(bs.solutions())
+        do_gather()
+        gsteps = min(steps, 10)
+        g_elapsed, last = sharding.timed_region_with_gather(bs, gsteps, barrier, do_gather)
+        mine = last[rank * batch:(rank + 1) * batch]
+        mine = mine.cpu().numpy() if hasattr(mine, "cpu") else np.asarray(mine)
+        intact = bool(np.array_equal(mine, local))
+        per_rank = sharding.all_over_ranks(elapsed, device=tdev)
+        red = sharding.max_over_ranks([elapsed, float(fails), kkt, g_elapsed, 0.0 if intact else 1.0], device=tdev)
+        if rank != 0:
+            return None
+        total = batch * world * steps
+        return {"workload": "nx=12 nu=4 N=1024 batch=%d per GPU x %d GPUs = %d problems, fp64, factor+solve per step"
+                            % (batch, world, batch * world),
+                "is_baseline_config4": bool(batch * world == 4096 and world == 8),
+                "steps": steps, "value": total / red[0], "unit": "solves/s", "ms_per_step": red[0] / steps * 1e3,
+                "elapsed_s_per_rank": per_rank, "elapsed_minmax_s": [min(per_rank), max(per_rank)],
+                "schedule": schedule, "cholesky_failures": int(red[1]), "kkt_residual_rel_max": red[2],
+                "gather": {"steps": gsteps, "value_incl_gather": batch * world * gsteps / red[3],
+                           "ms_per_step_incl_gather": red[3] / gsteps * 1e3,
+                           "bytes_per_rank_per_step": 8 * batch * bs.nvars,
+                           "every_rank_found_its_shard_intact": red[4] == 0.0}}
+    finally:
+        bs.close()
+
+
 def time_mode(rslqr_amd, n, m, N, batch, device, seed0, flags, steps, rhs_only=False):
     """ms per step of one more mode of the same workload (own solver, same synthetic problems)."""
     bs = rslqr_amd.BatchSolver(n, m, N, batch, device=device, flags=flags)
@@ -569,6 +626,8 @@ def main():
     ap.add_argument("--no-transfers", action="store_true", help="skip the transfer / end-to-end legs")
     ap.add_argument("--transfer-leg", action="store_true", help=argparse.SUPPRESS)  # internal: child process of the N=1 run
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the legs of the other BASELINE configurations")
+    ap.add_argument("--config4-batch", type=int, default=512,
+                    help="N>1: problems per GPU of the (12,4,1024) leg (512 x 8 GPUs = BASELINE config 4; 0: skip)")
     args = ap.parse_args()
 
     if args.transfer_leg:
@@ -734,6 +793,8 @@ def main():
         gather = {"steps": gsteps, "elapsed_s": g_elapsed, "own_shard_intact": gather_ok,
                   "bytes_per_rank_per_step": 8 * batch * bs.nvars}
 
+    tdev = "cuda" if backend == "nccl" else "cpu"
+    elapsed_per_rank = sharding.all_over_ranks(elapsed, device=tdev) if distributed else [elapsed]
     red = [elapsed, float(fails), kkt_worst]
     if elapsed_ordered is not None:
         elapsed_ordered = sharding.max_over_ranks([elapsed_ordered], device="cuda" if backend == "nccl" else "cpu")[0]
@@ -741,6 +802,15 @@ def main():
         red += [gather["elapsed_s"], 0.0 if gather["own_shard_intact"] else 1.0]
     red = sharding.max_over_ranks(red, device="cuda" if backend == "nccl" else "cpu")
     elapsed_max, fails_max, kkt_max = red[0], int(red[1]), red[2]
+
+    # ---- N>1: BASELINE config 4 on every rank ((12,4,1024) x 512 per GPU; the gather included), headline workload only
+    headline = (n, m, N, batch, args.flags) == (12, 4, 256, 1024, 0) or bool(os.environ.get("NDLQR_BENCH_FORCE_CONFIG4"))
+    config4 = None
+    if distributed and world > 1 and headline and not args.no_configs and args.config4_batch > 0:
+        log("rank %d: config 4 leg, (12,4,1024) x %d per GPU" % (rank, args.config4_batch))
+        bs.close()
+        config4 = config4_leg(rslqr_amd, sharding, dist, torch, rank, world, local_rank, backend, args.config4_batch,
+                              min(steps, 20), barrier)
 
     if rank == 0:
         total_solves = batch * world * steps
@@ -754,6 +824,7 @@ def main():
             "ms_per_solve": 1e3 / value,
             "device_ms_per_step": {"median": dev_median, "min": dev_min, "reps": len(per_solve),
                                    "note": "rank 0, HIP events per solve, one solve in flight"},
+            "elapsed_s_per_rank": elapsed_per_rank, "elapsed_minmax_s": [min(elapsed_per_rank), max(elapsed_per_rank)],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (seeded splitmix64 family of SURVEY.md 8d, time-varying A,B,Q,R)",
             "config": {"workload": "nx=%d nu=%d N=%d batch=%d per GPU, fp64, factor+solve per step"
@@ -800,7 +871,9 @@ def main():
             bs.close()  # the second solver of this leg needs the memory at the large-block sizes
             result["modes"]["rhs_only (flags=16 records kept, new right-hand side per step)"] = \
                 time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 16, msteps, rhs_only=True)
-        if world == 1 and not args.no_cpu:
+        if config4 is not None:
+            result.setdefault("configs", {})["config4: (12,4,1024) x %d per GPU x %d GPUs" % (args.config4_batch, world)] = config4
+        if not args.no_cpu:  # (rank 0 at any N: the other ranks wait at the closing barrier meanwhile)
             cores = host_cores()
             log("cpu_baseline leg on %d cores" % cores)
             count = args.cpu_sample or (3 if big else max(8, min(batch, 8 * cores)))  # ~10-30 s of CPU work

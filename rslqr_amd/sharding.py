@@ -36,6 +36,18 @@ def max_over_ranks(values, device=None):
     return [float(v) for v in t.tolist()]
 
 
+def all_over_ranks(value, device=None):
+    """One float per rank -> the list of every rank's value, in rank order (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def gather_solutions(local, device=None):
     """all_gather of per-rank solution arrays [B, nvars] -> [W*B, nvars] in global problem order."""
     import torch

@@ -122,9 +122,10 @@ def test_bench_two_ranks_on_one_gpu():
     """bench.py's own N = 2 path end to end on the one GPU of the test box: two rank processes (launched by
     bench.py itself), both on device 0, gloo instead of RCCL (one GPU cannot host two RCCL ranks); the real
     BatchSolver, the shared timed regions, the gather leg."""
-    proc, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--no-cpu", "--no-modes",
-                              "--spin-up-ms", "5"],
-                             {"NDLQR_BENCH_SAME_DEVICE": "1", "NDLQR_BENCH_BACKEND": "gloo"}, 600)
+    proc, lines = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--no-modes",
+                              "--spin-up-ms", "5", "--cpu-sample", "4", "--config4-batch", "8"],
+                             {"NDLQR_BENCH_SAME_DEVICE": "1", "NDLQR_BENCH_BACKEND": "gloo",
+                              "NDLQR_BENCH_FORCE_CONFIG4": "1"}, 900)
     assert proc.returncode == 0, proc.stderr[-3000:]
     assert len(lines) == 1, lines  # rank 0 alone prints
     res = lines[0]
@@ -132,6 +133,19 @@ def test_bench_two_ranks_on_one_gpu():
     assert res["scaling"] == "weak" and res["value"] > 0
     assert res["gather"]["every_rank_found_its_shard_intact"] is True
     assert res["config"]["kkt_residual_rel_max"] <= 1e-9 and res["config"]["cholesky_failures"] == 0
+    # the N > 1 line is complete: roofline, the CPU column (rank 0), every rank's elapsed time, and BASELINE config 4
+    # -- (12,4,1024) per GPU, gather included -- on every rank (at a reduced batch for this one-GPU rehearsal)
+    assert 0.0 < res["roofline"]["frac"] <= 1.0 and res["roofline"]["kernel"]
+    assert res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["cores"] >= 1
+    assert res["parity_rel_err_vs_cpu"] <= 1e-9
+    assert len(res["elapsed_s_per_rank"]) == 2
+    assert res["elapsed_minmax_s"][0] <= res["elapsed_minmax_s"][1] == max(res["elapsed_s_per_rank"])
+    c4 = [v for k, v in res["configs"].items() if k.startswith("config4")]
+    assert len(c4) == 1
+    c4 = c4[0]
+    assert c4["value"] > 0 and len(c4["elapsed_s_per_rank"]) == 2 and c4["is_baseline_config4"] is False
+    assert c4["kkt_residual_rel_max"] <= 1e-9 and c4["cholesky_failures"] == 0
+    assert c4["gather"]["every_rank_found_its_shard_intact"] is True and c4["gather"]["value_incl_gather"] > 0
 
 
 @pytest.mark.gpu
