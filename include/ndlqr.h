@@ -403,6 +403,14 @@ int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs);
 #define NDLQR_SOLN_INPUT 4u
 int ndlqr_BatchSetStepSelection(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks);
 int ndlqr_CopyBatchSolutionSlices(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out);
+/* Time-axis sharding: one problem (or a small batch) over G ranks, rank g on knots [g N / G, (g + 1) N / G) -- for jobs
+ * with fewer problems than GPUs (details and limits: ndlqr_hip.h). Per solve, on every rank:
+ * Factor -> ExportTop(buf) -> sum buf over the ranks -> ImportTop(buf) -> Finish -> ndlqr_BatchSynchronize. */
+int ndlqr_BatchTimeShardTopDoubles(NdLqrBatchSolver* bs, int G);
+int ndlqr_BatchTimeShardFactor(NdLqrBatchSolver* bs, int g, int G);
+int ndlqr_BatchTimeShardExportTop(NdLqrBatchSolver* bs, int G, double* buf);
+int ndlqr_BatchTimeShardImportTop(NdLqrBatchSolver* bs, int G, const double* buf);
+int ndlqr_BatchTimeShardFinish(NdLqrBatchSolver* bs, int g, int G);
 void* ndlqr_HostAlloc(size_t bytes); /* pinned host memory (NULL: no device / no memory) */
 void ndlqr_HostFree(void* p);
 int ndlqr_BatchNumVars(const NdLqrBatchSolver* bs);

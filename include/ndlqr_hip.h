@@ -117,6 +117,25 @@ int ndlqr_hip_synchronize_previous(NdlqrHipCtx* ctx);
 /* What a step brings down (ndlqr.h: ndlqr_BatchSetStepSelection) / the same slice of the latest solve, synchronously. */
 int ndlqr_hip_set_step_selection(NdlqrHipCtx* ctx, int knot0, int nknots, unsigned blocks);
 int ndlqr_hip_download_selection(NdlqrHipCtx* ctx, int knot0, int nknots, unsigned blocks, double* out);
+/* Time-axis sharding: ONE problem (or a small batch) solved by G ranks, each working on a chunk of
+ * N / G consecutive knots of the horizon -- for jobs with fewer problems than GPUs; the batch axis stays the sharding
+ * unit otherwise. Every rank holds the whole problem's inputs (upload as usual) and runs, for its chunk g:
+ *     ndlqr_hip_time_shard_factor(ctx, g, G)      bottom kernel + the tree levels inside the chunk (asynchronous)
+ *     ndlqr_hip_time_shard_export(ctx, G, buf)    the G - 1 accumulator slots between the chunks, packed
+ *                                                 [G - 1][batch][slot] (ndlqr_hip_time_shard_top_doubles); waits
+ *     -- the caller sums `buf` over the ranks: one all-reduce (RCCL over xGMI when every rank has its own GPU) --
+ *     ndlqr_hip_time_shard_import(ctx, G, buf)
+ *     ndlqr_hip_time_shard_finish(ctx, g, G)      the top log2(G) levels (redundantly on every rank: no multipliers
+ *                                                 travel back), top-down sweep, back-substitution of the chunk
+ * followed by ndlqr_hip_synchronize. The solution array then holds the knots [g N / G, (g + 1) N / G) of every problem
+ * (ndlqr_hip_download_solutions hands back whole vectors: the other knots are stale). buf: host or device memory.
+ * Default fast mode, size-specialised block sizes with a matrix-core instance, G a power of two, N / G >= 16,
+ * N <= 64 K / (8 n) knots. The loop being split: src/solve.c:68-134 (factor), :137-182 (solve). */
+int ndlqr_hip_time_shard_top_doubles(NdlqrHipCtx* ctx, int G);
+int ndlqr_hip_time_shard_factor(NdlqrHipCtx* ctx, int g, int G);
+int ndlqr_hip_time_shard_export(NdlqrHipCtx* ctx, int G, double* buf);
+int ndlqr_hip_time_shard_import(NdlqrHipCtx* ctx, int G, const double* buf);
+int ndlqr_hip_time_shard_finish(NdlqrHipCtx* ctx, int g, int G);
 /* Pinned host memory for the transfer functions (hipHostMalloc): copies from / to it are asynchronous and run at the
  * rate of the host link. NULL when no device / no memory. */
 void* ndlqr_hip_host_alloc(size_t bytes);

@@ -227,6 +227,11 @@ def lib():
     proto("ndlqr_BatchSynchronizePrevious", ci, vp)
     proto("ndlqr_BatchSetStepSelection", ci, vp, ci, ci, C.c_uint)
     proto("ndlqr_CopyBatchSolutionSlices", ci, vp, ci, ci, C.c_uint, dp)
+    proto("ndlqr_BatchTimeShardTopDoubles", ci, vp, ci)
+    proto("ndlqr_BatchTimeShardFactor", ci, vp, ci, ci)
+    proto("ndlqr_BatchTimeShardExportTop", ci, vp, ci, vp)
+    proto("ndlqr_BatchTimeShardImportTop", ci, vp, ci, vp)
+    proto("ndlqr_BatchTimeShardFinish", ci, vp, ci, ci)
     proto("ndlqr_HostAlloc", vp, C.c_size_t)
     proto("ndlqr_HostFree", None, vp)
     proto("ndlqr_BatchSynchronize", ci, vp)
@@ -404,6 +409,23 @@ class BatchSolver:
         ptr = lambda a: None if a is None else _ptr(a)
         self._step_refs = self._step_refs[-1:] + [(q, r, d, x0, soln)]
         return self.L.ndlqr_BatchStepAsync(self.h, ptr(q), ptr(r), ptr(d), ptr(x0), ptr(soln))
+
+    # ---- time-axis sharding (one problem over G ranks; include/ndlqr_hip.h)
+    def time_shard_top_doubles(self, G):
+        return self.L.ndlqr_BatchTimeShardTopDoubles(self.h, G)
+
+    def time_shard_factor(self, g, G):
+        return self.L.ndlqr_BatchTimeShardFactor(self.h, g, G)
+
+    def time_shard_export(self, G, ptr):
+        """`ptr`: address (int) of host or device memory for time_shard_top_doubles(G) doubles."""
+        return self.L.ndlqr_BatchTimeShardExportTop(self.h, G, C.c_void_p(int(ptr)))
+
+    def time_shard_import(self, G, ptr):
+        return self.L.ndlqr_BatchTimeShardImportTop(self.h, G, C.c_void_p(int(ptr)))
+
+    def time_shard_finish(self, g, G):
+        return self.L.ndlqr_BatchTimeShardFinish(self.h, g, G)
 
     def synchronize_previous(self):
         return self.L.ndlqr_BatchSynchronizePrevious(self.h)

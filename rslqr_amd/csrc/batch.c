@@ -279,6 +279,21 @@ int ndlqr_BatchSetStepSelection(NdLqrBatchSolver* bs, int knot0, int nknots, uns
 int ndlqr_CopyBatchSolutionSlices(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out) {
   return bs ? ndlqr_hip_download_selection(bs->ctx, knot0, nknots, blocks, out) : NDLQR_ERR_INVALID;
 }
+int ndlqr_BatchTimeShardTopDoubles(NdLqrBatchSolver* bs, int G) {
+  return bs ? ndlqr_hip_time_shard_top_doubles(bs->ctx, G) : NDLQR_ERR_INVALID;
+}
+int ndlqr_BatchTimeShardFactor(NdLqrBatchSolver* bs, int g, int G) {
+  return bs ? ndlqr_hip_time_shard_factor(bs->ctx, g, G) : NDLQR_ERR_INVALID;
+}
+int ndlqr_BatchTimeShardExportTop(NdLqrBatchSolver* bs, int G, double* buf) {
+  return bs ? ndlqr_hip_time_shard_export(bs->ctx, G, buf) : NDLQR_ERR_INVALID;
+}
+int ndlqr_BatchTimeShardImportTop(NdLqrBatchSolver* bs, int G, const double* buf) {
+  return bs ? ndlqr_hip_time_shard_import(bs->ctx, G, buf) : NDLQR_ERR_INVALID;
+}
+int ndlqr_BatchTimeShardFinish(NdLqrBatchSolver* bs, int g, int G) {
+  return bs ? ndlqr_hip_time_shard_finish(bs->ctx, g, G) : NDLQR_ERR_INVALID;
+}
 void* ndlqr_HostAlloc(size_t bytes) { return ndlqr_hip_host_alloc(bytes); }
 void ndlqr_HostFree(void* p) { ndlqr_hip_host_free(p); }
 

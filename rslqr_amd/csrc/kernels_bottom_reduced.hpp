@@ -638,7 +638,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void re
     Dims d, int l, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
     double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l) {
   __shared__ ReducedLds<NX, NU, false> lds;
-  reduced_separator_mc<NX, NU, false>(d, l, blockIdx.x * (2 << l), blockIdx.y, threadIdx.x, AB, QR, rhs, red, rec, F,
+  reduced_separator_mc<NX, NU, false>(d, l, (blockIdx.x + d.xoff) * (2 << l), blockIdx.y, threadIdx.x, AB, QR, rhs, red, rec, F,
                                       info, store_l, lds);
 }
 
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   double* abs_ = lds.buf;            // [A | B] of the four knots
   double* rq = lds.rq;               // 1 / [Q | R] of the four knots
   double* rh = lds.rh;               // their raw right-hand sides
-  const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = blockIdx.x * 4;
+  const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = (blockIdx.x + d.xoff) * 4;
   const int li = lane & 15, lk = lane >> 4;
   const int ri = li < NX ? li : NX - 1;
   const bool hasA = k0 > 0, hasB = k0 + 4 < N;  // separators k0 - 1 / k0 + 3 exist

@@ -9,6 +9,8 @@ struct Dims {
   int rows;  // 2n + m  rows of a factor block / entries of an rhs block
   int w;     // n + m    row length of the packed [A | B] input
   int fb;    // rows * n doubles per factor block
+  int xoff;  // added to blockIdx.x by the kernels of the separator-only schedule: 0, or the first workgroup of this
+             // rank's chunk of the horizon (time-axis sharding, launch_time_shard)
 };
 
 // acc + a*b. Fast mode: one fused multiply-add. Strict mode: rounded product, then rounded sum --

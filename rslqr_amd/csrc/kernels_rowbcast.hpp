@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
   const int g = lane >> 4, i = lane & 15;
   const int ic = i < NX ? i : NX - 1;  // rows >= NX of a DPP row are padding: they repeat row NX - 1
   const int kc = i < W ? i : W - 1;
-  const int kw = blockIdx.x * 16;      // first knot of the wavefront
+  const int kw = (blockIdx.x + d.xoff) * 16;  // first knot of the wavefront
   const int k0 = kw + 4 * g;           // first knot of this row's group
   const bool hasA = k0 > 0, hasB = k0 + 4 < N, first = k0 == 0;
   const bool rowlane = i < NX;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
   constexpr int R0 = Lds::R0;
   static_assert(9 * NX <= 256 && KPB * ROWS <= 256, "thread roles fit the workgroup");
   __shared__ Lds lds;
-  const int N = d.N, b = blockIdx.y, first = blockIdx.x * KPB;
+  const int N = d.N, b = blockIdx.y, first = (blockIdx.x + d.xoff) * KPB;
   auto sep_slot = [&](int s) -> int { return s < first ? 7 : (s >= first + 7 ? 8 : s - first); };
   const int t = threadIdx.x;
 

@@ -49,7 +49,9 @@ static SmallPlan plan_small(const NdlqrHipCtx* c) {
       p.tree = c->tree_cnt && (c->tree == 1 || (c->tree < 0 && (size_t)d.batch * (d.N >> 2) <= 2048));
       // compact level-0 records (S-bar^-1 only): not what a record-based re-solve reads, and the tree
       // schedule keeps the one-kernel back-substitution; rb_backsub's thread roles need 8 (2 nx + nu) <= 256
-      p.compact = !p.tree && !p.store_l && d.N >= 16 && 8 * (2 * NX + NU) <= 256;
+      // (and rb_backsub_top's sweep array, N / 8 multipliers, has to fit the LDS of its one workgroup per problem)
+      p.compact = !p.tree && !p.store_l && d.N >= 16 && 8 * (2 * NX + NU) <= 256 &&
+                  sizeof(double) * (size_t)(d.N >> 3) * NX <= 160 * 1024;
       // row-broadcast bottom kernel (one DPP row holds the rows of S-bar and of [A | B]'): its cost falls
       // with the block size, the matrix-core kernel's does not (16x16 tiles whatever n is). Measured bottom
       // kernel, N = 256 x 1024: (6,3) 0.105 vs 0.170 ms, (8,4) 0.144 vs 0.190, (9,3) 0.202 vs 0.244,
@@ -119,9 +121,13 @@ static int launch_small(NdlqrHipCtx* c) {
       }
       ScopedSlot t(c, SLOT_APPLY);
       if (compact) {
-        if (!top_sweeps)
-          hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256),
-                             sizeof(double) * (size_t)(d.N >> 3) * NX, c->stream, d, c->rec, c->ytop);
+        if (!top_sweeps) {
+          const size_t top_lds = sizeof(double) * (size_t)(d.N >> 3) * NX;
+          if (top_lds > 64 * 1024)  // (beyond the default limit of dynamic LDS: horizons of 8192 knots at 12 states)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ndlqr::rb_backsub_top<NX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)top_lds);
+          hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256), top_lds, c->stream, d, c->rec, c->ytop);
+        }
         hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
                            c->QR, c->rhs, c->rec, c->ytop, c->z);
       } else {
@@ -176,5 +182,75 @@ static void launch_rhs_records(NdlqrHipCtx* c) {
     ScopedSlot t(c, SLOT_APPLY);
     hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
                        c->QR, c->rhs, c->rec, c->z);
+  }
+}
+
+// Time-axis sharding of the separator-only schedule: the horizon is cut into G
+// chunks of N / G knots, rank g works on chunk g. The tree levels 0 .. K - log2(G) - 1 lie inside a chunk; what a
+// chunk exposes to the rest of the tree is what any subtree exposes: the blocks it adds to the slots of the G - 1
+// separators between the chunks (and the couplings between those). Phase 0 (here): bottom kernel and level launches
+// restricted to the chunk (Dims::xoff). Between the phases the caller sums the top slots over the ranks (one
+// all-reduce of (G - 1) slots per problem: every rank contributes the halves its chunk wrote, zeros elsewhere).
+// Phase 1: the top log2(G) levels -- G - 1 separators, eliminated REDUNDANTLY by every rank, which saves sending
+// multipliers back --, the top-down sweep, and the back-substitution of the chunk's knots.
+// Inputs are resident for the whole horizon on every rank (this prototype shards the work, not the storage).
+template <int NX, int NU>
+static int launch_time_shard(NdlqrHipCtx* c, const int phase, const int g, const int G) {
+  ndlqr::Dims d = c->d;
+  int lg = 0;
+  while ((1 << lg) < G) ++lg;
+  if (G < 2 || (1 << lg) != G || g < 0 || g >= G) return NDLQR_ERR_INVALID;
+  if constexpr (!ndlqr::P1OnMatrixCores<NX, NU>::value) {
+    return NDLQR_ERR_INVALID;
+  } else {
+    const int ltop = d.K - lg;  // levels [0, ltop) lie inside a chunk
+    if (!c->red || !c->ytop || ltop < 4 || 8 * (2 * NX + NU) > 256 || (c->flags & ~NDLQR_FLAG_PROFILE)) return NDLQR_ERR_INVALID;
+    const size_t top_lds = sizeof(double) * (size_t)(d.N >> 3) * NX;
+    if (top_lds > 160 * 1024) return NDLQR_ERR_INVALID;  // (rb_backsub_top's sweep array has to fit one workgroup's LDS)
+    if (top_lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ndlqr::rb_backsub_top<NX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)top_lds);
+    constexpr size_t SLOT = ndlqr::RedSlot<NX>::SIZE;
+    if (phase == 0) {
+      // whatever an earlier exchange left in the top slots goes: this rank's chunk writes its halves afresh
+      for (int j = 1; j < G; ++j) {
+        const int s = j * (d.N / G) - 1;
+        double* p = c->red + (size_t)(s >> 2) * SLOT;
+        if (hipMemset2DAsync(p, sizeof(double) * (size_t)(d.N >> 2) * SLOT, 0, sizeof(double) * SLOT, (size_t)d.batch,
+                             c->stream) != hipSuccess)
+          return NDLQR_ERR_NO_DEVICE;
+      }
+      {
+        ScopedSlot t(c, SLOT_BOTTOM);
+        const int cnt = (d.N >> 2) / G;
+        d.xoff = g * cnt;
+        hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, false>), dim3(cnt, d.batch), dim3(64), 0, c->stream, d,
+                           c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, 0, nullptr, 1);
+      }
+      for (int l = 2; l < ltop; ++l) {
+        ScopedSlot t(c, SLOT_UPPER);
+        const int cnt = (d.N >> (l + 1)) / G;
+        d.xoff = g * cnt;
+        hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(cnt, d.batch), dim3(64), 0, c->stream, d, l, c->AB,
+                           c->QR, c->rhs, c->red, c->rec, c->F, c->info, 0);
+      }
+    } else {
+      d.xoff = 0;
+      for (int l = ltop; l < d.K; ++l) {
+        ScopedSlot t(c, SLOT_TOP);
+        hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream, d,
+                           l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, 0);
+      }
+      ScopedSlot t(c, SLOT_APPLY);
+      // (the sweep runs over every separator of level >= 3; those of other chunks have no records here and resolve to
+      //  garbage nobody reads: a separator depends on its ancestors only, which are in this chunk or among the top ones)
+      hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256), top_lds, c->stream, d, c->rec, c->ytop);
+      const int cnt = (d.N >> 3) / G;
+      d.xoff = g * cnt;
+      hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(cnt, d.batch), dim3(256), 0, c->stream, d, c->AB, c->QR,
+                         c->rhs, c->rec, c->ytop, c->z);
+    }
+    c->schedule = "reduced-time-shard";
+    return NDLQR_OK;
   }
 }

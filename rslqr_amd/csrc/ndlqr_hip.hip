@@ -84,7 +84,7 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   auto set_dims = [&](ndlqr::Dims& x, int n_, int m_) {
     x.n = n_; x.m = m_; x.N = nhorizon; x.batch = batch;
     x.K = 0; while ((1 << x.K) < nhorizon) ++x.K;
-    x.rows = 2 * n_ + m_; x.w = n_ + m_; x.fb = x.rows * n_;
+    x.rows = 2 * n_ + m_; x.w = n_ + m_; x.fb = x.rows * n_; x.xoff = 0;
   };
   set_dims(c->du, nstates, ninputs);
   // Padded shapes: a block size without a size-specialised instance runs zero-padded inside the cheapest instance
@@ -695,7 +695,9 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
   int ndlqr_small_solve_##NX_##_##NU_(NdlqrHipCtx* c, bool strict, bool keep);       \
   int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep); \
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c);                               \
-  int ndlqr_small_kpb_##NX_##_##NU_(void);
+  int ndlqr_small_kpb_##NX_##_##NU_(void);                                          \
+  int ndlqr_small_tshard_##NX_##_##NU_(NdlqrHipCtx* c, int phase, int g, int G);      \
+  int ndlqr_small_slot_##NX_##_##NU_(void);
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 
@@ -705,6 +707,8 @@ struct SmallInstance {
   int (*needs_F)(const NdlqrHipCtx*, bool, bool);
   void (*rhs)(NdlqrHipCtx*);
   int (*kpb)(void);
+  int (*tshard)(NdlqrHipCtx*, int, int, int);
+  int (*slot)(void);
 };
 #ifdef NDLQR_SINGLE_TU
 #define NDLQR_SMALL_INSTANCE(NX_, NU_)                                                              \
@@ -717,7 +721,9 @@ struct SmallInstance {
     return keep ? plan_small<NX_, NU_, false, true>(c).needs_F : plan_small<NX_, NU_, false, false>(c).needs_F;           \
   }                                                                                                 \
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c) { launch_rhs_records<NX_, NU_>(c); }           \
-  int ndlqr_small_kpb_##NX_##_##NU_(void) { return ndlqr::SchurShape<NX_, NU_>::KPB; }
+  int ndlqr_small_kpb_##NX_##_##NU_(void) { return ndlqr::SchurShape<NX_, NU_>::KPB; }              \
+  int ndlqr_small_tshard_##NX_##_##NU_(NdlqrHipCtx* c, int phase, int g, int G) { return launch_time_shard<NX_, NU_>(c, phase, g, G); } \
+  int ndlqr_small_slot_##NX_##_##NU_(void) { return (int)ndlqr::RedSlot<NX_>::SIZE; }
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 #endif
@@ -725,7 +731,7 @@ struct SmallInstance {
 static const SmallInstance kSmallInstances[] = {
 #define NDLQR_SMALL_INSTANCE(NX_, NU_) \
   {NX_, NU_, ndlqr_small_solve_##NX_##_##NU_, ndlqr_small_needs_F_##NX_##_##NU_, ndlqr_small_rhs_##NX_##_##NU_, \
-   ndlqr_small_kpb_##NX_##_##NU_},
+   ndlqr_small_kpb_##NX_##_##NU_, ndlqr_small_tshard_##NX_##_##NU_, ndlqr_small_slot_##NX_##_##NU_},
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 };
@@ -1005,6 +1011,81 @@ int ndlqr_hip_solve_staged(NdlqrHipCtx* c) {
   c->state_dirty = false;
   return ndlqr_hip_synchronize(c);
 }
+
+// ------------------------------------------------------------------------------ time-axis sharding
+// One problem (or a small batch) over G ranks along the horizon: launch_time_shard (launch_small.hpp) says what the
+// phases do. The G - 1 top slots of every problem travel packed as [G - 1][batch][slot doubles].
+static const SmallInstance* time_shard_instance(NdlqrHipCtx* c, int G) {
+  if (!c || G < 2 || c->padded) return nullptr;
+  const SmallInstance* inst = pick_small(c);
+  if (!inst || c->d.N % G || (c->d.N / G) < 16) return nullptr;
+  return inst;
+}
+
+int ndlqr_hip_time_shard_top_doubles(NdlqrHipCtx* c, int G) {
+  const SmallInstance* inst = time_shard_instance(c, G);
+  return inst ? (G - 1) * c->d.batch * inst->slot() : NDLQR_ERR_INVALID;
+}
+
+static int time_shard_copy_slots(NdlqrHipCtx* c, int G, double* buf, bool to_buf) {
+  const SmallInstance* inst = time_shard_instance(c, G);
+  if (!inst || !buf) return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  const size_t slot = (size_t)inst->slot();
+  const size_t pitch_red = sizeof(double) * (size_t)(d.N >> 2) * slot, width = sizeof(double) * slot;
+  HIP_TRY(hipSetDevice(c->device));
+  for (int j = 1; j < G; ++j) {
+    const int s = j * (d.N / G) - 1;
+    double* p = c->red + (size_t)(s >> 2) * slot;
+    double* q = buf + (size_t)(j - 1) * d.batch * slot;
+    if (to_buf) HIP_TRY(hipMemcpy2DAsync(q, width, p, pitch_red, width, (size_t)d.batch, hipMemcpyDefault, c->stream));
+    else HIP_TRY(hipMemcpy2DAsync(p, pitch_red, q, width, width, (size_t)d.batch, hipMemcpyDefault, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NDLQR_OK;
+}
+int ndlqr_hip_time_shard_export(NdlqrHipCtx* c, int G, double* buf) { return time_shard_copy_slots(c, G, buf, true); }
+int ndlqr_hip_time_shard_import(NdlqrHipCtx* c, int G, const double* buf) {
+  return time_shard_copy_slots(c, G, const_cast<double*>(buf), false);
+}
+
+static int time_shard_phase(NdlqrHipCtx* c, int phase, int g, int G) {
+  const SmallInstance* inst = time_shard_instance(c, G);
+  if (!inst) {
+    g_last_error = "time-axis sharding: needs a size-specialised block size with a matrix-core instance, G a power of two, "
+                   "N / G >= 16";
+    return NDLQR_ERR_INVALID;
+  }
+  if (c->flags & ~NDLQR_FLAG_PROFILE) { g_last_error = "time-axis sharding runs the default fast mode only"; return NDLQR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  if (phase == 0) {
+    if (c->pipeline != 1 || c->in_alt) {
+      const int perr = ndlqr_hip_set_pipeline_depth(c, 1);  // stream-ordered on the primary buffer set
+      if (perr) return perr;
+    }
+    const int merr = rhs_make_current(c, 0xFu);
+    if (merr) return merr;
+    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  }
+  const int err = inst->tshard(c, phase, g, G);
+  if (err) {
+    if (g_last_error.empty() || err == NDLQR_ERR_INVALID) g_last_error = "time-axis sharding: horizon / chunk not supported by this instance";
+    return err;
+  }
+  HIP_TRY(hipGetLastError());
+  if (phase == 1) {
+    HIP_TRY(hipMemcpyAsync(c->h_fail, c->info + c->d.batch, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    c->timing_pending = true;
+    c->z_latest = c->z;
+    c->stream_latest = c->stream;
+    c->fact_valid = false;
+    c->rec_complete = false;
+  }
+  return NDLQR_OK;
+}
+int ndlqr_hip_time_shard_factor(NdlqrHipCtx* c, int g, int G) { return time_shard_phase(c, 0, g, G); }
+int ndlqr_hip_time_shard_finish(NdlqrHipCtx* c, int g, int G) { return time_shard_phase(c, 1, g, G); }
 
 // transfer staging of the current buffer set: max(flat right-hand side, packed solutions) doubles
 static int ensure_xfer(NdlqrHipCtx* c) {

@@ -5,6 +5,8 @@
 //   ndlqr_small_needs_F_<nx>_<nu>(ctx, strict, keep)  does that sequence touch the factor array?
 //   ndlqr_small_rhs_<nx>_<nu>(ctx)                      record-based right-hand-side re-solve
 //   ndlqr_small_kpb_<nx>_<nu>()                         knots per workgroup of its Schur kernels
+//   ndlqr_small_tshard_<nx>_<nu>(ctx, phase, g, G)      time-axis sharding: chunk g of G, phase 0 / 1 (launch_time_shard)
+//   ndlqr_small_slot_<nx>_<nu>()                        doubles per accumulator slot
 #include "launch_small.hpp"
 
 #if !defined(NDLQR_INST_NX) || !defined(NDLQR_INST_NU)
@@ -32,3 +34,9 @@ int NDLQR_INST_NAME(ndlqr_small_needs_F_)(const NdlqrHipCtx* c, bool strict, boo
 void NDLQR_INST_NAME(ndlqr_small_rhs_)(NdlqrHipCtx* c) { launch_rhs_records<NX, NU>(c); }
 
 int NDLQR_INST_NAME(ndlqr_small_kpb_)(void) { return ndlqr::SchurShape<NX, NU>::KPB; }
+
+int NDLQR_INST_NAME(ndlqr_small_tshard_)(NdlqrHipCtx* c, int phase, int g, int G) {
+  return launch_time_shard<NX, NU>(c, phase, g, G);
+}
+
+int NDLQR_INST_NAME(ndlqr_small_slot_)(void) { return (int)ndlqr::RedSlot<NX>::SIZE; }

@@ -90,3 +90,44 @@ def timed_region_with_gather(solver, steps, barrier, gather):
         last = gather()
     barrier()
     return time.perf_counter() - t0, last
+
+
+# ------------------------------------------------------------------------------------------------ time axis
+def solve_time_sharded(solver, rank, world, reduce_sum=None):
+    """One solve of a problem whose HORIZON is cut over `world` ranks (include/ndlqr_hip.h): rank
+    `rank` factors the tree levels inside its chunk of N / world knots, the world - 1 accumulator slots between the
+    chunks are summed over the ranks (`reduce_sum(array)` -> summed array, in place or returned; default: all_reduce
+    of a host tensor over the initialised process group), every rank eliminates the top log2(world) levels itself and
+    back-substitutes its chunk. Returns the solver's status; afterwards solver.solutions() holds valid knots
+    [rank N / world, (rank + 1) N / world)."""
+    count = solver.time_shard_top_doubles(world)
+    if count <= 0:
+        return -1
+    err = solver.time_shard_factor(rank, world)
+    if err:
+        return err
+    buf = np.zeros(count)
+    err = solver.time_shard_export(world, buf.ctypes.data)
+    if err:
+        return err
+    if reduce_sum is None:
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    else:
+        out = reduce_sum(buf)
+        if out is not None:
+            buf = np.ascontiguousarray(out)
+    err = solver.time_shard_import(world, buf.ctypes.data)
+    if err:
+        return err
+    err = solver.time_shard_finish(rank, world)
+    return err or solver.synchronize()
+
+
+def chunk_of_solution(sol, n, m, N, rank, world):
+    """The entries of packed solution vectors [.., nvars] that rank `rank`'s chunk of the horizon owns."""
+    zb = 2 * n + m
+    lo, hi = rank * (N // world) * zb, min((rank + 1) * (N // world) * zb, zb * N - m)
+    return slice(lo, hi)
