@@ -257,6 +257,33 @@ def test_non_spd_block_is_reported(ndlqr):
         bs.close()
 
 
+def test_non_spd_step_is_reported_one_step_behind(ndlqr):
+    """An MPC loop that only ever calls ndlqr_BatchSynchronizePrevious must learn that a step's solve met a
+    non-positive pivot before it consumes that step's `soln`: the call that waits for the step returns
+    NDLQR_ERR_NOT_SPD (the reference's ndlqr_Solve never tells, src/solve.c:189); later healthy steps return 0 again."""
+    n, m, N, batch = 12, 4, 64, 40
+    gens = [ndlqr.generate_synthetic(n, m, N, 300 + p) for p in range(batch)]
+    flat = {k: np.stack([g[k] for g in gens]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")}
+    bad = {k: v.copy() for k, v in flat.items()}
+    bad["R"][7, 5, 2] = -0.5
+    x0 = ndlqr.pinned_empty(flat["x0"].shape); x0[...] = flat["x0"]
+    outs = [ndlqr.pinned_empty((batch, (2 * n + m) * N - m)) for _ in range(2)]
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*[bad[k] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    assert bs.step_async(None, None, None, x0, outs[0]) == 0      # step 0: non-SPD
+    assert bs.step_async(None, None, None, x0, outs[1]) == 0      # step 1: the same inputs
+    assert bs.synchronize_previous() == -3                         # waits for step 0
+    assert bs.cholesky_failures() >= 1
+    assert bs.synchronize() == 0
+    bs.initialize_flat(*[flat[k] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    for s in range(3):
+        assert bs.step_async(None, None, None, x0, outs[s & 1]) == 0
+        if s >= 1:
+            assert bs.synchronize_previous() == 0
+    assert bs.synchronize() == 0 and bs.cholesky_failures() == 0
+    bs.close()
+
+
 @pytest.mark.parametrize("n,m,N", [(12, 4, 64), (12, 4, 256), (6, 3, 32), (13, 4, 16), (4, 1, 8), (10, 4, 128),
                                    # runtime-sized separator-only schedule: the compact records (factors) + slots of every separator
                                    (16, 4, 16), (20, 20, 16), (64, 16, 32), (7, 9, 8), (16, 4, 2), (33, 5, 4), (48, 16, 64),
