@@ -404,6 +404,32 @@ def test_harder_families_large_and_padded_paths(ndlqr, oracle, n, m, N, batch, w
         bs.close()
 
 
+@pytest.mark.parametrize("n,m,N,flags", [(12, 4, 256, "records"), (6, 3, 128, "records"), (64, 16, 64, "records"),
+                                         (12, 4, 64, "fact"), (20, 6, 32, "fact")])
+@pytest.mark.parametrize("a_scale,q_scale,r_scale", HARD_FAMILIES)
+def test_harder_families_rhs_only_resolve(ndlqr, oracle, n, m, N, flags, a_scale, q_scale, r_scale):
+    """The factor / solve split on the ill-conditioned families: a new right-hand side against the cached separator
+    records (fast mode) or the cached factor array, within 1e-9 of the oracle's full solve of that problem."""
+    g, prob = hard_problem(ndlqr, n, m, N, 21, a_scale, q_scale, r_scale)
+    fl = ndlqr.FLAG_KEEP_RECORDS if flags == "records" else ndlqr.FLAG_KEEP_FACT
+    bs = ndlqr.BatchSolver(n, m, N, 2, flags=fl)
+    bs.initialize_flat(*[np.stack([g[k]] * 2) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    assert bs.solve() == 0
+    rng = np.random.default_rng(5)
+    new = {k: g[k] + rng.standard_normal(g[k].shape) for k in ("q", "r", "d", "x0")}
+    bs.set_rhs_flat(*[np.stack([new[k]] * 2) for k in ("q", "r", "d", "x0")])
+    assert bs.solve_rhs_only() == 0
+    p2 = Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], new["q"], new["r"], new["d"], new["x0"])
+    ref = oracle.solve(p2, 8)[0][: p2.nvars]
+    sol = bs.solutions()
+    for p in range(2):
+        assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+    ores, obn = oracle.kkt_residual(p2, ref)
+    res, bn = oracle.kkt_residual(p2, sol[0])
+    assert res / max(1.0, bn) <= 10.0 * ores / max(1.0, obn) + 1e-12
+    bs.close()
+
+
 def _solve_in_subprocess(n, m, N, batch, seed, env):
     """Solutions of a fresh process with `env` added to the environment (the tuning variables are
     read once, at context creation)."""
