@@ -483,6 +483,27 @@ def test_tree_schedule_fills_the_chip(ndlqr, oracle, n, m, N, batch):
         assert np.linalg.norm(tree[b] - ref) / np.linalg.norm(ref) <= REL_TOL
 
 
+@pytest.mark.parametrize("n,m,N,batch,want", [(12, 4, 256, 8, "reduced-tree"), (6, 3, 256, 30, "reduced-tree"),
+                                              (12, 4, 128, 96, "reduced"), (64, 16, 32, 6, "generic-reduced")])
+def test_repeated_solves_are_bitwise_identical(ndlqr, n, m, N, batch, want):
+    """The hand-offs between wavefronts (arrival counters and write-through pushes of the tree schedule, atomic adds of
+    the level launches, the two buffer sets of the pipeline) leave no room for run-to-run differences: every accumulator
+    element receives its additions in a fixed order, so 150 solves of the same inputs are bit for bit the first one.
+    A missing ordering edge would show up here as an occasional stale operand."""
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_synthetic(123)
+    assert bs.solve() == 0
+    assert bs.schedule() == want
+    first = bs.solutions()
+    for rep in range(50):
+        assert bs.solve_async() == 0 and bs.solve_async() == 0 and bs.solve_async() == 0
+        assert bs.synchronize() == 0
+        assert np.array_equal(bs.solutions(), first), rep
+    res, bn = bs.kkt_residuals()
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    bs.close()
+
+
 def test_solve_pipeline(ndlqr, oracle):
     """Two-deep solve pipeline (include/ndlqr_hip.h): consecutive asynchronous solves alternate between two
     output-buffer sets / streams. Every solve is complete and identical to a stream-ordered one; replacing
