@@ -444,7 +444,10 @@ __device__ __forceinline__ void push_mc(const int lane, const bool hasA, const b
 // first: s == 0 -- knot 0 has its state fixed: its state columns drop out of S-bar and carry x0 in
 // the rhs (leaf phase of knot 0, src/nested_dissection.c:24-59). init(g): what else goes into
 // element (lk + 4 g, li) (the pushed blocks of an upper level).
-template <int NX, int NU, int WP, class Init>
+// NEXT = false: the terms of knot s + 1 (Q_{s+1}^-1 on the diagonal, z(s+1) in the rhs column) are not staged in LDS: q1 /
+// z1 are not read, init(g) supplies them (bottom8_reduced_mc: the level-2 separator's next knot belongs to the other
+// wavefront of the workgroup).
+template <int NX, int NU, int WP, bool NEXT = true, class Init>
 __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first, const double* am, const double* q0,
                                                const double* q1, const double* z0, const double* z1, Init init) {
   constexpr int W = NX + NU, KS = (W + 3) / 4;
@@ -455,7 +458,8 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
-    w1[g] = q1[ic]; za[g] = z1[ic]; zb[g] = z1[NX + ic];
+    if constexpr (NEXT) { w1[g] = q1[ic]; za[g] = z1[ic]; zb[g] = z1[NX + ic]; }
+    else { w1[g] = 0.0; za[g] = 0.0; zb[g] = 0.0; }
     in0[g] = init(g);
   }
 #pragma unroll
@@ -510,18 +514,20 @@ struct alignas(16) ReducedLds {
 // (see reduced_level): subtree [base, base + 2^(l+1)) of problem b, by one wavefront.
 // TREE: called from the tree schedule -- the slot was written by wavefronts of this launch, possibly
 // on another XCD: it is read with L1-bypassing (`sc1`) loads and the couplings are stored through.
-template <int NX, int NU, bool TREE, class LdsT>
+// EXT: the separator's slot is not in `red` but at `slot_ext` in LDS, complete (bottom8_reduced_mc: its children pushed
+// there); nothing of it is loaded from memory.
+template <int NX, int NU, bool TREE, class LdsT, bool EXT = false>
 __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l, const int base, const int b,
                                                      const int lane, const double* __restrict__ AB,
                                                      const double* __restrict__ QR,
                                                      const double* __restrict__ rhs, double* red,
                                                      double* __restrict__ rec, double* F, int* __restrict__ info,
-                                                     const int store_l, LdsT& lds) {
+                                                     const int store_l, LdsT& lds, const double* slot_ext = nullptr) {
   constexpr int W = NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
   constexpr int WP = ReducedLds<NX, NU>::WP, SLOT = RedSlot<NX>::SIZE;
   // slot and [A | B] are dead once the tile and the panel columns are in registers: the tiles of the
   // pass (McWyLayout) lie over them
-  double* slot = lds.buf;          // DL | DR | CA | CB | gL | gR of this separator
+  const double* slot = EXT ? slot_ext : lds.buf;  // DL | DR | CA | CB | gL | gR of this separator
   double* abs_ = lds.buf + SLOT;   // [A_s | B_s]
   double* rq = lds.rq;             // 1 / [Q_s | R_s], 1 / Q_{s+1}
   double* zs = lds.rh;             // rhs(s), rhs(s+1).lambda | x
@@ -550,7 +556,7 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
     double2 ts[IS];
     double ta[IA], tq[IQ], tr[IR];
 #pragma unroll
-    for (int it = 0; it < IS; ++it) {
+    for (int it = 0; it < (EXT ? 0 : IS); ++it) {
       const int e = lane + 64 * it, ec = e < NS ? e : NS - 1;
       if constexpr (TREE) {
         ts[it].x = __hip_atomic_load(sl + 2 * ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -569,9 +575,9 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
     // last element with its own value): a store under a lane predicate makes the compiler sink the
     // load behind the predicate too, and the loads then complete one after the other.
 #pragma unroll
-    for (int it = 0; it < IS; ++it) {
+    for (int it = 0; it < (EXT ? 0 : IS); ++it) {
       const int e = lane + 64 * it, ec = e < NS ? e : NS - 1;
-      reinterpret_cast<double2*>(slot)[ec] = ts[it];
+      reinterpret_cast<double2*>(lds.buf)[ec] = ts[it];
     }
 #pragma unroll
     for (int it = 0; it < IA; ++it) {
@@ -643,6 +649,114 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void re
 }
 
 
+// The level-2 separator s = base + 3 of bottom8_reduced_mc from its leaf tile (registers) and its slot (LDS): what
+// reduced_separator_mc does behind its loads and its leaf tile, in two parts with a workgroup barrier between them.
+// Part 1 (first wavefront): S-bar assembly and the pass (chol_wy_mc) -> the tiles Y0, Y1, W in `buf`.
+template <int NX, int NU>
+__device__ __forceinline__ void reduced_eliminate_pass_mc(const Dims& d, const int base, const int b, const int lane,
+                                                          const acc4_t& c_leaf, const double* slot,
+                                                          int* __restrict__ info, double* buf) {
+  constexpr int NN = NX * NX, TRI = RedSlot<NX>::TRI;
+  const int N = d.N, T = 8;
+  const bool hasA = base > 0, hasB = base + T < N;
+  const int li = lane & 15, lk = lane >> 4, ri = li < NX ? li : NX - 1;
+  const double *DL = slot, *DR = slot + TRI, *CA = slot + 2 * TRI, *CB = slot + 2 * TRI + NN;
+  const double *gL = slot + 2 * TRI + 2 * NN, *gR = slot + 2 * TRI + 2 * NN + NX;
+  acc4_t c0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+    const int tix = RedSlot<NX>::tri(ic, ri);
+    const double dd = DL[tix] + DR[tix], gg = gL[ic] + gR[ic];
+    c0[g] = c_leaf[g] - (li == NX ? gg : dd);
+  }
+  double wcol[NX];
+  {
+    const int h = lane & 31;
+    const bool is_a = h < NX, is_b = h > NX && h <= 2 * NX;
+    const double* src = is_a ? CA + h : CB + (is_b ? h - NX - 1 : 0);
+    const double sign = ((is_a && hasA) || (is_b && hasB)) ? -1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) wcol[k] = src[k * NX] * sign;
+  }
+  wave_lds_sync();
+  if (chol_wy_mc<NX>(lane, c0, buf, wcol, nullptr) && lane == 0) flag_failure(info, d, b);
+}
+// Part 2, shared by the two wavefronts: `gram` -- the Gram products of Y and the pushes (atomic adds behind the groups'
+// plain stores); else -- X = W'Y and the record.
+template <int NX, int NU>
+__device__ __forceinline__ void reduced_eliminate_tail_mc(const Dims& d, const int base, const int b, const int lane,
+                                                          const bool gram, double* red, double* __restrict__ rec,
+                                                          const double* buf) {
+  using P = McWyLayout<NX>;
+  constexpr int NN = NX * NX, KS = P::KS;
+  const int N = d.N, T = 8, s = base + 3;
+  const bool hasA = base > 0, hasB = base + T < N, leftchild = (base & T) == 0;
+  const int li = lane & 15, lk = lane >> 4;
+  double y0[KS], y1[KS];
+  acc4_t Z0 = {0.0, 0.0, 0.0, 0.0}, Z1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    y0[q] = buf[P::Y0 + (4 * q + lk) * P::YP + li];
+    y1[q] = buf[P::Y1 + (4 * q + lk) * P::YP + li];
+    Z0[q] = y0[q]; Z1[q] = y1[q];
+  }
+  if (gram) {  // (uniform per wavefront)
+    const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
+    const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
+    acc4_t g00, g01, g11, unused;
+    gram_mc<NX, true, true, false, true>(y0, y1, Z0, Z1, g00, g01, unused, g11);
+    const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
+    push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(), StorePlain());
+  } else {
+    double wt[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) wt[q] = buf[P::W + (4 * q + lk) * P::WP + li];
+    acc4_t X0 = {0.0, 0.0, 0.0, 0.0}, X1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y0[q], X0, 0, 0, 0);
+      X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y1[q], X1, 0, 0, 0);
+    }
+    store_record_mc<NX>(rec + ((size_t)b * N + s) * (2 * NN + NX), lane, hasA, hasB, X0, X1);
+  }
+}
+
+// Leaf phase + tree levels 0, 1 AND 2 in one launch: a workgroup of two wavefronts per EIGHT knots (round 4). Each wavefront
+// runs the four-knot group of bottom_reduced_mc; what the two groups push to the level-2 separator m = k0 + 3 between
+// them -- DL | gL | CA from the left group, DR | gR | CB from the right one -- goes to a slot in LDS instead of `red`, and
+// behind a workgroup barrier the first wavefront takes m through the pass, from there and from the leaf tile it formed
+// while [A_m | B_m] was staged (nothing is loaded from memory behind the barrier: the other wavefront's slot idles
+// meanwhile); behind a second barrier the two wavefronts share the tail (Gram products + pushes / X = W'Y + record).
+// Gone: the level-2 launch, the slot of every level-2 separator (written by pushes, read back: 480 + 324 doubles per eight knots) and its
+// second read of [A | B] are gone; m's own pushes to the separators k0 - 1 and k0 + 7 follow the groups' plain stores
+// as atomic adds (the groups' stores are acknowledged before the barrier), like those of a level launch.
+//   grid (N / 8, batch), block 128; N >= 16 (a level-3 separator exists); compact level-0 records.
+template <int NX, int NU>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void bottom8_reduced_mc(
+    Dims d, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs, double* red,
+    double* __restrict__ rec, int* __restrict__ info) {
+  __shared__ ReducedLds<NX, NU> lds[2];
+  __shared__ __attribute__((aligned(16))) double mslot[RedSlot<NX>::SIZE];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.y;
+  const int kw = (blockIdx.x + d.xoff) * 8;
+  int lane = threadIdx.x & 63;
+  // (parts of the slot that no group writes -- the coupling to a neighbour that does not exist -- are read and
+  //  multiplied by zero: they have to be finite)
+  for (int e = threadIdx.x; e < RedSlot<NX>::SIZE; e += 128) mslot[e] = 0.0;
+  __syncthreads();
+  acc4_t c_m = {0.0, 0.0, 0.0, 0.0};  // leaf tile of m (the first wavefront: it has [A_m | B_m] staged)
+  bottom_group_mc<NX, NU, false, true>(d, kw + 4 * wave, b, lane, AB, QR, rhs, red, rec, nullptr, info, 0, 1, lds[wave],
+                                       wave == 1 ? mslot : nullptr, wave == 0 ? mslot : nullptr, wave == 0, &c_m);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's plain stores to k0 - 1 / k0 + 7 are acknowledged
+  __syncthreads();
+  asm volatile("" : "+v"(lane));
+  if (wave == 0) reduced_eliminate_pass_mc<NX, NU>(d, kw, b, lane, c_m, mslot, info, lds[0].buf);
+  __syncthreads();
+  // (the tail is shared: the first wavefront forms the Gram products and pushes, the second X = W'Y and the record)
+  reduced_eliminate_tail_mc<NX, NU>(d, kw, b, lane, wave == 0, red, rec, lds[0].buf);
+}
+
 // The top of the tree in ONE launch: the last three levels (4 + 2 + 1 separators per problem), one workgroup of four
 // wavefronts per problem, one separator per wavefront and level, a workgroup barrier between levels. These levels
 // are bound by the latency of a single wavefront (~4.5 us per separator however few there are), and as launches of
@@ -698,11 +812,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 // Every accumulator element still receives its additions in a fixed order: its contributors are
 // the separators along one spine of the subtree below it, and each of them finishes its pushes
 // before its parent starts.
-template <int NX, int NU, bool TREE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bottom_reduced_mc(
-    Dims d, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
-    double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l, int* cnt,
-    const int compact0) {
+// The four knots k0 .. k0 + 3 of problem b by one wavefront: leaf phase + tree levels 0 and 1 (body of bottom_reduced_mc
+// and of bottom8_reduced_mc). slotA / slotB: where the group's pushes to the separators k0 - 1 / k0 + 3 go instead of
+// their slots in `red` (bottom8_reduced_mc: the level-2 separator between its two groups lives in LDS); null: `red`.
+template <int NX, int NU, bool TREE, bool REDIRECT>
+__device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, const int b, const int lane,
+                                                const double* __restrict__ AB, const double* __restrict__ QR,
+                                                const double* __restrict__ rhs, double* red, double* __restrict__ rec,
+                                                double* F, int* __restrict__ info, const int store_l, const int compact0,
+                                                ReducedLds<NX, NU>& lds, double* slotA, double* slotB,
+                                                const bool with_m = false, acc4_t* c_m = nullptr) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
   constexpr int REC = 2 * NN + NX;
   // row pitch of the staged [A | B]: even W padded by two doubles so that the 16 rows an operand
@@ -710,11 +829,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   constexpr int WP = ReducedLds<NX, NU>::WP;
   // the staged [A | B] is dead once the leaf tiles and coupling fragments are in registers: the
   // core's scratch lies over it
-  __shared__ ReducedLds<NX, NU> lds;
   double* abs_ = lds.buf;            // [A | B] of the four knots
   double* rq = lds.rq;               // 1 / [Q | R] of the four knots
   double* rh = lds.rh;               // their raw right-hand sides
-  const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = (blockIdx.x + d.xoff) * 4;
+  const int N = d.N;
   const int li = lane & 15, lk = lane >> 4;
   const int ri = li < NX ? li : NX - 1;
   const bool hasA = k0 > 0, hasB = k0 + 4 < N;  // separators k0 - 1 / k0 + 3 exist
@@ -771,6 +889,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   acc4_t c_t = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + NX * WP, rq + W, rq + 2 * W, rh + ROWS, rh + 2 * ROWS, none);
   acc4_t c_s2 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + 2 * NX * WP, rq + 2 * W, rq + 3 * W, rh + 2 * ROWS,
                                          rh + 3 * ROWS, none);
+  if constexpr (REDIRECT) {
+    // bottom8_reduced_mc, the wavefront that will eliminate the level-2 separator m = k0 + 3 behind the workgroup barrier:
+    // the leaf tile of m now, while [A_m | B_m] is staged (no load from memory stands between the barrier and the
+    // elimination: the other wavefront's slot idles meanwhile). Knot m + 1 is the other wavefront's: its weights and
+    // right-hand side come from memory, one element per lane, and reach the lanes that need them by shuffles.
+    if (with_m) {
+      const double* qn = QR + ((size_t)b * N + k0 + 4) * W;      // Q_{m+1}
+      const double* rn = rhs + ((size_t)b * N + k0 + 4) * ROWS;  // rhs(m+1): lambda | x | ..
+      const int e = lane < 3 * NX ? lane : 3 * NX - 1;
+      const double raw = e < NX ? qn[e] : rn[e - NX];
+      const double val = e < NX ? 1.0 / raw : raw;  // (one division per wavefront, like the staged weights)
+      double nw[4], nl[4], nxv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = lk + 4 * g, ic = i < NX ? i : NX - 1;
+        nw[g] = __shfl(val, ic, 64); nl[g] = __shfl(val, NX + ic, 64); nxv[g] = __shfl(val, 2 * NX + ic, 64);
+      }
+      *c_m = leaf_tile_mc<NX, NU, WP, false>(lane, false, abs_ + 3 * NX * WP, rq + 3 * W, rq, rh + 3 * ROWS, rh, none);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = lk + 4 * g;
+        (*c_m)[g] += li == NX ? -fma(nxv[g], nw[g], nl[g]) : (i == li ? nw[g] : 0.0);
+      }
+    }
+  }
   acc4_t X0, X1, unused;
   double* myrec = rec + ((size_t)b * N + k0) * REC;
   // what the two level-0 separators hand to t and to the neighbours of the group (the Gram products take (R, X) or,
@@ -883,8 +1026,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
     wave_lds_sync();  // the S-bar tile of the pass goes over the coupling tiles
   }
   const bool leftchild = (k0 & 4) == 0;
-  const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
-  const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
+  RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? k0 - 1 : 3);
+  RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? k0 + 3 : 3);
+  if constexpr (REDIRECT) {
+    if (slotA) sa.p = slotA;
+    if (slotB) sb.p = slotB;
+  }
   if (chol_wy_mc<NX>(lane, c_t, lds.buf, wcol, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr) && lane == 0)
     flag_failure(info, d, b);
   tail_wy_mc<NX>(lane, lds.buf, X0, X1,
@@ -904,6 +1051,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bo
   __builtin_amdgcn_s_waitcnt(0);
 #endif
   SEG(36);
+}
+
+template <int NX, int NU, bool TREE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bottom_reduced_mc(
+    Dims d, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
+    double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l, int* cnt,
+    const int compact0) {
+  __shared__ ReducedLds<NX, NU> lds;
+  const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = (blockIdx.x + d.xoff) * 4;
+  bottom_group_mc<NX, NU, TREE, false>(d, k0, b, lane, AB, QR, rhs, red, rec, F, info, store_l, compact0, lds, nullptr,
+                                       nullptr);
 
   if constexpr (TREE) {
     int l = 1, base = k0;  // finished: the level-l separator of subtree [base, base + 2^(l+1))

@@ -84,6 +84,7 @@ static int launch_small(NdlqrHipCtx* c) {
       // records have to serve a record-based re-solve (KEEP_RECORDS) or the tree schedule runs
       const bool compact = plan.compact;
       c->schedule = tree ? "reduced-tree" : (compact ? "reduced" : "reduced-records");
+      bool fuse2 = false;
       {
         ScopedSlot t(c, SLOT_BOTTOM);
         bool launched = false;
@@ -94,7 +95,15 @@ static int launch_small(NdlqrHipCtx* c) {
             launched = true;
           }
         }
+        // NDLQR_FUSE2=1: levels 0-2 in one launch (bottom8_reduced_mc: two wavefronts per eight knots, the level-2 slot
+        // in LDS). Not the default: 12 % less HBM traffic and one launch less per step, but the level-2 work costs inside
+        // the bottom launch what it costs outside -- step 0.572 -> 0.566 ms on one box (profiles/r04_fuse2_ab.txt)
+        fuse2 = !launched && !tree && compact && !store_l && c->fuse2 > 0;
+        if (fuse2) c->schedule = "reduced-fused2";
         if (launched) {
+        } else if (fuse2) {
+          hipLaunchKernelGGL((ndlqr::bottom8_reduced_mc<NX, NU>), dim3(d.N >> 3, d.batch), dim3(128), 0, c->stream, d,
+                             c->AB, c->QR, c->rhs, c->red, c->rec, c->info);
         } else if (tree)
           hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, true>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream,
                              d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, c->tree_cnt, 0);
@@ -105,7 +114,7 @@ static int launch_small(NdlqrHipCtx* c) {
       // upper levels: one launch per level while a level has more than four separators per problem, then the
       // last three levels in one launch (reduced_top_mc; NDLQR_NO_TOP=1: a launch per level to the root)
       const int ltop = (d.K >= 5 && !c->no_top) ? d.K - 3 : d.K;
-      for (int l = 2; l < ltop && !tree; ++l) {
+      for (int l = fuse2 ? 3 : 2; l < ltop && !tree; ++l) {
         ScopedSlot t(c, SLOT_UPPER);
         hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,
                            d, l, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l);
@@ -116,7 +125,8 @@ static int launch_small(NdlqrHipCtx* c) {
                               sizeof(double) * (size_t)(d.N >> 3) * NX <= 4 * sizeof(ndlqr::ReducedLds<NX, NU, false>);
       if (!tree && ltop < d.K) {
         ScopedSlot t(c, SLOT_TOP);  // (a profile slot of its own: one kernel name per slot, like rocprofv3's per-kernel averages)
-        hipLaunchKernelGGL((ndlqr::reduced_top_mc<NX, NU>), dim3(d.batch), dim3(256), 0, c->stream, d, ltop, c->AB,
+        const int l0 = (fuse2 && ltop < 3) ? 3 : ltop;  // (level 2 went with the bottom launch)
+        hipLaunchKernelGGL((ndlqr::reduced_top_mc<NX, NU>), dim3(d.batch), dim3(256), 0, c->stream, d, l0, c->AB,
                            c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, top_sweeps ? c->ytop : (double*)nullptr);
       }
       ScopedSlot t(c, SLOT_APPLY);

@@ -51,11 +51,37 @@ def compulsory_bytes(n, m, N):
     return 8 * (inputs_doubles(n, m, N) + N * (2 * n + m))
 
 
-def reduced_model(n, m, N, compact_level0=False):
+def reduced_model(n, m, N, compact_level0=False, fused2=False):
     """Separator-only ("reduced") schedule of the size-specialised shapes: bottom kernel (leaf phase +
     tree levels 0, 1), one launch per upper level, back-substitution. Returns
-    {slot: {"bytes": per solve, "flops": per solve, "launches": per solve}}."""
+    {slot: {"bytes": per solve, "flops": per solve, "launches": per solve}}.
+    fused2 (round 4, bottom8_reduced_mc): the bottom launch also eliminates the level-2 separators, whose slots live in
+    LDS -- per eight knots it stores the two groups' shares of the outer separators, adds the level-2 separator's
+    (two symmetric blocks + two vectors each, one coupling block) and writes the level-2 record."""
     K = int(math.log2(N))
+    if fused2 and N >= 16:
+        base = reduced_model(n, m, N, compact_level0, False)
+        w, rows = n + m, 2 * n + m
+        tri = n * (n + 1) // 2
+        rec0, rec = record_doubles(n, 0, compact_level0), record_doubles(n, 1)
+        fs = separator_flops(n, w)
+        push = 2 * tri + n * n + 2 * n
+        slot = 2 * tri + 2 * n * n + 2 * n
+        per_sep = slot + n * w + w + n + rows + 2 * n + rec + push   # an upper-level separator in a launch of its own
+        nsep2 = N // 8
+        base["bottom"] = {"bytes": 8 * (inputs_doubles(n, m, N) + (N // 2) * rec0 + (N // 4 + nsep2) * rec +
+                                       nsep2 * (4 * (tri + n) + n * n)),
+                          "flops": (3 * N // 4 + nsep2) * fs, "launches": 1}
+        if "upper" in base:
+            left = base["upper"]["bytes"] // 8 // per_sep - nsep2   # separators still eliminated by level launches
+            if left > 0:
+                base["upper"] = {"bytes": 8 * left * per_sep, "flops": left * fs, "launches": base["upper"]["launches"] - 1}
+            else:
+                del base["upper"]
+        elif "top" in base and K == 5:   # the top launch is left with levels 3 and 4
+            sweep_b = (N // 8 - 1) * rec + (N // 8) * n
+            base["top"] = {"bytes": 8 * (3 * per_sep + sweep_b), "flops": 3 * fs + (N // 8 - 1) * 4 * n * n, "launches": 1}
+        return base
     w, rows = n + m, 2 * n + m
     tri = n * (n + 1) // 2        # DL, DR are symmetric: packed lower triangles (round 3)
     push = 2 * tri + n * n + 2 * n      # what one four-knot group / one upper separator pushes to its neighbours
@@ -177,6 +203,8 @@ def model_for(schedule, n, m, N):
     model for it (strict / KEEP schedules stream the whole factor array: model (B) is their roofline)."""
     if schedule == "reduced":  # compact level-0 records, two-launch back-substitution
         return reduced_model(n, m, N, compact_level0=True)
+    if schedule == "reduced-fused2":  # ... with tree level 2 inside the bottom launch (NDLQR_FUSE2=1)
+        return reduced_model(n, m, N, compact_level0=True, fused2=True)
     if schedule in ("reduced-tree", "reduced-records"):
         return reduced_model(n, m, N)
     if schedule == "knot-lean":

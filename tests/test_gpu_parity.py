@@ -461,6 +461,46 @@ def test_env_variants_fast_mode(ndlqr, oracle):
         assert err <= REL_TOL, (env, err)
 
 
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 256, 40), (12, 4, 16, 200), (12, 4, 32, 100), (13, 4, 64, 60), (9, 3, 128, 40),
+                                         (11, 3, 64, 48)])
+def test_fused_bottom_launch(ndlqr, oracle, n, m, N, batch):
+    """NDLQR_FUSE2=1: tree level 2 inside the bottom launch (bottom8_reduced_mc: two wavefronts per eight knots, the
+    level-2 separator's slot in LDS, its tail shared by the two wavefronts) -- an opt-in alternative of the level-per-launch
+    schedule (12 % less traffic, same kernel time). Same tolerance as the default; the weak-input-cost family too;
+    horizons of 16 and 32 knots exercise the top launch starting at level 3 / the root as a level launch."""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+        "import rslqr_amd as R\n"
+        "n, m, N, batch = %d, %d, %d, %d\n"
+        "out = {}\n"
+        "for fam, rs in (('benign', 1.0), ('weakR', 1e-4)):\n"
+        "    gs = [R.generate_synthetic(n, m, N, 60 + p) for p in range(batch)]\n"
+        "    for g in gs: g['R'] *= rs\n"
+        "    bs = R.BatchSolver(n, m, N, batch)\n"
+        "    bs.initialize_flat(*[np.stack([g[k] for g in gs]) for k in ('A','B','Q','R','q','r','d','x0')])\n"
+        "    assert bs.solve() == 0 and bs.solve() == 0\n"
+        "    res, bn = bs.kkt_residuals()\n"
+        "    out[fam] = dict(schedule=bs.schedule(), sol=bs.solutions()[[0, batch - 1]].tolist(), kkt=float((res / np.maximum(1.0, bn)).max()))\n"
+        "    bs.close()\n"
+        "print(json.dumps(out))\n" % (root, n, m, N, batch))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NDLQR_FUSE2="1", NDLQR_TREE="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for fam, rs in (("benign", 1.0), ("weakR", 1e-4)):
+        assert out[fam]["schedule"] == ("reduced-fused2" if n >= 9 else "reduced"), out[fam]["schedule"]
+        assert out[fam]["kkt"] <= 1e-9
+        for row, p in enumerate((0, batch - 1)):
+            g = ndlqr.generate_synthetic(n, m, N, 60 + p)
+            g["R"] = g["R"] * rs
+            prob = Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+            ref = oracle.solve(prob, 4)[0][: prob.nvars]
+            got = np.array(out[fam]["sol"][row])
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= REL_TOL, (fam, p)
+
+
 @pytest.mark.parametrize("n,m,N,batch", [(12, 4, 256, 32), (6, 3, 256, 48), (13, 4, 512, 24), (7, 9, 256, 40)])
 def test_tree_schedule_fills_the_chip(ndlqr, oracle, n, m, N, batch):
     """The one-launch tree schedule at sizes where its bottom wavefronts (e.g. 32 x 256 / 4 = 2048) spread
