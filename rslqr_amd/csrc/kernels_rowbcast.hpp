@@ -561,12 +561,22 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
     constexpr int NQ = KPB * W, NR = KPB * ROWS;
     static_assert(NQ <= 256 && NR <= 256, "one load per thread for the vectors");
     static_assert((KPB * NX * W) % 2 == 0, "eight knots of [A | B] are whole 16-byte words");
-    double2 ta[IA];
+    // [A | B]: where a knot is a whole number of 32-thread rounds of 16-byte words (96 at (12,4)), thread t takes words
+    // (t & 31) + 32 j of knot t >> 5 -- the same coalescing, and no division by the knot size in the index arithmetic
+    // (the constant divisions of the staging indices were a sixth of this kernel's vector instructions)
+    constexpr int KW = NX * W / 2;                                             // 16-byte words per knot (W even)
+    constexpr bool BYKNOT = (NX * W) % 2 == 0 && KW % 32 == 0;
+    constexpr int JA = BYKNOT ? KW / 32 : IA;
+    double2 ta[JA];
     double t0[I0][G], t1[I1][G];
 #pragma unroll
-    for (int it = 0; it < IA; ++it) {
-      const int e = t + 256 * it;
-      ta[it] = reinterpret_cast<const double2*>(abm)[e < NA ? e : NA - 1];
+    for (int it = 0; it < JA; ++it) {
+      if constexpr (BYKNOT) {
+        ta[it] = reinterpret_cast<const double2*>(abm)[(t >> 5) * KW + (t & 31) + 32 * it];
+      } else {
+        const int e = t + 256 * it;
+        ta[it] = reinterpret_cast<const double2*>(abm)[e < NA ? e : NA - 1];
+      }
     }
 #pragma unroll
     for (int it = 0; it < I0; ++it) {
@@ -590,13 +600,18 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
       if (sx >= 0 && sx < N - 1) ty = ytop[((size_t)b * (N >> 3) + (sx >> 3)) * NX + (t < NX ? t : t - NX)];
     }
 #pragma unroll
-    for (int it = 0; it < IA; ++it) {
-      const int e = t + 256 * it, ec = e < NA ? e : NA - 1;
+    for (int it = 0; it < JA; ++it) {
+      if constexpr (BYKNOT) {
+        const int w_ = 2 * ((t & 31) + 32 * it), row = w_ / W, c = w_ - row * W;  // (W even: both doubles in one row)
+        *reinterpret_cast<double2*>(&lds.ab[t >> 5][row * WP + c]) = ta[it];
+      } else {
+        const int e = t + 256 * it, ec = e < NA ? e : NA - 1;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {  // (the two doubles of a word may sit in different rows when W is odd)
-        const int ed = 2 * ec + h, kn = ed / (NX * W), w_ = ed - kn * NX * W;
-        const int row = w_ / W, c = w_ - row * W;
-        lds.ab[kn][row * WP + c] = h ? ta[it].y : ta[it].x;
+        for (int h = 0; h < 2; ++h) {  // (the two doubles of a word may sit in different rows when W is odd)
+          const int ed = 2 * ec + h, kn = ed / (NX * W), w_ = ed - kn * NX * W;
+          const int row = w_ / W, c = w_ - row * W;
+          lds.ab[kn][row * WP + c] = h ? ta[it].y : ta[it].x;
+        }
       }
     }
 #pragma unroll
