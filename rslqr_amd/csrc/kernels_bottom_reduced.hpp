@@ -885,7 +885,10 @@ __device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, con
   SEG(20);
 
   auto none = [](int) { return 0.0; };
-  acc4_t c_s0 = leaf_tile_mc<NX, NU, WP>(lane, k0 == 0, abs_, rq, rq + W, rh, rh + ROWS, none);
+  // (knot 0 -- fixed state -- is one wavefront in N / 4: a uniform branch keeps its selects out of everybody else's tile)
+  acc4_t c_s0;
+  if (k0 == 0) c_s0 = leaf_tile_mc<NX, NU, WP>(lane, true, abs_, rq, rq + W, rh, rh + ROWS, none);
+  else c_s0 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_, rq, rq + W, rh, rh + ROWS, none);
   acc4_t c_t = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + NX * WP, rq + W, rq + 2 * W, rh + ROWS, rh + 2 * ROWS, none);
   acc4_t c_s2 = leaf_tile_mc<NX, NU, WP>(lane, false, abs_ + 2 * NX * WP, rq + 2 * W, rq + 3 * W, rh + 2 * ROWS,
                                          rh + 3 * ROWS, none);

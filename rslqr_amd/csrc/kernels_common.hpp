@@ -84,6 +84,9 @@ __device__ unsigned long long ndlqr_seg[128];  // [k] cycle sums, [64 + k] sampl
     seg_last = seg_now;                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                 \
   } while (0)
+#elif defined(NDLQR_ISA_MARK)  // developer builds: segment boundaries as comments in the assembly (static instruction counts per phase)
+#define SEG_INIT() do {} while (0)
+#define SEG(k) asm volatile("; SEGMARK %0" ::"n"(k) : "memory")
 #else
 #define SEG_INIT() do {} while (0)
 #define SEG(k) do {} while (0)
