@@ -163,3 +163,21 @@ def test_mpc_batch_example(ndlqr, tmp_path, args):
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("re-solve") >= 2
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [[], ["6", "3", "32", "7", "5"], ["7", "9", "16", "3", "4"], ["20", "6", "16", "4", "3"]])
+def test_mpc_step_example(ndlqr, tmp_path, args):
+    """examples/mpc_step.c: the asynchronous MPC step in plain C -- x0 up, factor + solve, u of knot 0 down
+    (ndlqr_BatchSetStepSelection), two steps in flight on pinned host memory; the program checks the KKT residual of
+    every problem on the device and the slice against the resident solution (specialised, padded and generic shapes)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mpc_step")
+    libdir = os.path.dirname(ndlqr.library_path())
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "mpc_step.c"), "-L" + libdir, "-lrslqr_amd",
+                    "-Wl,-rpath," + libdir, "-lm", "-o", exe], check=True)
+    out = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "matches the resident solution" in out.stdout
