@@ -2,11 +2,16 @@
 // (separator-only) system, no knot states at all. Default path of the batch API for the instances
 // with matrix-core products (6 <= nstates <= 15).
 //
-//   bottom_reduced_mc   leaf phase + tree levels 0 and 1, one wavefront per four consecutive knots
+//   bottom_reduced_mc   leaf phase + tree levels 0 and 1, one wavefront per four consecutive knots (bottom_group_mc)
 //                       (TREE: the wavefront climbs on through the upper levels on arrival counters)
+//   bottom8_reduced_mc  the same for eight knots per two-wavefront workgroup with tree level 2 behind it, the level-2
+//                       slot in LDS (opt-in: NDLQR_FUSE2=1)
 //   reduced_level_mc    one upper level, one wavefront per separator (reduced_separator_mc)
-//   factor_solve_mc     the separator core: fused Cholesky + inverse on the vector ALU, everything
-//                       else as v_mfma_f64_16x16x4_f64 products chained through accumulator registers
+//   reduced_top_mc      the last three levels + the top-down sweep of the back-substitution, one workgroup per problem
+//   the separator core  chol_pair_y_mc / chol_wy_mc (the Cholesky pass on the vector ALU, one row of S-bar per lane of
+//                       every 16-lane DPP row; the panel -- and for separators that keep full records the unit
+//                       vectors -- ride through it, one column per lane) + v_mfma_f64_16x16x4_f64 products chained
+//                       through accumulator registers (tail_wy_mc, factor_tail_mc, gram_mc)
 //
 // eliminating the states and inputs of every knot (ndlqr_SolveLeaf,
 // src/nested_dissection.c:10-105) leaves a block-tridiagonal system in the multipliers,
@@ -239,7 +244,7 @@ __device__ __forceinline__ bool chol_pair_mc(const int lane_in, const acc4_t& cA
   const bool bad = rb_chol_inv<NX>(li, acc, w);
   wave_lds_sync();  // (every lane has its row of S-bar: W_B may overwrite tile A)
   {  // rows 0-1 store W_A, rows 2-3 W_B, every lane its column (two identical copies each: benign duplicates;
-     // unconditional stores, see factor_solve_mc)
+     // unconditional stores, see chol_wy_mc)
     double* wdst = buf + (lk < 2 ? P::W_A : P::W_B) + li;
 #pragma unroll
     for (int r = 0; r < NX; ++r) wdst[r * WP] = w[r];
