@@ -114,11 +114,13 @@ def _rank_main(rank, world, port, n, m, N, outdir):
     dist.destroy_process_group()
 
 
-def test_time_axis_two_ranks(ndlqr, oracle, tmp_path):
-    """Two rank PROCESSES (gloo; both on the one GPU of the test box -- with a GPU each the same code runs over RCCL),
-    rslqr_amd.sharding.solve_time_sharded: batch 1, (12,4), N = 4096."""
+@pytest.mark.parametrize("world,N", [(2, 4096), (4, 2048)])
+def test_time_axis_rank_processes(ndlqr, oracle, tmp_path, world, N):
+    """Rank PROCESSES (gloo; all on the one GPU of the test box -- with a GPU each the same code runs over RCCL),
+    rslqr_amd.sharding.solve_time_sharded: batch 1, (12,4), N = 4096 over two ranks, N = 2048 over four (the top TWO
+    levels eliminated redundantly by every rank, three slots in the all-reduce)."""
     import torch.multiprocessing as mp
-    n, m, N, world = 12, 4, 4096, 2
+    n, m = 12, 4
     mp.spawn(_rank_main, args=(world, _free_port(), n, m, N, str(tmp_path)), nprocs=world, join=True)
     whole = np.load(tmp_path / "whole.npy")
     _, prob = _problem(ndlqr, n, m, N, 71)
