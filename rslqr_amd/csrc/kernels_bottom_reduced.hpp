@@ -513,6 +513,9 @@ struct alignas(16) ReducedLds {
   double buf[NBUF];
   double rq[NRQ];
   double rh[NRH];
+#ifdef NDLQR_DEV_LDS_PAD  // developer builds: fewer wavefronts per CU (occupancy experiments)
+  double dev_pad[BOTTOM ? NDLQR_DEV_LDS_PAD / 8 : 1];
+#endif
 };
 
 // One separator of an upper level (l >= 2) of the separator-only schedule on the matrix-core core
@@ -737,6 +740,13 @@ __device__ __forceinline__ void reduced_eliminate_tail_mc(const Dims& d, const i
 // second read of [A | B] are gone; m's own pushes to the separators k0 - 1 and k0 + 7 follow the groups' plain stores
 // as atomic adds (the groups' stores are acknowledged before the barrier), like those of a level launch.
 //   grid (N / 8, batch), block 128; N >= 16 (a level-3 separator exists); compact level-0 records.
+template <int NX, int NU, bool TREE, bool REDIRECT>
+__device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, const int b, const int lane,
+                                                const double* __restrict__ AB, const double* __restrict__ QR,
+                                                const double* __restrict__ rhs, double* red, double* __restrict__ rec,
+                                                double* F, int* __restrict__ info, const int store_l, const int compact0,
+                                                ReducedLds<NX, NU>& lds, double* slotA, double* slotB,
+                                                const bool with_m = false, acc4_t* c_m = nullptr);  // (below)
 template <int NX, int NU>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void bottom8_reduced_mc(
     Dims d, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs, double* red,
@@ -826,7 +836,7 @@ __device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, con
                                                 const double* __restrict__ rhs, double* red, double* __restrict__ rec,
                                                 double* F, int* __restrict__ info, const int store_l, const int compact0,
                                                 ReducedLds<NX, NU>& lds, double* slotA, double* slotB,
-                                                const bool with_m = false, acc4_t* c_m = nullptr) {
+                                                const bool with_m, acc4_t* c_m) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, KSN = (NX + 3) / 4;
   constexpr int REC = 2 * NN + NX;
   // row pitch of the staged [A | B]: even W padded by two doubles so that the 16 rows an operand
