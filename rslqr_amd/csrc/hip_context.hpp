@@ -53,9 +53,6 @@ struct NdlqrAltSlot {
   hipGraphExec_t graph_exec = nullptr;
   unsigned graph_flags = 0;
   hipStream_t graph_stream = nullptr;
-  hipGraphExec_t graph_cs[2] = {nullptr, nullptr};  // co-scheduled launch sequences of this set (NdlqrHipCtx::graph_cs)
-  unsigned graph_cs_flags[2] = {0, 0};
-  hipStream_t graph_cs_stream[2] = {nullptr, nullptr};
   bool graph_rec_complete = false;
   const char* graph_schedule = "none";
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -134,18 +131,6 @@ struct NdlqrHipCtx {
   unsigned graph_flags;
   hipStream_t graph_stream;
   bool fact_valid;   // the device holds a complete factorisation (last solve ran with KEEP_FACT)
-  // Co-scheduled solves (kernels_cosched.hpp): the bottom levels of a solve and the back-substitution of the solve
-  // before it -- which lives in the other buffer set -- in ONE launch. A solve then enqueues [bottom (+ the previous
-  // solve's back-substitution)] -> levels -> top and leaves its own back-substitution pending; the next solve picks
-  // it up, or whoever needs the solution, the streams or the inputs launches it alone (cosched_flush).
-  int cosched;           // NDLQR_COSCHED=0 / 1; default 1 (only the pipelined separator-only schedule has the kernel)
-  int cosched_mode;      // what launch_small enqueues: 0 a whole solve, 1 bottom -> top, 2 the same with the other set's
-                         // back-substitution inside the bottom launch, 3 the current set's back-substitution alone
-  bool apply_pending;    // the latest solve's back-substitution has not been enqueued yet
-  int apply_set;         // ... and the buffer set it belongs to (0 primary, 1 alternate)
-  hipGraphExec_t graph_cs[2];   // captured sequences of modes 1 and 2 on the current set
-  unsigned graph_cs_flags[2];
-  hipStream_t graph_cs_stream[2];
   // profile
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;

@@ -535,19 +535,18 @@ struct alignas(16) RbBacksubLds {
   double vs[4][NX];       // v of the four level-0 separators
 };
 
-// (device function: body of rb_backsub and of the back-substitution role of bottom_backsub_mc, kernels_cosched.hpp)
 template <int NX, int NU>
-__device__ __forceinline__ void rb_backsub_body(const Dims& d, const int first, const int b, const int t,
-                                                const double* __restrict__ AB, const double* __restrict__ QR,
-                                                const double* __restrict__ rhs, const double* __restrict__ recs,
-                                                const double* __restrict__ ytop, double* __restrict__ z,
-                                                RbBacksubLds<NX, NU>& lds) {
+__global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+                                                  const double* __restrict__ rhs, const double* __restrict__ recs,
+                                                  const double* __restrict__ ytop, double* __restrict__ z) {
   using Lds = RbBacksubLds<NX, NU>;
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP;
   constexpr int R0 = Lds::R0;
   static_assert(9 * NX <= 256 && KPB * ROWS <= 256, "thread roles fit the workgroup");
-  const int N = d.N;
+  __shared__ Lds lds;
+  const int N = d.N, b = blockIdx.y, first = (blockIdx.x + d.xoff) * KPB;
   auto sep_slot = [&](int s) -> int { return s < first ? 7 : (s >= first + 7 ? 8 : s - first); };
+  const int t = threadIdx.x;
 
   // ---- one round of loads
   {
@@ -747,14 +746,6 @@ __device__ __forceinline__ void rb_backsub_body(const Dims& d, const int first, 
     out = (i == N - 1) ? rv : (rv - dot) * lds.qs[kn][rr - NX];
   }
   z[((size_t)b * N + i) * ROWS + rr] = out;
-}
-
-template <int NX, int NU>
-__global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
-                                                  const double* __restrict__ rhs, const double* __restrict__ recs,
-                                                  const double* __restrict__ ytop, double* __restrict__ z) {
-  __shared__ RbBacksubLds<NX, NU> lds;
-  rb_backsub_body<NX, NU>(d, (blockIdx.x + d.xoff) * 8, blockIdx.y, threadIdx.x, AB, QR, rhs, recs, ytop, z, lds);
 }
 
 }  // namespace ndlqr

@@ -7,7 +7,6 @@
 #include "kernels_small.hpp"
 #include "kernels_bottom_reduced.hpp"
 #include "kernels_rowbcast.hpp"
-#include "kernels_cosched.hpp"
 
 // Size-specialised launch sequences.
 //   separator-only ("reduced"): bottom kernel (leaf phase + levels 0, 1) -> one launch per upper level
@@ -28,7 +27,6 @@ struct SmallPlan {
   bool compact;  // ... with compact level-0 records and the two-launch back-substitution (kernels_rowbcast.hpp)
   bool rowbcast; // ... and the bottom levels on the row-broadcast core (four separators per wavefront)
   bool needs_F;  // the schedule reads or writes the factor array
-  bool cosched;  // ... has the co-scheduled form (bottom_backsub_mc: NdlqrHipCtx::cosched_mode)
 };
 
 template <int NX, int NU, bool STRICT, bool KEEP>
@@ -43,7 +41,6 @@ static SmallPlan plan_small(const NdlqrHipCtx* c) {
   p.tree = false;
   p.rowbcast = false;
   p.compact = false;
-  p.cosched = false;
   if constexpr (!STRICT && !KEEP && ndlqr::P1OnMatrixCores<NX, NU>::value) {
     if (p.lean && c->red) {
       p.reduced = true;
@@ -62,21 +59,11 @@ static SmallPlan plan_small(const NdlqrHipCtx* c) {
       // (10,4) 0.230 vs 0.207, (9,3) 0.203 vs 0.187, (8,4) 0.143 vs 0.152, (6,3) 0.104 vs 0.134 -- so it serves n <= 8
       // (NDLQR_ROWBCAST=0/1 overrides)
       p.rowbcast = p.compact && NX <= 16 && NX + NU <= 16 && (c->rowbcast == 1 || (c->rowbcast < 0 && NX <= 8));
-      // bottom levels + the previous solve's back-substitution in one launch: the matrix-core bottom kernel with
-      // compact records, sixteen knots per triple of workgroups
-      p.cosched = p.compact && !p.rowbcast && c->fuse2 <= 0 && d.N >= 16;
     }
   }
   // the separator-only schedule touches F only to park the factors of KEEP_RECORDS
   p.needs_F = !(p.reduced && !p.store_l);
   return p;
-}
-
-// what ndlqr_hip.hip asks about a plan before a solve: bit 0 needs_F, bit 1 cosched
-template <int NX, int NU, bool STRICT, bool KEEP>
-static int plan_bits_small(const NdlqrHipCtx* c) {
-  const SmallPlan p = plan_small<NX, NU, STRICT, KEEP>(c);
-  return (p.needs_F ? 1 : 0) | (p.cosched ? 2 : 0);
 }
 
 template <int NX, int NU, bool STRICT, bool KEEP>
@@ -97,25 +84,8 @@ static int launch_small(NdlqrHipCtx* c) {
       // records have to serve a record-based re-solve (KEEP_RECORDS) or the tree schedule runs
       const bool compact = plan.compact;
       c->schedule = tree ? "reduced-tree" : (compact ? "reduced" : "reduced-records");
-      // co-scheduled forms (NdlqrHipCtx::cosched_mode; the host asks for them only where plan.cosched holds)
-      const int csm = plan.cosched ? c->cosched_mode : 0;
-      auto launch_apply = [&]() {
-        hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
-                           c->QR, c->rhs, c->rec, c->ytop, c->z);
-      };
-      if (csm == 3) {  // the pending back-substitution of the current set, alone
-        ScopedSlot t(c, SLOT_APPLY);
-        launch_apply();
-        return NDLQR_OK;
-      }
       bool fuse2 = false;
-      if (csm == 2) {  // bottom levels of this set + back-substitution of the other set's solve
-        ScopedSlot t(c, SLOT_BOTTOM);
-        const NdlqrAltSlot& o = c->alt;
-        hipLaunchKernelGGL((ndlqr::bottom_backsub_mc<NX, NU>), dim3(3 * (d.N >> 4), d.batch), dim3(256), 0, c->stream, d,
-                           c->AB, c->QR, c->rhs, c->red, c->rec, c->info, (const double*)o.rhs, (const double*)o.rec,
-                           (const double*)o.ytop, o.z);
-      } else {
+      {
         ScopedSlot t(c, SLOT_BOTTOM);
         bool launched = false;
         if constexpr (NX <= 16 && NX + NU <= 16) {
@@ -159,17 +129,6 @@ static int launch_small(NdlqrHipCtx* c) {
         hipLaunchKernelGGL((ndlqr::reduced_top_mc<NX, NU>), dim3(d.batch), dim3(256), 0, c->stream, d, l0, c->AB,
                            c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, top_sweeps ? c->ytop : (double*)nullptr);
       }
-      if (csm == 1 || csm == 2) {  // this solve's back-substitution stays pending; its top-down sweep does not
-        if (!top_sweeps) {
-          ScopedSlot t(c, SLOT_APPLY);
-          const size_t top_lds = sizeof(double) * (size_t)(d.N >> 3) * NX;
-          if (top_lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ndlqr::rb_backsub_top<NX>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)top_lds);
-          hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256), top_lds, c->stream, d, c->rec, c->ytop);
-        }
-        return NDLQR_OK;
-      }
       ScopedSlot t(c, SLOT_APPLY);
       if (compact) {
         if (!top_sweeps) {
@@ -179,7 +138,8 @@ static int launch_small(NdlqrHipCtx* c) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)top_lds);
           hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256), top_lds, c->stream, d, c->rec, c->ytop);
         }
-        launch_apply();
+        hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+                           c->QR, c->rhs, c->rec, c->ytop, c->z);
       } else {
         hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
                            c->QR, c->rhs, c->rec, c->z);

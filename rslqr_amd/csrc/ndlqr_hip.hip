@@ -116,9 +116,6 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   c->sel_knot0 = 0; c->sel_nknots = 0; c->sel_blocks = 7u; c->step_set[0] = c->step_set[1] = 0;
   c->h_io = nullptr; c->graph_staged = nullptr; c->graph_staged_flags = 0;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;
-  c->cosched = getenv("NDLQR_COSCHED") ? atoi(getenv("NDLQR_COSCHED")) : 0;
-  c->cosched_mode = 0; c->apply_pending = false; c->apply_set = 0;
-  for (int k = 0; k < 2; ++k) { c->graph_cs[k] = nullptr; c->graph_cs_flags[k] = 0; c->graph_cs_stream[k] = nullptr; }
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -169,7 +166,6 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   free_alt(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-  for (hipGraphExec_t& ge : c->graph_cs) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
   if (c->graph_staged) (void)hipGraphExecDestroy(c->graph_staged);
   if (c->h_io) (void)hipHostFree(c->h_io);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
@@ -198,10 +194,6 @@ static void swap_slot(NdlqrHipCtx* c) {
   std::swap(c->graph_exec, a.graph_exec); std::swap(c->graph_flags, a.graph_flags);
   std::swap(c->graph_stream, a.graph_stream); std::swap(c->graph_rec_complete, a.graph_rec_complete);
   std::swap(c->graph_schedule, a.graph_schedule);
-  for (int k = 0; k < 2; ++k) {
-    std::swap(c->graph_cs[k], a.graph_cs[k]); std::swap(c->graph_cs_flags[k], a.graph_cs_flags[k]);
-    std::swap(c->graph_cs_stream[k], a.graph_cs_stream[k]);
-  }
   std::swap(c->ev_start, a.ev_start); std::swap(c->ev_stop, a.ev_stop);
   c->in_alt = !c->in_alt;
 }
@@ -211,12 +203,6 @@ static void free_alt(NdlqrHipCtx* c) {
   NdlqrAltSlot& a = c->alt;
   if (a.stream) (void)hipStreamSynchronize(a.stream);
   if (a.graph_exec) (void)hipGraphExecDestroy(a.graph_exec);
-  // (the co-scheduled sequences of EITHER set hold addresses of the other one)
-  c->apply_pending = false;
-  for (int k = 0; k < 2; ++k) {
-    if (a.graph_cs[k]) (void)hipGraphExecDestroy(a.graph_cs[k]);
-    if (c->graph_cs[k]) { (void)hipGraphExecDestroy(c->graph_cs[k]); c->graph_cs[k] = nullptr; }
-  }
   (void)hipFree(a.rec); (void)hipFree(a.red); (void)hipFree(a.ytop); (void)hipFree(a.z); (void)hipFree(a.tree_cnt);
   (void)hipFree(a.rhs); (void)hipFree(a.xfer);
   if (a.h_fail) (void)hipHostFree(a.h_fail);
@@ -272,9 +258,7 @@ static bool ensure_alt(NdlqrHipCtx* c) {
 }
 
 // every solve in flight on either slot has finished
-static int cosched_flush(NdlqrHipCtx* c);  // below: a pending back-substitution is enqueued first
 static hipError_t sync_all(NdlqrHipCtx* c) {
-  if (cosched_flush(c)) return hipErrorLaunchFailure;
   hipError_t e = c->stream ? hipStreamSynchronize(c->stream) : hipSuccess;
   if (c->alt.stream) { const hipError_t e2 = hipStreamSynchronize(c->alt.stream); if (e == hipSuccess) e = e2; }
   return e;
@@ -329,11 +313,6 @@ int ndlqr_hip_ensure_F(NdlqrHipCtx* c) {
 
 int ndlqr_hip_set_flags(NdlqrHipCtx* c, unsigned flags) {
   if (!c) return NDLQR_ERR_INVALID;
-  if (c->apply_pending) {  // (the pending back-substitution belongs to the schedule of the current flags)
-    HIP_TRY(hipSetDevice(c->device));
-    const int ferr = cosched_flush(c);
-    if (ferr) return ferr;
-  }
   c->flags = flags;
   return NDLQR_OK;
 }
@@ -465,10 +444,6 @@ int ndlqr_hip_device_pointers(NdlqrHipCtx* c, void** out5) {
                    "use ndlqr_hip_pack_flat_device, or NDLQR_NO_PAD=1";
     fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
     return NDLQR_ERR_INVALID;
-  }
-  {
-    const int perr = cosched_flush(c);
-    if (perr) return perr;
   }
   const int ferr = ndlqr_hip_ensure_F(c);  // the caller asks for the factor array: it has to exist
   if (ferr) return ferr;
@@ -743,8 +718,8 @@ struct SmallInstance {
     return keep ? launch_small<NX_, NU_, false, true>(c) : launch_small<NX_, NU_, false, false>(c);           \
   }                                                                                                 \
   int ndlqr_small_needs_F_##NX_##_##NU_(const NdlqrHipCtx* c, bool strict, bool keep) {             \
-    if (strict) return keep ? plan_bits_small<NX_, NU_, true, true>(c) : plan_bits_small<NX_, NU_, true, false>(c); \
-    return keep ? plan_bits_small<NX_, NU_, false, true>(c) : plan_bits_small<NX_, NU_, false, false>(c);           \
+    if (strict) return keep ? plan_small<NX_, NU_, true, true>(c).needs_F : plan_small<NX_, NU_, true, false>(c).needs_F; \
+    return keep ? plan_small<NX_, NU_, false, true>(c).needs_F : plan_small<NX_, NU_, false, false>(c).needs_F;           \
   }                                                                                                 \
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c) { launch_rhs_records<NX_, NU_>(c); }           \
   int ndlqr_small_kpb_##NX_##_##NU_(void) { return ndlqr::SchurShape<NX_, NU_>::KPB; }              \
@@ -808,14 +783,7 @@ static bool try_launch_small(NdlqrHipCtx* c, bool strict, int* err) {
 static bool solve_needs_F(const NdlqrHipCtx* c) {
   const SmallInstance* inst = pick_small(c);
   if (!inst) return !plan_reduced_generic(c).ok;  // the other runtime-sized kernels work on F
-  return (inst->needs_F(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0) & 1) != 0;
-}
-
-// does the schedule of the current flags have the co-scheduled form (kernels_cosched.hpp)?
-static bool solve_can_cosched(const NdlqrHipCtx* c) {
-  const SmallInstance* inst = pick_small(c);
-  if (!inst || c->cosched <= 0 || (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT))) return false;
-  return (inst->needs_F(c, false, false) & 2) != 0;
+  return inst->needs_F(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0) != 0;
 }
 
 // Enqueue leaf/bottom + per-level + apply launches on the context's stream.
@@ -889,38 +857,26 @@ static int launch_solve(NdlqrHipCtx* c) {
   } else {
     // The sequence is a fixed chain of up to 1 + 2K short launches: capture it once as a hipGraph
     // and replay it (launch-bound single solves -- batch 1 -- gain the most).
-    // (the co-scheduled forms of the sequence -- cosched_mode 1, 2 -- are captured sequences of their own)
-    const int gm = c->cosched_mode;
-    hipGraphExec_t& gexec = gm ? c->graph_cs[gm - 1] : c->graph_exec;
-    unsigned& gflags = gm ? c->graph_cs_flags[gm - 1] : c->graph_flags;
-    hipStream_t& gstream = gm ? c->graph_cs_stream[gm - 1] : c->graph_stream;
-    const bool stale = !gexec || gflags != c->flags || gstream != c->stream;
+    const bool stale = !c->graph_exec || c->graph_flags != c->flags || c->graph_stream != c->stream;
     if (stale) {
-      if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+      if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       err = enqueue_solve(c);
       hipError_t e = hipStreamEndCapture(c->stream, &graph);
       if (err) { if (graph) (void)hipGraphDestroy(graph); return err; }
       if (e != hipSuccess) return fail("hipStreamEndCapture", e);
-      e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+      e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
-      if (e != hipSuccess) { gexec = nullptr; return fail("hipGraphInstantiate", e); }
-      gflags = c->flags;
-      gstream = c->stream;
-      if (!gm) {
-        c->graph_rec_complete = c->rec_complete;  // what the captured sequence leaves behind
-        c->graph_schedule = c->schedule;
-      }
+      if (e != hipSuccess) { c->graph_exec = nullptr; return fail("hipGraphInstantiate", e); }
+      c->graph_flags = c->flags;
+      c->graph_stream = c->stream;
+      c->graph_rec_complete = c->rec_complete;  // what the captured sequence leaves behind
+      c->graph_schedule = c->schedule;
     }
-    HIP_TRY(hipGraphLaunch(gexec, c->stream));
-    if (gm) {
-      c->rec_complete = false;
-      c->schedule = "reduced-cosched";
-    } else {
-      c->rec_complete = c->graph_rec_complete;
-      c->schedule = c->graph_schedule;
-    }
+    HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    c->rec_complete = c->graph_rec_complete;
+    c->schedule = c->graph_schedule;
   }
   if (err) return err;
   HIP_TRY(hipGetLastError());
@@ -932,57 +888,16 @@ static int launch_solve(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
-// The latest solve's back-substitution, left pending by the co-scheduled form (hip_context.hpp), as a launch of its
-// own on that solve's buffer set and stream. Called by whatever needs the solution, either stream idle, or the
-// inputs / flags unchanged no longer (sync_all does).
-static int cosched_flush(NdlqrHipCtx* c) {
-  if (!c->apply_pending) return NDLQR_OK;
-  c->apply_pending = false;
-  const bool other = c->apply_set != (c->in_alt ? 1 : 0);
-  if (other) swap_slot(c);
-  c->cosched_mode = 3;
-  int err = NDLQR_OK;
-  const bool done = try_launch_small(c, false, &err);
-  c->cosched_mode = 0;
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipEventRecord(c->ev_stop, c->stream);  // (the solve ends here)
-  if (other) swap_slot(c);
-  if (!done || err) return err ? err : NDLQR_ERR_INVALID;
-  if (e != hipSuccess) return fail("back-substitution launch", e);
-  return NDLQR_OK;
-}
-
 int ndlqr_hip_solve_async(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
-  bool pipelined = false;
-  int err = prepare_solve(c, &pipelined);
+  int err = prepare_solve(c, nullptr);
   if (err) return err;
   err = rhs_make_current(c, 0xFu);  // (this buffer set's copy of the right-hand side may be behind: steps write one set)
   if (err) return err;
-  // co-scheduled form: this solve's bottom launch carries the back-substitution of the previous solve when that one is
-  // pending on the other buffer set; its own back-substitution stays pending
-  const int cur = c->in_alt ? 1 : 0;
-  int mode = 0;
-  if (pipelined && solve_can_cosched(c)) {
-    if (c->apply_pending && c->apply_set != cur && c->alt.ready) {
-      mode = 2;
-    } else {
-      err = cosched_flush(c);
-      if (err) return err;
-      mode = 1;
-    }
-  } else {
-    err = cosched_flush(c);
-    if (err) return err;
-  }
-  if (mode == 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->alt.ev_stop, 0));  // the other set's tree levels are done
   HIP_TRY(hipEventRecord(c->ev_start, c->stream));
-  c->cosched_mode = mode;
   err = launch_solve(c);
-  c->cosched_mode = 0;
   if (err) return err;
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
-  if (mode) { c->apply_pending = true; c->apply_set = cur; }
   c->timing_pending = true;
   c->state_dirty = false;
   return NDLQR_OK;
@@ -1197,8 +1112,6 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   if (!c || !x0 || !soln) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   int err = prepare_solve(c, nullptr);
-  if (err) return err;
-  err = cosched_flush(c);  // (a plain solve before this step may have left its back-substitution pending)
   if (err) return err;
   err = ensure_xfer(c);  // (before anything is captured: allocation is not a stream operation)
   if (err) return err;
@@ -1536,10 +1449,6 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* c, double* dst) {
   if (!c || !dst) return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
-  {
-    const int ferr = cosched_flush(c);
-    if (ferr) return ferr;
-  }
   // on the stream of the latest solve: ordered behind it, asynchronous for the caller
   hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0,
                      c->stream_latest ? c->stream_latest : c->stream, c->du, d, c->z_latest ? c->z_latest : c->z, dst);

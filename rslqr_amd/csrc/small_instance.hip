@@ -2,7 +2,7 @@
 // Compiled once per line of small_instances.def with -DNDLQR_INST_NX=<nstates>
 // -DNDLQR_INST_NU=<ninputs>; exports the two entry points ndlqr_hip.hip dispatches to:
 //   ndlqr_small_solve_<nx>_<nu>(ctx, strict, keep)   factor + solve launch sequence
-//   ndlqr_small_needs_F_<nx>_<nu>(ctx, strict, keep)  bit 0: does that sequence touch the factor array? bit 1: has it the co-scheduled form?
+//   ndlqr_small_needs_F_<nx>_<nu>(ctx, strict, keep)  does that sequence touch the factor array?
 //   ndlqr_small_rhs_<nx>_<nu>(ctx)                      record-based right-hand-side re-solve
 //   ndlqr_small_kpb_<nx>_<nu>()                         knots per workgroup of its Schur kernels
 //   ndlqr_small_tshard_<nx>_<nu>(ctx, phase, g, G)      time-axis sharding: chunk g of G, phase 0 / 1 (launch_time_shard)
@@ -27,8 +27,8 @@ int NDLQR_INST_NAME(ndlqr_small_solve_)(NdlqrHipCtx* c, bool strict, bool keep) 
 }
 
 int NDLQR_INST_NAME(ndlqr_small_needs_F_)(const NdlqrHipCtx* c, bool strict, bool keep) {
-  if (strict) return keep ? plan_bits_small<NX, NU, true, true>(c) : plan_bits_small<NX, NU, true, false>(c);
-  return keep ? plan_bits_small<NX, NU, false, true>(c) : plan_bits_small<NX, NU, false, false>(c);
+  if (strict) return keep ? plan_small<NX, NU, true, true>(c).needs_F : plan_small<NX, NU, true, false>(c).needs_F;
+  return keep ? plan_small<NX, NU, false, true>(c).needs_F : plan_small<NX, NU, false, false>(c).needs_F;
 }
 
 void NDLQR_INST_NAME(ndlqr_small_rhs_)(NdlqrHipCtx* c) { launch_rhs_records<NX, NU>(c); }
