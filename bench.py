@@ -473,7 +473,9 @@ def dropin_leg(rslqr_amd, json_path, reps=200, with_reference=True):
     sees; src/solve.h:20-32, examples/importexample/main.c:5-27): ndlqr_InitializeWithLQRProblem + ndlqr_Solve +
     ndlqr_CopySolution, steady state. `default`: the first solve of the solver is profiled, the timed ones replay one
     captured graph (copies up, launch chain, copy down); `profiling_every_solve`: ndlqr_SetDeviceProfiling(solver, 1),
-    eager launches with an event pair per kernel (the reference's always-on profiler; round 3's default)."""
+    eager launches with an event pair per kernel (the reference's always-on profiler; round 3's default);
+    `mirroring_the_factorisation`: ndlqr_SetFactorMirroring(solver, 1), every solve keeps the factor array and brings it
+    down into solver->fact (what the reference's ndlqr_Solve leaves there)."""
     import ctypes as C
     L = rslqr_amd.lib()
     prob = L.ndlqr_ReadLQRProblemJSONFile(json_path.encode())
@@ -487,10 +489,12 @@ def dropin_leg(rslqr_amd, json_path, reps=200, with_reference=True):
                        % (os.path.basename(json_path), n, m, N), "reps": reps}
     x = np.zeros(soln.size)
     xp = x.ctypes.data_as(C.POINTER(C.c_double))
-    for mode, prof in (("default", None), ("profiling_every_solve", 1)):
+    for mode, prof in (("default", None), ("profiling_every_solve", 1), ("mirroring_the_factorisation", None)):
         solver = L.ndlqr_NewNdLqrSolver(n, m, N)
         if prof is not None:
             L.ndlqr_SetDeviceProfiling(solver, prof)
+        if mode == "mirroring_the_factorisation":  # solver->fact left behind by every solve, like the reference's
+            L.ndlqr_SetFactorMirroring(solver, 1)
         t = np.zeros((reps + 5, 3))
         rc = 0
         for i in range(reps + 5):

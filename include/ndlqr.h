@@ -256,7 +256,7 @@ typedef struct {
   OrderedBinaryTree tree;
   Matrix* diagonals; /* (nhorizon, 2): dense Q_k, R_k host mirrors */
   NdData* data;      /* host mirror of the KKT coupling blocks */
-  NdData* fact;      /* host mirror of the factorisation (filled by ndlqr_SyncFactorsToHost) */
+  NdData* fact;      /* host mirror of the factorisation (filled by ndlqr_SyncFactorsToHost, or by every ndlqr_Solve under ndlqr_SetFactorMirroring) */
   NdData* soln;      /* rhs in, solution out (always synced by ndlqr_Solve) */
   NdLqrCholeskyFactors* cholfacts;
   double solve_time_ms;
@@ -269,6 +269,7 @@ typedef struct {
   int device_profiling;      /* ndlqr_SetDeviceProfiling: -1 (default) first solve only, 1 every solve, 0 never */
   int device_profiled;       /* a profiled solve has filled the per-kernel buckets of `profile` */
   NdLqrProfile device_split; /* ... which are kept here for the solves that replay the captured graph */
+  int mirror_fact;           /* ndlqr_SetFactorMirroring: ndlqr_Solve leaves the factorisation in `fact` like the reference */
 } NdLqrSolver;
 
 NdLqrSolver* ndlqr_NewNdLqrSolver(int nstates, int ninputs, int nhorizon);
@@ -301,6 +302,13 @@ int ndlqr_SetDeviceFlags(NdLqrSolver* solver, unsigned flags);
 /* additive: copy the device factorisation into solver->fact->data (reference layout). Without
  * NDLQR_FLAG_KEEP_FACT on the solve the (still resident) problem is factored once more for it. */
 int ndlqr_SyncFactorsToHost(NdLqrSolver* solver);
+/* additive: on = 1 makes every ndlqr_Solve of this solver end the way the reference's does (src/solve.c:120-131,
+ * src/nddata.h:83-93): with the complete factorisation in solver->fact->data -- the solve runs with
+ * NDLQR_FLAG_KEEP_FACT and the factor array comes down with the solution (N K (2n+m) n doubles: 1.5 MB at (6,3,256)).
+ * Default 0 (solution only; ndlqr_SyncFactorsToHost on demand), or 1 when the environment has
+ * NDLQR_SOLVE_MIRRORS_FACT=1 at ndlqr_NewNdLqrSolver -- for callers that read solver->fact behind an unmodified
+ * ndlqr_Solve. */
+int ndlqr_SetFactorMirroring(NdLqrSolver* solver, int on);
 
 /* ------------------------------------------------------------------ nested_dissection.h:39-147 */
 /* Stage functions on the host mirrors; each runs its dense math through the device-backed

@@ -105,7 +105,7 @@ class NdLqrSolver(C.Structure):
                 ("linalg_time_ms", C.c_double), ("profile", NdLqrProfile),
                 ("num_threads", C.c_int), ("device_ctx", C.c_void_p),
                 ("device_flags", C.c_uint), ("device_profiling", C.c_int), ("device_profiled", C.c_int),
-                ("device_split", NdLqrProfile)]
+                ("device_split", NdLqrProfile), ("mirror_fact", C.c_int)]
 
 
 _LIB = None
@@ -196,6 +196,7 @@ def lib():
     proto("ndlqr_SyncFactorsToHost", ci, sp)
     proto("ndlqr_SetDeviceProfiling", ci, sp, ci)
     proto("ndlqr_SetDeviceFlags", ci, sp, C.c_uint)
+    proto("ndlqr_SetFactorMirroring", ci, sp, ci)
     # stage functions
     proto("ndlqr_SolveLeaf", ci, sp, ci)
     proto("ndlqr_SolveLeaves", ci, sp)

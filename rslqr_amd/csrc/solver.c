@@ -100,6 +100,10 @@ NdLqrSolver* ndlqr_NewNdLqrSolver(int nstates, int ninputs, int nhorizon) {
   s->num_threads = 1;
   s->device_ctx = NULL;
   s->device_flags = 0u;
+  {
+    const char* mf = getenv("NDLQR_SOLVE_MIRRORS_FACT");
+    s->mirror_fact = (mf && atoi(mf) != 0) ? 1 : 0;
+  }
   s->device_profiling = -1;
   s->device_profiled = 0;
   s->device_split = ndlqr_NewNdLqrProfile();
@@ -273,6 +277,7 @@ int ndlqr_Solve(NdLqrSolver* solver) {
    * the whole call -- inputs up, launch chain, solution down -- is one captured graph (ndlqr_hip_solve_staged). */
   const int profiled = solver->device_profiling > 0 || (solver->device_profiling < 0 && !solver->device_profiled);
   unsigned want = solver->device_flags & ~NDLQR_FLAG_PROFILE;
+  if (solver->mirror_fact) want |= NDLQR_FLAG_KEEP_FACT; /* the reference's ndlqr_Solve leaves fact behind (src/solve.c:120-131) */
   if (profiled) want |= NDLQR_FLAG_PROFILE;
   ndlqr_hip_set_flags(ctx, want);
   if (profiled) ndlqr_hip_profile_reset(ctx);
@@ -285,6 +290,10 @@ int ndlqr_Solve(NdLqrSolver* solver) {
   if (ndlqr_hip_cholesky_failures(ctx) > 0) err = NDLQR_ERR_NOT_SPD;
   /* full rhs blocks (N*(2n+m)) so the unused trailing u_N slot mirrors the device too */
   memcpy(solver->soln->data, hz, sizeof(double) * (size_t)solver->nhorizon * (2 * solver->nstates + solver->ninputs));
+  if (solver->mirror_fact) {
+    const int ferr = ndlqr_CopyBatchFactors(bs, 0, solver->fact->data);
+    if (ferr && !err) err = ferr;
+  }
 
   solver->solve_time_ms = ndlqr_BatchSolveTimeMs(bs);
   solver->linalg_time_ms = 0.0; /* the reference's global LA timer is compiled out by default too */
@@ -335,6 +344,12 @@ int ndlqr_CopySolution(NdLqrSolver* solver, double* soln) {
 int ndlqr_SetDeviceProfiling(NdLqrSolver* solver, int on) {
   if (!solver) return -1;
   solver->device_profiling = on ? 1 : 0;
+  return 0;
+}
+
+int ndlqr_SetFactorMirroring(NdLqrSolver* solver, int on) {
+  if (!solver) return -1;
+  solver->mirror_fact = on ? 1 : 0;
   return 0;
 }
 

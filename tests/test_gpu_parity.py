@@ -614,6 +614,40 @@ def test_dropin_solve_flags(ndlqr, oracle):
         L.ndlqr_FreeNdLqrSolver(solver)
 
 
+def test_dropin_solve_leaves_the_factorisation(ndlqr, oracle, monkeypatch):
+    """ndlqr_SetFactorMirroring / NDLQR_SOLVE_MIRRORS_FACT=1: ndlqr_Solve ends like the reference's (src/solve.c:120-131),
+    with the complete factorisation in solver->fact -- no ndlqr_SyncFactorsToHost; bit-identical in strict mode."""
+    L = ndlqr.lib()
+    for fname, by_env, flags in (("lqr_prob.json", False, 0), ("lqr_prob_256.json", False, ndlqr.FLAG_STRICT_FP),
+                                 ("lqr_prob_256.json", True, 0)):
+        pyprob, soln = load_json_problem(os.path.join(GOLDEN, fname))
+        z, fact, _, _ = oracle.solve(pyprob, 1, want_fact=True)
+        if by_env:
+            monkeypatch.setenv("NDLQR_SOLVE_MIRRORS_FACT", "1")
+        prob = L.ndlqr_ReadLQRProblemJSONFile(os.path.join(GOLDEN, fname).encode())
+        solver = L.ndlqr_NewNdLqrSolver(pyprob.n, pyprob.m, pyprob.N)
+        monkeypatch.delenv("NDLQR_SOLVE_MIRRORS_FACT", raising=False)
+        if not by_env:
+            assert solver.contents.mirror_fact == 0
+            assert L.ndlqr_SetFactorMirroring(solver, 1) == 0
+        assert solver.contents.mirror_fact == 1
+        assert L.ndlqr_SetDeviceFlags(solver, flags) == 0
+        for rep in range(2):  # (the second call replays the captured sequence)
+            assert L.ndlqr_InitializeWithLQRProblem(prob, solver) == 0
+            solver.contents.fact.contents.numpy()[:] = -7.0
+            assert L.ndlqr_Solve(solver) == 0
+            got = solver.contents.fact.contents.numpy()
+            x = np.zeros(soln.size)
+            L.ndlqr_CopySolution(solver, x.ctypes.data_as(C.POINTER(C.c_double)))
+            if flags & ndlqr.FLAG_STRICT_FP:
+                assert np.array_equal(got, fact) and np.array_equal(x, z[: soln.size])
+            else:
+                assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
+                assert np.linalg.norm(x - z[: soln.size]) / np.linalg.norm(z[: soln.size]) <= REL_TOL
+        L.ndlqr_FreeLQRProblem(prob)
+        L.ndlqr_FreeNdLqrSolver(solver)
+
+
 @pytest.mark.parametrize("n,m,N,batch", [(6, 3, 64, 5), (13, 4, 32, 3), (9, 3, 8, 4), (8, 4, 256, 2), (10, 4, 16, 1),
                                          (12, 4, 16, 7), (6, 3, 1024, 2), (13, 4, 512, 2)])
 def test_separator_only_schedules_other_shapes(ndlqr, oracle, n, m, N, batch):
