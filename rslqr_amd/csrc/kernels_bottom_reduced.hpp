@@ -50,29 +50,6 @@ typedef double acc4_t __attribute__((ext_vector_type(4)));
 // give 5e-12 (tools/reduced_model.py reproduces both; tests: test_harder_families_large_and_padded_paths).
 // Everything is written branch-free: loads are unconditional with clamped indices, the tiles are padded to 16 x 16
 // in LDS (pad rows / columns of W are zero, so padding never reaches a result), conditions only select values.
-// Products on 4 x 4 blocks (round 4). v_mfma_f64_4x4x4_4b_f64 takes the operand registers of one k-step of the 16x16x4
-// instruction -- A: lane (li, lk) holds A(li, k = lk), B: lane (li, lk) holds B(k = lk, li) -- and forms only the four
-// DIAGONAL 4 x 4 blocks of their product: lane (li, lk) receives element (4 (li >> 2) + lk, li), i.e. component li >> 2
-// of that lane's 16x16x4 accumulator (tools/ubench/mfma44_layout.hip), in 16 cycles instead of 64. With an A operand
-// that holds row block g in EVERY one of its four slots -- lane (li, lk): A(4 g + (li & 3), lk) -- the instruction
-// therefore delivers component g of the 16 x 16 tile in the standard accumulator layout: a tile whose rows fill
-// QB = ceil(rows / 4) < 4 blocks costs QB x 16 cycles per k-step instead of 64, with nothing else about it changed.
-// At 12 states: 3 of 4 (the rhs always rides as a COLUMN, so row 12 of a tile is never needed). The A operands come
-// from LDS anyway (one ds_read per row block instead of one per tile); products whose operands exist in registers
-// only (factor_tail_mc: the tree schedule and KEEP_RECORDS at level 0) stay on the 16x16x4 instruction.
-template <int NX>
-struct Mc44 {
-  static constexpr int QB = (NX + 3) / 4;
-#ifdef NDLQR_NO_MFMA44  // (developer builds: A/B against the 16x16x4 products)
-  static constexpr bool ON = false;
-#else
-  static constexpr bool ON = QB < 4;
-#endif
-};
-__device__ __forceinline__ double mfma44(const double a, const double b, const double c) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-
 template <int NX>
 struct McPitch {
   static constexpr int SP = 18, WP = 17;  // row pitch of the S-bar tile / of W in LDS
@@ -93,21 +70,20 @@ __device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, 
   int lane_o = lane;  // (opaque: the lane predicates of one core are recomputed, not kept in scalar registers)
   asm volatile("" : "+v"(lane_o));
   const int li = lane_o & 15, lk = lane_o >> 4;
-  double wt[KS], wa[KS], b0[KS], b1[KS];
+  double wt[KS], wa[KS], b0[KS];
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
     wt[q] = Wm[(4 * q + lk) * WP + li];  // W(k, li): A operand of W'(i, k)
     wa[q] = Wm[li * WP + 4 * q + lk];    // W(li, k): A operand of W(i, k)
     // columns beyond the blocks carry finite don't-cares: they only reach tile elements nobody reads
     b0[q] = li == NX ? c[q] : ra[q];
-    b1[q] = li == NX ? c[q] : rb[q];  // (column NX of Y1, too, is y~: Y_bb' y~ comes out as column NX of Y1'Y1, see push_mc)
   }
   const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
   acc4_t Y0 = zero, Y1 = zero;
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
     Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], b0[q], Y0, 0, 0, 0);
-    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], b1[q], Y1, 0, 0, 0);
+    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], rb[q], Y1, 0, 0, 0);
   }
   X0 = zero; X1 = zero;
   double y0[KS], y1[KS];
@@ -117,7 +93,7 @@ __device__ __forceinline__ void factor_tail_mc(const int lane, const acc4_t& c, 
     X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y0[q], X0, 0, 0, 0);
     X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], Y1[q], X1, 0, 0, 0);
   }
-  hook(std::false_type{}, nullptr, nullptr, y0, y1, Y0, Y1);
+  hook(y0, y1, Y0, Y1);
 }
 
 // The pass of ONE separator whose record keeps X = S-bar^-1 R (every level >= 1): the paired pass (chol_pair_y_mc
@@ -134,7 +110,7 @@ struct McWyLayout {
   static constexpr int SP = McPitch<NX>::SP, WP = McPitch<NX>::WP, KS = (NX + 3) / 4, YP = 17, TILE = 4 * KS * YP;
   static constexpr int Y0 = 0, Y1 = TILE, W = 2 * TILE;
   static constexpr int SIZE = 2 * TILE + 16 * WP > 16 * SP ? 2 * TILE + 16 * WP : 16 * SP;
-  static_assert(2 * NX + 2 <= 32, "the panel and the second copy of b~ fit the lanes of two DPP rows");
+  static_assert(2 * NX + 1 <= 32, "the panel fits the lanes of two DPP rows");
 };
 template <int NX>
 __device__ __forceinline__ bool chol_wy_mc(const int lane_in, const acc4_t& c, double* buf, double (&w)[NX],
@@ -163,18 +139,17 @@ __device__ __forceinline__ bool chol_wy_mc(const int lane_in, const acc4_t& c, d
   if (lk >= 2) {  // (plain selects / loads under lane predicates: no cross-lane operation inside)
 #pragma unroll
     for (int k = 0; k < NX; ++k) w[k] = (k == li) ? 1.0 : 0.0;
-  } else if (h == NX || h == 2 * NX + 1) {  // (the first idle lane carries b~ as well: column NX of Y1, see below)
+  } else if (h == NX) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) w[k] = buf[k * SP + NX];
   }
   const bool bad = rb_chol_inv<NX, false>(li, acc, w);
   wave_lds_sync();  // (every lane has its row of S-bar and the rhs column: the tiles may overwrite the S-bar tile)
   {
-    // rows 0-1: column h of Y0 (h <= NX), column h - NX - 1 of Y1 (h <= 2 NX + 1: column NX of Y1 is y~ once more, so that
-    // Y_bb' y~ comes out of the Gram product Y1'Y1 as a column), the idle lanes dump into the pad column of Y1; rows 2-3:
-    // column li of W (twice the same values: benign duplicates; lanes li >= NX hold zeros).
+    // rows 0-1: column h of Y0 (h <= NX), column h - NX - 1 of Y1 (h <= 2 NX), the idle lanes dump into the pad column
+    // of Y1; rows 2-3: column li of W (twice the same values: benign duplicates; lanes li >= NX hold zeros).
     // Unconditional stores: a store under a lane predicate makes the compiler sink the recurrence behind it.
-    const int ycol = h <= NX ? P::Y0 + h : P::Y1 + (h <= 2 * NX + 1 ? h - NX - 1 : YP - 1);
+    const int ycol = h <= NX ? P::Y0 + h : P::Y1 + (h <= 2 * NX ? h - NX - 1 : YP - 1);
     double* dst = buf + (lk < 2 ? ycol : P::W + li);
 #pragma unroll
     for (int k = 0; k < NX; ++k) dst[k * YP] = w[k];
@@ -208,42 +183,23 @@ __device__ __forceinline__ void tail_wy_mc(const int lane, const double* buf, ac
   int lane_o = lane;
   asm volatile("" : "+v"(lane_o));
   const int li = lane_o & 15, lk = lane_o >> 4;
-  double y0[KS], y1[KS];
+  double wt[KS], y0[KS], y1[KS];
   acc4_t Z0 = {0.0, 0.0, 0.0, 0.0}, Z1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
+    wt[q] = buf[P::W + (4 * q + lk) * P::WP + li];  // W(k, li): A operand of W'(i, k)
     y0[q] = buf[P::Y0 + (4 * q + lk) * P::YP + li];
     y1[q] = buf[P::Y1 + (4 * q + lk) * P::YP + li];
     Z0[q] = y0[q]; Z1[q] = y1[q];
   }
   const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
   X0 = zero; X1 = zero;
-  if constexpr (Mc44<NX>::ON) {
-    // row block g of W' in every slot: W(k, 4 g + (li & 3)) (rows of X beyond NX: never stored)
-    constexpr int QB = Mc44<NX>::QB;
-    const int j4 = li & 3;
 #pragma unroll
-    for (int q = 0; q < KS; ++q) {
-      double wg[QB];
-#pragma unroll
-      for (int g = 0; g < QB; ++g) wg[g] = buf[P::W + (4 * q + lk) * P::WP + 4 * g + j4];
-#pragma unroll
-      for (int g = 0; g < QB; ++g) {
-        X0[g] = mfma44(wg[g], y0[q], X0[g]);
-        X1[g] = mfma44(wg[g], y1[q], X1[g]);
-      }
-    }
-  } else {
-    double wt[KS];
-#pragma unroll
-    for (int q = 0; q < KS; ++q) wt[q] = buf[P::W + (4 * q + lk) * P::WP + li];  // W(k, li): A operand of W'(i, k)
-#pragma unroll
-    for (int q = 0; q < KS; ++q) {
-      X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y0[q], X0, 0, 0, 0);
-      X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y1[q], X1, 0, 0, 0);
-    }
+  for (int q = 0; q < KS; ++q) {
+    X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y0[q], X0, 0, 0, 0);
+    X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[q], y1[q], X1, 0, 0, 0);
   }
-  hook(std::true_type{}, buf + P::Y0, buf + P::Y1, y0, y1, Z0, Z1);
+  hook(y0, y1, Z0, Z1);
 }
 
 // The Cholesky + inverse of TWO independent separators in one pass: DPP rows 0-1 (lanes 0..31) work on tile cA,
@@ -348,8 +304,7 @@ __device__ __forceinline__ bool chol_pair_y_mc(const int lane_in, const acc4_t& 
 #pragma unroll
     for (int j = 0; j < NX; ++j) acc[j] = tile[ri * SP + j];
   }
-  if (h == NX || h == 2 * NX + 1) {  // the rhs column of the tile (plain loads under a lane predicate: no cross-lane
-                                      // operation inside); the first idle lane carries it too: column NX of Y1
+  if (h == NX) {  // the rhs column of the tile (plain loads under a lane predicate: no cross-lane operation inside)
 #pragma unroll
     for (int k = 0; k < NX; ++k) w[k] = tile[k * SP + NX];
   }
@@ -357,9 +312,8 @@ __device__ __forceinline__ bool chol_pair_y_mc(const int lane_in, const acc4_t& 
   wave_lds_sync();  // (every lane has its row of S-bar and the rhs column: the Y tiles may overwrite the S-bar tiles)
   {
     const int x = lk >> 1;
-    // column h of Y0 (h <= NX), column h - NX - 1 of Y1 (h <= 2 NX + 1: column NX of Y1 is y~ once more, see chol_wy_mc);
-    // the idle lanes dump into the pad column of Y1
-    double* ydst = buf + (h <= NX ? P::tile(x, 0) + h : P::tile(x, 1) + (h <= 2 * NX + 1 ? h - NX - 1 : YP - 1));
+    // column h of Y0 (h <= NX), column h - NX - 1 of Y1 (h <= 2 NX); the idle lanes dump into the pad column of Y1
+    double* ydst = buf + (h <= NX ? P::tile(x, 0) + h : P::tile(x, 1) + (h <= 2 * NX ? h - NX - 1 : YP - 1));
 #pragma unroll
     for (int k = 0; k < NX; ++k) ydst[k * YP] = w[k];
     if constexpr (4 * KS > NX) {  // rows NX .. 4 KS - 1 of the tiles are read by the last k-step: zero
@@ -400,44 +354,6 @@ __device__ __forceinline__ void gram_mc(const double (&R0)[(NX + 3) / 4], const 
   }
 }
 
-// The same blocks from the solved panel where it lies in LDS (tiles Y0t, Y1t: rows = k, pitch YP), on 4 x 4 blocks
-// (Mc44): b0 / b1 = the tiles' B-operand fragments (b0[q] = Y0(4 q + lk, li)), the A operands -- row block g of Y' in
-// every slot, Y(4 q + lk, 4 g + (li & 3)) -- are fetched here. Rows beyond NX of a result are not formed (zero).
-template <int NX, bool N00, bool N01, bool N10, bool N11>
-__device__ __forceinline__ void gram44_mc(const double* Y0t, const double* Y1t, const int yp, const int lane,
-                                          const double (&b0)[(NX + 3) / 4], const double (&b1)[(NX + 3) / 4],
-                                          acc4_t& g00, acc4_t& g01, acc4_t& g10, acc4_t& g11) {
-  constexpr int KS = (NX + 3) / 4, QB = Mc44<NX>::QB;
-  const int lk = lane >> 4, j4 = lane & 3;
-  const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-  g00 = zero; g01 = zero; g10 = zero; g11 = zero;
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    double a0[QB], a1[QB];
-#pragma unroll
-    for (int g = 0; g < QB; ++g) {
-      if constexpr (N00 || N01) a0[g] = Y0t[(4 * q + lk) * yp + 4 * g + j4];
-      if constexpr (N10 || N11) a1[g] = Y1t[(4 * q + lk) * yp + 4 * g + j4];
-    }
-#pragma unroll
-    for (int g = 0; g < QB; ++g) {
-      if constexpr (N00) g00[g] = mfma44(a0[g], b0[q], g00[g]);
-      if constexpr (N01) g01[g] = mfma44(a0[g], b1[q], g01[g]);
-      if constexpr (N10) g10[g] = mfma44(a1[g], b0[q], g10[g]);
-      if constexpr (N11) g11[g] = mfma44(a1[g], b1[q], g11[g]);
-    }
-  }
-}
-// ... whichever form the operands allow: IN_LDS = false -- the panel exists in registers only
-template <int NX, bool N00, bool N01, bool N10, bool N11, bool IN_LDS>
-__device__ __forceinline__ void gram_any_mc(const double* Y0t, const double* Y1t, const int yp, const int lane,
-                                            const double (&R0)[(NX + 3) / 4], const double (&R1)[(NX + 3) / 4],
-                                            const acc4_t& X0, const acc4_t& X1, acc4_t& g00, acc4_t& g01, acc4_t& g10,
-                                            acc4_t& g11) {
-  if constexpr (Mc44<NX>::ON && IN_LDS) gram44_mc<NX, N00, N01, N10, N11>(Y0t, Y1t, yp, lane, R0, R1, g00, g01, g10, g11);
-  else gram_mc<NX, N00, N01, N10, N11>(R0, R1, X0, X1, g00, g01, g10, g11);
-}
-
 // Component g of an accumulator tile holds row lk + 4 g: rows_all(g) -- the row is inside the
 // block for every lane; rows_none(g) -- for no lane (both known at compile time, so that the
 // stores below sit in as few predicated regions as possible).
@@ -475,10 +391,9 @@ __device__ __forceinline__ void store_record_mc(double* __restrict__ myrec, cons
 }
 
 // What a separator contributes to the reduced system of its two neighbours (see reduced_level),
-// from its Gram tiles g00 = Y_a'[Y_a | y_z], g01 = Y_a'Y_bb, g11 = Y_bb'[Y_bb | y_z] (column NX of BOTH panel tiles is
-// y_z: the right-hand side rides as a column everywhere, no tile needs its row NX) plus whatever its children parked
-// (pa, pb11; zero tiles for none):
-//   A: DR += g00 (columns < NX), gR += g00 (column NX)      B: DL += g11 (columns < NX), gL += g11 (column NX)
+// from its Gram tiles g00 = Y_a'[Y_a | y_z], g01 = [Y_a | y_z]'Y_bb, g11 = Y_bb'Y_bb plus whatever
+// its children parked (pa, pb01, pb11; zero tiles for none):
+//   A: DR += g00 (columns < NX), gR += g00 (column NX)      B: DL += g11, gL += g01 (row NX)
 //   coupling of the parent to the other neighbour: CA[B] = g01' (left child) or CB[A] = g01.
 // put(p, v): store (first writer of the launch) or atomic add; set(p, v): store of a single-writer
 // block (the couplings). Under the tree schedule the stores are write-through (agent-scope
@@ -498,7 +413,7 @@ struct AddAtomic { __device__ __forceinline__ void operator()(double* p, double 
 template <int NX, class Put, class Set>
 __device__ __forceinline__ void push_mc(const int lane, const bool hasA, const bool hasB, const bool leftchild,
                                         const RedSlot<NX>& sa, const RedSlot<NX>& sb, const acc4_t& g00,
-                                        const acc4_t& g01, const acc4_t& g11, const acc4_t& pa,
+                                        const acc4_t& g01, const acc4_t& g11, const acc4_t& pa, const acc4_t& pb01,
                                         const acc4_t& pb11, Put put, Set set) {
   const int li = lane & 15, lk = lane >> 4;
   if (hasA && li <= NX) {
@@ -510,15 +425,13 @@ __device__ __forceinline__ void push_mc(const int lane, const bool hasA, const b
         put(li < NX ? sa.DR() + r * (r + 1) / 2 + li : sa.gR() + r, g00[g] + pa[g]);
     }
   }
-  if (hasB && li <= NX) {
+  if (hasB && li < NX) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = lk + 4 * g;
-      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX) && (li <= r || li == NX))
-        put(li < NX ? sb.DL() + r * (r + 1) / 2 + li : sb.gL() + r, g11[g] + pb11[g]);
+      if (!rows_none<NX>(g) && (rows_all<NX>(g) || r < NX) && li <= r) put(sb.DL() + r * (r + 1) / 2 + li, g11[g] + pb11[g]);
     }
-  }
-  if (hasB && li < NX) {
+    if (lk == NX % 4) put(sb.gL() + li, g01[NX / 4] + pb01[NX / 4]);  // row NX of g01: y_z' Y_bb
     if (hasA) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -567,20 +480,6 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
     // rows / columns beyond the block: finite don't-cares
     c[g] = (li == NX ? -fma(zb[g], w1[g], za[g]) : ((i == li) ? w1[g] : 0.0)) + in0[g];
   }
-  // (Mc44: row block g of [A_s | B_s] in every slot of the A operand, one 4x4x4 instruction per block and k-step)
-  constexpr int QB = Mc44<NX>::QB;
-  double ag[Mc44<NX>::ON ? QB : 1][KS];
-  if constexpr (Mc44<NX>::ON) {
-#pragma unroll
-    for (int g = 0; g < QB; ++g) {
-      const int rg = 4 * g + (li & 3) < NX ? 4 * g + (li & 3) : NX - 1;
-#pragma unroll
-      for (int q = 0; q < KS; ++q) {
-        const int kq = 4 * q + lk, k = kq < W ? kq : W - 1;
-        ag[g][q] = am[rg * WP + k];
-      }
-    }
-  }
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
     const int kq = 4 * q + lk, k = kq < W ? kq : W - 1;
@@ -588,13 +487,8 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
     const double sv = fx ? 0.0 : av[q] * wk[q];            // S-bar columns
     const double zc = fx ? -zraw[q] : zraw[q] * wk[q];     // rhs column
     const double bsel = li == NX ? zc : sv;
-    if constexpr (Mc44<NX>::ON) {
-#pragma unroll
-      for (int g = 0; g < QB; ++g) c[g] = mfma44((W % 4 == 0 || kin) ? ag[g][q] : 0.0, bsel, c[g]);
-    } else {
-      if constexpr (W % 4 == 0) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bsel, c, 0, 0, 0);
-      else c = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? av[q] : 0.0, bsel, c, 0, 0, 0);
-    }
+    if constexpr (W % 4 == 0) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bsel, c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? av[q] : 0.0, bsel, c, 0, 0, 0);
   }
   return c;
 }
@@ -733,17 +627,15 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
     flag_failure(info, d, b);
   SEG(31);
   tail_wy_mc<NX>(lane, lds.buf, X0, X1,
-                 [&](auto in_lds, const double* Y0t, const double* Y1t, const double (&R0)[KSN], const double (&R1)[KSN],
-                     const acc4_t& Z0, const acc4_t& Z1) {
+                 [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
                    acc4_t g00, g01, g11;
-                   gram_any_mc<NX, true, true, false, true, decltype(in_lds)::value>(Y0t, Y1t, McWyLayout<NX>::YP, lane, R0, R1,
-                                                                                     Z0, Z1, g00, g01, unused, g11);
+                   gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
                    const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
                    if constexpr (TREE)
-                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, AddAtomic(),
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
                                  StoreThrough());
                    else
-                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, AddAtomic(),
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(),
                                  StorePlain());
                  });
   SEG(13);
@@ -821,9 +713,9 @@ __device__ __forceinline__ void reduced_eliminate_tail_mc(const Dims& d, const i
     const RedSlot<NX> sa = red_slot<NX>(red, d, b, hasA ? base - 1 : s);
     const RedSlot<NX> sb = red_slot<NX>(red, d, b, hasB ? base + T - 1 : s);
     acc4_t g00, g01, g11, unused;
-    gram_any_mc<NX, true, true, false, true, true>(buf + P::Y0, buf + P::Y1, P::YP, lane, y0, y1, Z0, Z1, g00, g01, unused, g11);
+    gram_mc<NX, true, true, false, true>(y0, y1, Z0, Z1, g00, g01, unused, g11);
     const acc4_t zero = {0.0, 0.0, 0.0, 0.0};
-    push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, AddAtomic(), StorePlain());
+    push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, zero, zero, zero, AddAtomic(), StorePlain());
   } else {
     double wt[KS];
 #pragma unroll
@@ -1045,19 +937,15 @@ __device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, con
   // what the two level-0 separators hand to t and to the neighbours of the group (the Gram products take (R, X) or,
   // for compact records, (Y, Y))
   acc4_t park_a, ca_t, park_b11, cb_t;
-  auto hook_s0 = [&](auto in_lds, const double* Y0t, const double* Y1t, const double (&R0)[KSN], const double (&R1)[KSN],
-                     const acc4_t& Z0, const acc4_t& Z1) {
+  auto hook_s0 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
     acc4_t g11;  // s0 (left child of t): DL[t], gL[t], CA[t]; its a-side faces separator k0 - 1
-    gram_any_mc<NX, true, false, true, true, decltype(in_lds)::value>(Y0t, Y1t, McPairYLayout<NX>::YP, lane, R0, R1, Z0, Z1,
-                                                                      park_a, unused, ca_t, g11);
+    gram_mc<NX, true, false, true, true>(R0, R1, Z0, Z1, park_a, unused, ca_t, g11);
 #pragma unroll
     for (int g = 0; g < 4; ++g) c_t[g] -= (li < NX) ? g11[g] : ca_t[g];  // column NX: Y_bb' y_z
   };
-  auto hook_s2 = [&](auto in_lds, const double* Y0t, const double* Y1t, const double (&R0)[KSN], const double (&R1)[KSN],
-                     const acc4_t& Z0, const acc4_t& Z1) {
+  auto hook_s2 = [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
     acc4_t g00;  // s2 (right child of t): DR[t], gR[t], CB[t]; bb-side faces separator k0 + 3
-    gram_any_mc<NX, true, true, false, true, decltype(in_lds)::value>(Y0t, Y1t, McPairYLayout<NX>::YP, lane, R0, R1, Z0, Z1,
-                                                                      g00, cb_t, unused, park_b11);
+    gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, cb_t, unused, park_b11);
 #pragma unroll
     for (int g = 0; g < 4; ++g) c_t[g] -= g00[g];  // Y_a' [Y_a | y_z]
   };
@@ -1099,7 +987,7 @@ __device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, con
         y1[q] = Y1[(4 * q + lk) * PY::YP + li];
         Z0[q] = y0[q]; Z1[q] = y1[q];
       }
-      if (x == 0) hook_s0(std::true_type{}, Y0, Y1, y0, y1, Z0, Z1); else hook_s2(std::true_type{}, Y0, Y1, y0, y1, Z0, Z1);
+      if (x == 0) hook_s0(y0, y1, Z0, Z1); else hook_s2(y0, y1, Z0, Z1);
     }
     SEG(35);
   } else {
@@ -1165,17 +1053,15 @@ __device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, con
   if (chol_wy_mc<NX>(lane, c_t, lds.buf, wcol, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr) && lane == 0)
     flag_failure(info, d, b);
   tail_wy_mc<NX>(lane, lds.buf, X0, X1,
-                 [&](auto in_lds, const double* Y0t, const double* Y1t, const double (&R0)[KSN], const double (&R1)[KSN],
-                     const acc4_t& Z0, const acc4_t& Z1) {
+                 [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {
                    acc4_t g00, g01, g11;
-                   gram_any_mc<NX, true, true, false, true, decltype(in_lds)::value>(Y0t, Y1t, McWyLayout<NX>::YP, lane, R0, R1,
-                                                                                     Z0, Z1, g00, g01, unused, g11);
+                   gram_mc<NX, true, true, false, true>(R0, R1, Z0, Z1, g00, g01, unused, g11);
                    if constexpr (TREE)
-                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, park_b11, StoreThrough(),
-                                 StoreThrough());
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
+                                 StoreThrough(), StoreThrough());
                    else
-                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, park_b11, StorePlain(),
-                                 StorePlain());
+                     push_mc<NX>(lane, hasA, hasB, leftchild, sa, sb, g00, g01, g11, park_a, cb_t, park_b11,
+                                 StorePlain(), StorePlain());
                  });
   SEG(34);
   store_record_mc<NX>(myrec + REC, lane, hasA, hasB, X0, X1);
