@@ -351,12 +351,15 @@ typedef struct NdLqrBatchSolver NdLqrBatchSolver;
                                      ndlqr_CopyBatchFactors does not. Size-specialised shapes and every
                                      other one up to 128 states. */
 /* Reach of the modes by block size (runtime-sized kernels; the size-specialised instances of
- * rslqr_amd/csrc/small_instances.def support every mode): the default fast mode and NDLQR_FLAG_KEEP_RECORDS work up
- * to 128 states (n + m + 4 staged columns within the 160 KB of LDS: (128,32) is refused). NDLQR_FLAG_STRICT_FP and
- * NDLQR_FLAG_KEEP_FACT run the knot-based kernels, whose separator kernel stages S-bar and the whole right-hand-side
- * panel: up to about 82 states, and tile-filling block sizes (n a multiple of 16) up to 112; beyond that a solve
- * returns NDLQR_ERR_INVALID with ndlqr_hip_last_error() = "nstates too large for ...". So does ndlqr_SyncFactorsToHost
- * and the factor-based rhs-only re-solve there; the record-based one (NDLQR_FLAG_KEEP_RECORDS) is the way beyond. */
+ * rslqr_amd/csrc/small_instances.def support every mode): EVERY mode works for every block size the device memory holds
+ * (round 4; tested up to (256,32)). What changes with the size is the speed: the default fast mode and
+ * NDLQR_FLAG_KEEP_RECORDS run the separator-only schedule on the matrix cores up to 128 states (n + m + 4 staged columns
+ * within the 160 KB of LDS; (128,32) and everything beyond: the knot-based kernels). NDLQR_FLAG_STRICT_FP and
+ * NDLQR_FLAG_KEEP_FACT always run the knot-based kernels, whose separator kernel keeps S-bar and the whole right-hand-side
+ * panel in LDS up to about 82 states (tile-filling block sizes, n a multiple of 16, up to 112) and in global memory beyond
+ * (one scratch pair per level-0 separator, allocated by the first such solve; NDLQR_ERR_INVALID with
+ * ndlqr_hip_last_error() = "global scratch ... does not fit" if the device is too small for the batch). The factor-based
+ * rhs-only re-solve reads the factor where it lies beyond ~140 states. */
 
 NdLqrBatchSolver* ndlqr_NewBatchSolver(int nstates, int ninputs, int nhorizon, int batch,
                                        int device);

@@ -25,7 +25,11 @@
 namespace ndlqr {
 
 // ------------------------------------------------------------------------------------- separators
-// grid (N / 2^(l+1), batch), block 256, dynamic LDS = (n (n+1) + n (2n+1)) doubles.
+// grid (N / 2^(l+1), batch), block 256, dynamic LDS = (n (n+1) + n (2n+1)) doubles -- or, for blocks whose S-bar and
+// panel do not fit the 160 KB of LDS (beyond ~80 states on this path), `scratch` != nullptr: the same two arrays per
+// workgroup in global memory, [batch][N / 2^(l+1)][n (n+1) + n (2n+1)] doubles (they stay in the L2 of the workgroup's
+// XCD; __syncthreads orders the workgroup's global accesses like its LDS accesses). Same code, same arithmetic: every
+// block size the device memory holds is solvable in every mode, slowly.
 // For the level-l separator s of each subtree: S-bar, the two outer right-hand sides f_a, f_bb and
 // the rhs vector; Cholesky; solves; results stored in the lambda rows of knot s+1.
 // LDS: S-bar / L with rows padded to n+1 (lane i walks row i: no bank conflicts), and ONE panel
@@ -67,7 +71,7 @@ __device__ __forceinline__ bool chol16_and_inverse(double* Sblk, const int ns, d
 
 template <bool STRICT>
 __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, double* F, double* z,
-                                  int* __restrict__ info, double* __restrict__ rec) {
+                                  int* __restrict__ info, double* __restrict__ rec, double* scratch = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = d.n, m = d.m, w = d.w, N = d.N;
   const int b = blockIdx.y;
@@ -76,8 +80,8 @@ __global__ void separator_generic(Dims d, int l, const double* __restrict__ AB, 
   outer_columns(base, l, N, a, bb);
   const int ns = n + 1, ncols = 2 * n + 1;
   const int xs = ncols;
-  double* S = sm;
-  double* X = S + n * ns;
+  double* S = scratch ? scratch + ((size_t)b * gridDim.x + blockIdx.x) * ((size_t)n * ns + (size_t)n * xs) : sm;
+  double* X = S + (size_t)n * ns;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
 
   const double* ab = AB + ((size_t)b * N + s) * n * w;
@@ -507,23 +511,26 @@ __global__ void rhs_leaf_generic(Dims d, const double* __restrict__ QR, const do
 
 // grid (N >> (l+1), batch), block 64 (one wavefront), dynamic LDS n (n+1) + n doubles: the cached
 // factor is staged in LDS first (whole rows, coalesced) so that the substitutions do not pay a
-// global-memory round trip per pivot.
+// global-memory round trip per pivot. staged == 0 (blocks whose factor does not fit the LDS: beyond ~140 states):
+// dynamic LDS n doubles, the factor is read where it lies.
 template <bool STRICT>
 __global__ void rhs_separator_generic(Dims d, int l, const double* __restrict__ AB,
-                                      const double* __restrict__ F, double* z) {
+                                      const double* __restrict__ F, double* z, const int staged = 1) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = d.n, m = d.m, w = d.w, N = d.N, b = blockIdx.y;
-  const int ns = n + 1;
-  double* Ls = sm;
-  double* v = sm + n * ns;
   const int half = 1 << l, base = blockIdx.x * (2 << l), s = base + half - 1;
   const double* ab = AB + ((size_t)b * N + s) * n * w;
   const double* zsl = z + ((size_t)b * N + s) * d.rows;
   double* zs1 = z + ((size_t)b * N + s + 1) * d.rows;
   const double* L = Fblk(F, d, b, l, s + 1);  // lambda rows: Cholesky factor of S-bar, row-major
-  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-    const int i = e / n, j = e - i * n;
-    Ls[i * ns + j] = L[e];
+  const int ns = staged ? n + 1 : n;
+  const double* Ls = staged ? sm : L;
+  double* v = staged ? sm + n * ns : sm;
+  if (staged) {
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+      const int i = e / n, j = e - i * n;
+      sm[i * ns + j] = L[e];
+    }
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double* arow = ab + i * w;

@@ -116,6 +116,7 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   c->sel_knot0 = 0; c->sel_nknots = 0; c->sel_blocks = 7u; c->step_set[0] = c->step_set[1] = 0;
   c->h_io = nullptr; c->graph_staged = nullptr; c->graph_staged_flags = 0;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;
+  c->sep_scratch = nullptr;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -172,6 +173,7 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
+  (void)hipFree(c->sep_scratch);
   (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->xfer); (void)hipFree(c->pad_stage);
   for (double* h : c->h_stage) if (h) (void)hipHostFree(h);
   if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
@@ -611,6 +613,43 @@ static void launch_rhs_reduced_generic(NdlqrHipCtx* c) {
   launch_backsub_reduced_generic(c);
 }
 
+// The separator kernel of the knot-based runtime-sized schedules and where its S-bar (n x (n+1)) and right-hand-side panel
+// (n x (2n+1)) live: separator_mfma (fast mode, blocks that fill 16x16 tiles; the panel goes through LDS in chunks of
+// kSepChunkTiles column tiles, + the inverses of the 16x16 diagonal blocks, pitch 17) while its LDS and its wavefronts
+// fit a workgroup; else separator_generic with both arrays in LDS; else -- blocks beyond ~80 states -- separator_generic
+// with both arrays in global memory (NdlqrHipCtx::sep_scratch): every mode, any block size the device holds.
+struct GenericSepPlan {
+  bool mfma;
+  bool scratch;
+  size_t lds;
+  int threads;
+};
+static GenericSepPlan plan_generic_sep(const NdlqrHipCtx* c, const bool strict) {
+  const ndlqr::Dims& d = c->d;
+  GenericSepPlan p;
+  p.mfma = !strict && d.n % 16 == 0 && d.w % 4 == 0 && !c->no_mfma;
+  p.scratch = false;
+  const int ctl = 2 * (d.n / 16) + 1, ctc = ctl < kSepChunkTiles ? ctl : kSepChunkTiles;
+  const size_t lds_mfma = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (16 * ctc + 1) + (size_t)d.n * 17);
+  const size_t lds_generic = sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (2 * d.n + 1));
+  // matrix-core separator: one wavefront per 16x16 tile of the products / updates; 512 threads let two
+  // workgroups (67 KB of LDS each at n = 64) share a CU
+  p.threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 32 ? 512 : 256);
+  if (p.mfma) {  // separator_mfma: a wavefront per tile of a block row of W, at most three panel tiles per wavefront
+    const int need = (d.n / 16) > ((d.n / 16) * ctc + 2) / 3 ? (d.n / 16) : ((d.n / 16) * ctc + 2) / 3;
+    if (p.threads < 64 * need) p.threads = 64 * need;
+    if (p.threads > 1024 || lds_mfma > 160 * 1024) p.mfma = false;
+  }
+  if (p.mfma) {
+    p.lds = lds_mfma;
+    return p;
+  }
+  p.scratch = lds_generic > 160 * 1024;
+  p.lds = p.scratch ? 0 : lds_generic;
+  p.threads = p.scratch ? 1024 : 256;
+  return p;
+}
+
 template <bool STRICT>
 static int launch_generic(NdlqrHipCtx* c, bool lean) {
   const ndlqr::Dims& d = c->d;
@@ -623,21 +662,17 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
   }
   // S (n x (n+1)) + right-hand-side panel (n x (2n+1)); on the matrix-core path the panel goes through
   // LDS in chunks of kSepChunkTiles column tiles (+ the inverses of the 16x16 diagonal blocks, pitch 17)
-  const bool p1mfma = !STRICT && d.n % 16 == 0 && d.w % 4 == 0 && !c->no_mfma;
-  const int ctl = 2 * (d.n / 16) + 1, ctc = ctl < kSepChunkTiles ? ctl : kSepChunkTiles;
-  const size_t lds = p1mfma ? sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (16 * ctc + 1) + (size_t)d.n * 17)
-                            : sizeof(double) * ((size_t)d.n * (d.n + 1) + (size_t)d.n * (2 * d.n + 1));
-  if (lds > 160 * 1024) {
-    g_last_error = "nstates too large for the separator kernel's LDS staging";
-    return NDLQR_ERR_INVALID;
-  }
-  // matrix-core separator: one wavefront per 16x16 tile of the products / updates; 512 threads let two
-  // workgroups (67 KB of LDS each at n = 64) share a CU
-  int sep_threads = c->sep_threads > 0 ? c->sep_threads : (d.n >= 32 ? 512 : 256);
-  if (p1mfma) {  // separator_mfma: a wavefront per tile of a block row of W, at most three panel tiles per wavefront
-    const int need = (d.n / 16) > ((d.n / 16) * ctc + 2) / 3 ? (d.n / 16) : ((d.n / 16) * ctc + 2) / 3;
-    if (sep_threads < 64 * need) sep_threads = 64 * need;
-    if (sep_threads > 1024) { g_last_error = "nstates too large for separator_mfma"; return NDLQR_ERR_INVALID; }
+  const GenericSepPlan sp = plan_generic_sep(c, STRICT);
+  const bool p1mfma = sp.mfma;
+  const size_t lds = sp.lds;
+  const int sep_threads = sp.threads;
+  double* sep_scratch = nullptr;
+  if (sp.scratch) {
+    sep_scratch = c->sep_scratch;
+    if (!sep_scratch) {
+      g_last_error = "nstates too large for the separator kernel's LDS staging and no global scratch";
+      return NDLQR_ERR_INVALID;
+    }
   }
   for (int l = 0; l < d.K; ++l) {
     const int nsub = d.N >> (l + 1);
@@ -647,8 +682,8 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
         hipLaunchKernelGGL((ndlqr::separator_mfma<kSepChunkTiles>), dim3(nsub, d.batch), dim3(sep_threads), lds,
                            c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
       else
-        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT>), dim3(nsub, d.batch), dim3(256), lds,
-                           c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
+        hipLaunchKernelGGL((ndlqr::separator_generic<STRICT>), dim3(nsub, d.batch), dim3(sep_threads), lds,
+                           c->stream, d, l, c->AB, c->F, c->z, c->info, rec, sep_scratch);
     }
     if (lean && l == d.K - 1) break;  // nothing above the root separator
     {
@@ -816,6 +851,23 @@ static int prepare_solve(NdlqrHipCtx* c, bool* pipelined_out) {
     if (ferr) return ferr;
   }
   const bool red_generic = !pick_small(c) && plan_reduced_generic(c).ok;
+  if (!pick_small(c) && !red_generic && !c->sep_scratch) {
+    // knot-based runtime-sized path with a block too large for the separator kernel's LDS (launch_generic): S-bar and
+    // the panel of every level-0 separator in global memory. Before any capture starts: allocation is not a stream operation.
+    const ndlqr::Dims& dd = c->d;
+    const size_t per_sep = (size_t)dd.n * (dd.n + 1) + (size_t)dd.n * (2 * dd.n + 1);
+    if (plan_generic_sep(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0).scratch) {
+      const size_t bytes = sizeof(double) * per_sep * (size_t)dd.batch * (dd.N / 2 > 0 ? dd.N / 2 : 1);
+      if (hipMalloc(&c->sep_scratch, bytes) != hipSuccess) {
+        c->sep_scratch = nullptr;
+        (void)hipGetLastError();
+        g_last_error = "global scratch of the large-block separator kernel does not fit on the device (" +
+                       std::to_string(bytes >> 20) + " MiB): use a smaller batch";
+        fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+        return NDLQR_ERR_INVALID;
+      }
+    }
+  }
   if (c->state_dirty) {
     // the previous solve did not launch or complete: its arrival counters may be odd and its failure
     // words meaningless -- start from zero (the kernels themselves leave both clean)
@@ -1268,8 +1320,10 @@ static void launch_rhs_sweep(NdlqrHipCtx* c) {
   for (int l = 0; l < d.K; ++l) {
     {
       ScopedSlot t(c, SLOT_SEP);
+      const size_t lds_staged = sizeof(double) * ((size_t)d.n * (d.n + 1) + d.n);
+      const int staged = lds_staged <= 160 * 1024 ? 1 : 0;
       hipLaunchKernelGGL((ndlqr::rhs_separator_generic<STRICT>), dim3(d.N >> (l + 1), d.batch), dim3(64),
-                         sizeof(double) * ((size_t)d.n * (d.n + 1) + d.n), c->stream, d, l, c->AB, c->F, c->z);
+                         staged ? lds_staged : sizeof(double) * (size_t)d.n, c->stream, d, l, c->AB, c->F, c->z, staged);
     }
     {
       ScopedSlot t(c, SLOT_SCHUR);

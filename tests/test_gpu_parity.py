@@ -201,13 +201,11 @@ def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch, mon
             assert np.linalg.norm(sol[p] - refs[p]) / np.linalg.norm(refs[p]) <= REL_TOL
     res, bnorm = bs.kkt_residuals()
     assert np.all(res <= 1e-9 * np.maximum(1.0, bnorm))
-    # strict mode and KEEP_FACT leave the schedule (they need the factor array)
+    # strict mode and KEEP_FACT leave the schedule (they need the factor array); where the knot-based separator kernel
+    # cannot stage S-bar and the panel in LDS (beyond 82 states, tile-filling blocks beyond 112) it keeps them in global memory
     bs.set_flags(ndlqr.FLAG_KEEP_FACT)
-    if 3 * n * n + 2 * n <= 20480 or (n % 16 == 0 and (n + m) % 4 == 0 and n * (n + 1) + 66 * n <= 20480):
-        assert bs.solve() == 0 and bs.schedule() == "generic-keep"
-        assert np.linalg.norm(bs.solution(0) - refs[0]) / np.linalg.norm(refs[0]) <= REL_TOL
-    else:  # (the knot-based separator kernel stages S-bar and the panel in LDS: up to 82 states, tile-filling blocks up to 112)
-        assert bs.solve() == -1
+    assert bs.solve() == 0 and bs.schedule() == "generic-keep"
+    assert np.linalg.norm(bs.solution(0) - refs[0]) / np.linalg.norm(refs[0]) <= REL_TOL
     bs.close()
     if N >= 4:
         bad = probs[0]
@@ -215,6 +213,62 @@ def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch, mon
         R[N // 2, 0] = -1.0
         bs = ndlqr.BatchSolver(n, m, N, 1)
         bs.initialize_flat(*[np.asarray(a)[None] for a in (bad.A, bad.B, bad.Q, R, bad.q, bad.r, bad.d, bad.x0)])
+        assert bs.solve() == -3
+        assert bs.cholesky_failures() >= 1
+        bs.close()
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(144, 16, 8, 2), (130, 5, 4, 1), (160, 16, 16, 1), (150, 10, 8, 2), (200, 8, 4, 1),
+                                         (256, 32, 4, 1), (96, 16, 8, 1), (112, 16, 4, 1), (128, 16, 4, 1)])
+def test_blocks_beyond_the_lds(ndlqr, oracle, n, m, N, batch):
+    """Block sizes whose S-bar and right-hand-side panel do not fit the LDS of the knot-based separator kernel -- every
+    block beyond 128 states in every mode, strict mode and KEEP_FACT beyond ~82 -- run that kernel with both arrays in
+    global memory (separator_generic, `scratch`): strict mode bit-identical to the oracle on the solution AND the whole
+    factor array, fast mode within tolerance, KEEP_FACT + rhs-only re-solve (the factor read where it lies beyond ~140
+    states), a non-positive weight reported. (Round 3: a solve beyond 128 states returned NDLQR_ERR_INVALID.)"""
+    probs = [synth(ndlqr, n, m, N, 4100 + p) for p in range(batch)]
+    full = [oracle.solve(prob, 8, want_fact=True) for prob in probs]
+    for flags in (ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT, ndlqr.FLAG_KEEP_FACT, 0):
+        bs = ndlqr.BatchSolver(n, m, N, batch, flags=flags)
+        bs.initialize_flat(*stack(probs))
+        assert bs.solve() == 0
+        if flags == 0:
+            assert bs.schedule() == ("generic-lean" if n > 128 else "generic-reduced")
+        sol = bs.solutions()
+        for p, prob in enumerate(probs):
+            z, fact = full[p][0], full[p][1]
+            ref = z[: prob.nvars]
+            if flags & ndlqr.FLAG_STRICT_FP:
+                assert np.array_equal(sol[p], ref)
+                assert np.array_equal(bs.factors(p), fact)
+            else:
+                assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+                ok, detail = _kkt_ok(oracle, prob, sol[p])
+                assert ok, detail
+                # (the matrix-core separator of the tile-filling blocks up to 112 states leaves other leftovers than the
+                #  reference in the never-read upper triangles of the Cholesky factors: compared where separator_generic runs)
+                if (flags & ndlqr.FLAG_KEEP_FACT) and not (n % 16 == 0 and (n + m) % 4 == 0 and n <= 112):
+                    got = bs.factors(p)
+                    assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
+        if flags & ndlqr.FLAG_KEEP_FACT:  # new right-hand side against the kept factor array
+            other = [synth(ndlqr, n, m, N, 4200 + p) for p in range(batch)]
+            mixed = [Problem(n, m, N, a.A, a.B, a.Q, a.R, o.q, o.r, o.d, o.x0) for a, o in zip(probs, other)]
+            bs.set_rhs_flat(*[np.stack([getattr(q, f) for q in mixed]) for f in ("q", "r", "d", "x0")])
+            assert bs.solve_rhs_only() == 0
+            sol = bs.solutions()
+            for p, prob in enumerate(mixed):
+                ref = oracle.solve(prob, 4)[0][: prob.nvars]
+                if flags & ndlqr.FLAG_STRICT_FP:
+                    assert np.array_equal(sol[p], ref)
+                else:
+                    assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+        bs.close()
+    if N >= 4:
+        bad = probs[0]
+        Q = bad.Q.copy()
+        Q[N // 2, 1] = -2.0
+        bs = ndlqr.BatchSolver(n, m, N, 1)
+        bs.initialize_flat(*[np.asarray(a)[None] for a in (bad.A, bad.B, Q, bad.R, bad.q, bad.r, bad.d, bad.x0)])
         assert bs.solve() == -3
         assert bs.cholesky_failures() >= 1
         bs.close()
