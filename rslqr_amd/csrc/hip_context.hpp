@@ -54,6 +54,7 @@ struct NdlqrAltSlot {
   unsigned graph_flags = 0;
   hipStream_t graph_stream = nullptr;
   bool graph_rec_complete = false;
+  bool graph_rec_compact = false;
   const char* graph_schedule = "none";
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
@@ -101,7 +102,10 @@ struct NdlqrHipCtx {
   bool no_top;        // NDLQR_NO_TOP=1: the last three tree levels as launches of their own (A/B timing of reduced_top_mc)
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
+  bool rec_compact;   // ... in the compact form of the default schedule (level-0 records = L, the factors of the upper
+                      // separators in the slack of those slots): the re-solve is rb_forward / rb_forward_top / rb_backsub
   bool graph_rec_complete;  // the same for the captured launch sequence (replays do not re-enter the launch code)
+  bool graph_rec_compact;
   const char* graph_schedule;  // and its name
   int sep_threads;    // NDLQR_SEP_THREADS: workgroup size of the matrix-core separator (0 = by block size)
   hipEvent_t ev_start, ev_stop;

@@ -493,6 +493,28 @@ __device__ __forceinline__ acc4_t leaf_tile_mc(const int lane, const bool first,
   return c;
 }
 
+// store_l == 2 (NDLQR_FLAG_KEEP_RECORDS on the default schedule, round 4): the Cholesky factor of a separator of level >= 1
+// -- n x n, row-major, what the record-based re-solve substitutes with (rb_forward, kernels_rowbcast.hpp) -- goes into the
+// slack of the record slot in front of it: slot s - 1 belongs to a level-0 separator, whose compact record uses
+// n (n + 1) / 2 of the slot's 2 n^2 + n doubles. (store_l == 1: into the factor array, the full-record schedules.)
+template <int NX>
+__device__ __forceinline__ constexpr int rb_lrec_offset() { return (NX * (NX + 1) / 2 + 1) / 2 * 2; }
+// where the Cholesky factor of the separator s of level >= 1 (odd s) is kept: n x n, row-major
+template <int NX>
+__device__ __forceinline__ double* rb_lrec(double* rec, const Dims& d, const int b, const int s) {
+  return rec + ((size_t)b * d.N + (s - 1)) * (2 * NX * NX + NX) + rb_lrec_offset<NX>();
+}
+template <int NX>
+__device__ __forceinline__ const double* rb_lrec(const double* rec, const Dims& d, const int b, const int s) {
+  return rec + ((size_t)b * d.N + (s - 1)) * (2 * NX * NX + NX) + rb_lrec_offset<NX>();
+}
+
+template <int NX>
+__device__ __forceinline__ double* lstore_of(const int store_l, double* F, double* rec, const Dims& d, const int b,
+                                             const int level, const int s) {
+  return store_l == 2 ? rb_lrec<NX>(rec, d, b, s) : (store_l ? Fblk(F, d, b, level, s + 1) : nullptr);
+}
+
 // LDS of one wavefront working on the reduced system: a buffer that first holds the staged inputs
 // and then, once the tiles and the panel columns are in registers, the tiles of the pass; plus the
 // reciprocal weights and right-hand sides of the knots involved. BOTTOM: sized for the four knots of the
@@ -623,7 +645,7 @@ __device__ __forceinline__ void reduced_separator_mc(const Dims& d, const int l,
   SEG(9);
 
   acc4_t X0, X1, unused;
-  if (chol_wy_mc<NX>(lane, c0, lds.buf, wcol, store_l ? Fblk(F, d, b, l, s + 1) : nullptr) && lane == 0)
+  if (chol_wy_mc<NX>(lane, c0, lds.buf, wcol, lstore_of<NX>(store_l, F, rec, d, b, l, s)) && lane == 0)
     flag_failure(info, d, b);
   SEG(31);
   tail_wy_mc<NX>(lane, lds.buf, X0, X1,
@@ -1050,7 +1072,7 @@ __device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, con
     if (slotA) sa.p = slotA;
     if (slotB) sb.p = slotB;
   }
-  if (chol_wy_mc<NX>(lane, c_t, lds.buf, wcol, store_l ? Fblk(F, d, b, 1, k0 + 2) : nullptr) && lane == 0)
+  if (chol_wy_mc<NX>(lane, c_t, lds.buf, wcol, lstore_of<NX>(store_l, F, rec, d, b, 1, k0 + 1)) && lane == 0)
     flag_failure(info, d, b);
   tail_wy_mc<NX>(lane, lds.buf, X0, X1,
                  [&](const double (&R0)[KSN], const double (&R1)[KSN], const acc4_t& Z0, const acc4_t& Z1) {

@@ -748,4 +748,310 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
   z[((size_t)b * N + i) * ROWS + rr] = out;
 }
 
+// ------------------------------------------------------------------------------------- right-hand-side re-solve (round 4)
+// New q, r, d, x0 against what a solve of the default schedule with NDLQR_FLAG_KEEP_RECORDS leaves behind:
+// the compact level-0 records (L of S-bar, packed), the records f_a | f_bb of every separator of level >= 1 and --
+// kept for this -- its Cholesky factor L, n x n row-major, in the slack of the record slot in front of it (slot s - 1
+// belongs to a level-0 separator, which uses n (n + 1) / 2 of its 2 n^2 + n doubles: rb_lrec). Forward pass over the
+// separators, the right-hand-side column of the factorisation alone (b~ = leaf - gL - gR):
+//     level 0:    z_s = (L L')^-1 leafb_s;   gR[s - 1] += r_a(s)' z_s,  gL[s + 1] += r_bb(s)' z_s   (couplings from the data)
+//     level >= 1: b~_s = leafb_s - gL[s] - gR[s];  z_sep(s) = (L L')^-1 b~_s -> record;
+//                 gR[A] += f_a(s)' b~_s,  gL[B] += f_bb(s)' b~_s        (r_a' S-bar^-1 b~ = (S-bar^-1 r_a)' b~)
+// then the back-substitution of a full solve (backsub_top_body, rb_backsub) as it stands. Two launches:
+//   rb_forward      grid (N / 8, batch), block 256: levels 0-2 of eight knots (the staging of rb_backsub plus the
+//                   three factors of level 1 / 2); what the block adds to its two outer separators -> fsum
+//   rb_forward_top  grid (batch), block 256, dynamic LDS 4 (N / 8) NX doubles: levels >= 3 of a problem, level by level,
+//                   and straight on to the top-down sweep -> ytop
+// against 0.73 ms of the full-record re-solve (rhs_forward_small / _upper, backsub_small) and 0.59 of a full solve.
+// x <- (L L')^-1 x for the separator of this lane's 16-lane DPP row (lane r15 of the row: entry r15; lrow[c] = L(r15, c)
+// for c < r15, lcol[c] = L(c, r15) for c > r15, zero elsewhere; dinv = 1 / L(r15, r15)). Every lane of the wavefront
+// executes it (DPP); the freshly resolved entry is broadcast inside the row, no LDS round trip and no barrier per step.
+template <int NX>
+__device__ __forceinline__ double rb_llt_solve(double x, const double (&lrow)[NX], const double (&lcol)[NX], const double dinv) {
+  sfor<NX>([&](auto cc) {  // forward: t_c = x_c / L(c, c) is final when step c starts
+    constexpr int c = decltype(cc)::value;
+    double xs = x * dinv;
+    dpp_fence(xs);
+    x = fma(-lrow[c], row_bc<c>(xs), x);
+  });
+  x = x * dinv;  // t_r
+  sfor<NX>([&](auto cc) {  // backward, c descending: y_c is final when its step starts
+    constexpr int c = NX - 1 - decltype(cc)::value;
+    double xs = x * dinv;
+    dpp_fence(xs);
+    x = fma(-lcol[c], row_bc<c>(xs), x);
+  });
+  return x * dinv;
+}
+
+template <int NX, int NU>
+struct alignas(16) RbForwardLds {
+  static constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, R0 = NX * (NX + 1) / 2;
+  static constexpr int R0P = (R0 + 1) / 2 * 2, WP = RbKnot<NX, NU>::WP;
+  double ab[8][NX * WP];
+  double rec0[4][R0P];    // level-0 separators first + 0, 2, 4, 6: L, packed lower triangle
+  double l1[3][NN];       // separators first + 1, first + 3, first + 5: L, n x n row-major
+  double f1[3][2 * NN];   // ... and their records f_a | f_bb
+  double qs[8][W];        // 1 / [Q | R]
+  double rs[8][ROWS];     // raw right-hand sides
+  double bt[7][NX];       // b~ of the local separators (level 0: leafb)
+  double zs[4][NX];       // z of the level-0 separators
+  double gl[7][NX], gr[7][NX];  // what has been pushed to the local separators of level 1, 2 (slots 1, 3, 5)
+  double outl[3][NX], outr[3][NX];  // contributions to first - 1 (from first, first + 1, first + 3) / first + 7 (first + 6, + 5, + 3)
+};
+
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void rb_forward(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+                                                  const double* __restrict__ rhs, double* __restrict__ recs,
+                                                  double* __restrict__ fsum) {
+  using Lds = RbForwardLds<NX, NU>;
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP, R0 = Lds::R0;
+  static_assert(7 * NX <= 256 && KPB * ROWS <= 256 && KPB * W <= 256, "thread roles fit the workgroup");
+  __shared__ Lds lds;
+  const int N = d.N, b = blockIdx.y, first = blockIdx.x * KPB, t = threadIdx.x;
+  // ---- staging: [A | B] of the eight knots, weights, right-hand sides, the seven separators' factors and records --
+  //      every load is requested before the first store (16-byte words wherever the pieces are 16-byte granules, like
+  //      rb_backsub's)
+  {
+    const double* abm = AB + ((size_t)b * N + first) * NX * W;
+    const double* rc0 = recs + ((size_t)b * N + first) * REC;
+    constexpr bool WIDE = NX % 2 == 0 && R0 % 2 == 0 && (NX * W) % 2 == 0;
+    constexpr int G = WIDE ? 2 : 1;
+    constexpr int NA = KPB * NX * W / G, IA = (NA + 255) / 256;
+    constexpr int N0 = 4 * R0 / G, I0 = (N0 + 255) / 256, NL = 3 * NN / G, IL = (NL + 255) / 256;
+    constexpr int NF = 3 * 2 * NN / G, IF = (NF + 255) / 256;
+    double ta[IA][G], t0[I0][G], tl[IL][G], tf[IF][G];
+    auto ld = [](const double* src, double (&dst)[G]) {
+      if constexpr (WIDE) { const double2 v = *reinterpret_cast<const double2*>(src); dst[0] = v.x; dst[1] = v.y; }
+      else dst[0] = *src;
+    };
+#pragma unroll
+    for (int it = 0; it < IA; ++it) { const int e = t + 256 * it, ec = e < NA ? e : NA - 1; ld(abm + G * ec, ta[it]); }
+#pragma unroll
+    for (int it = 0; it < I0; ++it) {
+      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / (R0 / G), w_ = ec - j * (R0 / G);
+      ld(rc0 + (size_t)(2 * j) * REC + G * w_, t0[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < IL; ++it) {  // (factor of first + 2 j + 1: slack of slot first + 2 j)
+      const int e = t + 256 * it, ec = e < NL ? e : NL - 1, j = ec / (NN / G), w_ = ec - j * (NN / G);
+      ld(rc0 + (size_t)(2 * j) * REC + rb_lrec_offset<NX>() + G * w_, tl[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < IF; ++it) {
+      const int e = t + 256 * it, ec = e < NF ? e : NF - 1, j = ec / (2 * NN / G), w_ = ec - j * (2 * NN / G);
+      ld(rc0 + (size_t)(2 * j + 1) * REC + G * w_, tf[it]);
+    }
+    const double tq = QR[((size_t)b * N + first) * W + (t < KPB * W ? t : KPB * W - 1)];
+    const double tr = rhs[((size_t)b * N + first) * ROWS + (t < KPB * ROWS ? t : KPB * ROWS - 1)];
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+      const int e = t + 256 * it, ec = e < NA ? e : NA - 1;
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        const int ed = G * ec + h, kn = ed / (NX * W), w_ = ed - kn * NX * W, row = w_ / W, c = w_ - row * W;
+        lds.ab[kn][row * WP + c] = ta[it][h];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < I0; ++it) {
+      const int e = t + 256 * it, ec = e < N0 ? e : N0 - 1, j = ec / (R0 / G), w_ = ec - j * (R0 / G);
+#pragma unroll
+      for (int h = 0; h < G; ++h) lds.rec0[j][G * w_ + h] = t0[it][h];
+    }
+#pragma unroll
+    for (int it = 0; it < IL; ++it) {
+      const int e = t + 256 * it, ec = e < NL ? e : NL - 1;
+#pragma unroll
+      for (int h = 0; h < G; ++h) (&lds.l1[0][0])[G * ec + h] = tl[it][h];
+    }
+#pragma unroll
+    for (int it = 0; it < IF; ++it) {
+      const int e = t + 256 * it, ec = e < NF ? e : NF - 1;
+#pragma unroll
+      for (int h = 0; h < G; ++h) (&lds.f1[0][0])[G * ec + h] = tf[it][h];
+    }
+    (&lds.qs[0][0])[t < KPB * W ? t : KPB * W - 1] = 1.0 / tq;
+    (&lds.rs[0][0])[t < KPB * ROWS ? t : KPB * ROWS - 1] = tr;
+  }
+  __syncthreads();
+  const int q = t / NX, r = t - q * NX;
+  const bool sep_thread = q < 7;
+  // ---- leafb of the seven local separators: [A_s | B_s] z-hat(s) - z(s+1).lambda - z(s+1).x / Q_{s+1}
+  if (sep_thread) {
+    const int s = first + q;
+    const bool fst = s == 0;
+    const double* arow = lds.ab[q] + r * WP;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const double wq = lds.qs[q][c];
+      const double zh = (c < NX && fst) ? -lds.rs[q][c] : lds.rs[q][NX + c] * wq;
+      v = fma(arow[c], zh, v);
+    }
+    v -= lds.rs[q + 1][r] + lds.rs[q + 1][NX + r] * lds.qs[q + 1][r];
+    lds.bt[q][r] = v;
+  }
+  __syncthreads();
+  // one wavefront solves with up to four factors at once, one per 16-lane DPP row: sel(j) = local separator of row j
+  auto solve_rows = [&](const int nrows, auto sel, const bool packed) {
+    if (t < 64) {
+      const int j = t >> 4, r15 = t & 15, rc = r15 < NX ? r15 : NX - 1;
+      const int jj = j < nrows ? j : nrows - 1;  // (idle rows shadow a live one)
+      const int sl = sel(jj);
+      double lrow[NX], lcol[NX], dinv;
+      if (packed) {
+        const double* Lp = lds.rec0[sl >> 1];
+        dinv = 1.0 / Lp[rc * (rc + 1) / 2 + rc];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          const double lo = Lp[rc * (rc + 1) / 2 + (c < rc ? c : rc)];
+          const double up = Lp[(c > rc ? c : rc) * ((c > rc ? c : rc) + 1) / 2 + rc];
+          lrow[c] = (c < r15 && r15 < NX) ? lo : 0.0;
+          lcol[c] = (c > r15 && r15 < NX) ? up : 0.0;
+        }
+      } else {
+        const double* Lf = lds.l1[sl >> 1];
+        dinv = 1.0 / Lf[rc * NX + rc];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          lrow[c] = (c < r15 && r15 < NX) ? Lf[rc * NX + c] : 0.0;
+          lcol[c] = (c > r15 && r15 < NX) ? Lf[c * NX + rc] : 0.0;
+        }
+      }
+      const double x = rb_llt_solve<NX>(lds.bt[sl][rc], lrow, lcol, dinv);
+      if (r15 < NX && j < nrows) {
+        if (packed) lds.zs[sl >> 1][r15] = x;
+        else recs[((size_t)b * N + first + sl) * REC + 2 * NN + r15] = x;  // z_sep of a separator of level 1 / 2
+      }
+    }
+  };
+  // ---- level 0
+  solve_rows(4, [](int j) { return 2 * j; }, true);
+  __syncthreads();
+  // what the level-0 separators push: s = first + 2 j to s - 1 (gR) and s + 1 (gL); threads (j, side, r)
+  if (t < 8 * NX) {
+    const int j = t / (2 * NX), side = (t / NX) & 1, rr = t % NX, k = 2 * j;
+    double a = 0.0;
+    if (side == 0) {  // gR[s - 1](rr) = -(1 / Q_s(rr)) (A_s' z)(rr)
+      if (first + k > 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a = fma(lds.ab[k][i * WP + rr], lds.zs[j][i], a);
+        a = -a * lds.qs[k][rr];
+      }
+      if (j == 0) lds.outl[0][rr] = a; else lds.gr[k - 1][rr] = a;
+    } else {          // gL[s + 1](rr) = -(A_{s+1} (z / Q_{s+1}))(rr)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) a = fma(lds.ab[k + 1][rr * WP + i], lds.zs[j][i] * lds.qs[k + 1][i], a);
+      a = -a;
+      if (j == 3) lds.outr[0][rr] = a; else lds.gl[k + 1][rr] = a;
+    }
+  }
+  __syncthreads();
+  // ---- level 1: t = first + 1, first + 5 (local 1, 5)
+  if (t < 2 * NX) { const int sl = t < NX ? 1 : 5, rr = t % NX; lds.bt[sl][rr] -= lds.gl[sl][rr] + lds.gr[sl][rr]; }
+  __syncthreads();
+  solve_rows(2, [](int j) { return 4 * j + 1; }, false);
+  // their pushes: f_a' b~ to the separator left of the subtree, f_bb' b~ to the one right of it; threads (which, side, c)
+  if (t >= 64 && t < 64 + 4 * NX) {
+    const int u = t - 64, which = u / (2 * NX), side = (u / NX) & 1, c = u % NX, sl = 4 * which + 1;
+    const double* f = lds.f1[sl >> 1] + side * NN;
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) a = fma(f[i * NX + c], lds.bt[sl][i], a);
+    // local 1: A = first - 1, B = local 3;   local 5: A = local 3, B = first + 7
+    if (which == 0) { if (side == 0) lds.outl[1][c] = (first > 0) ? a : 0.0; else lds.gl[3][c] += a; }
+    else { if (side == 0) lds.gr[3][c] += a; else lds.outr[1][c] = (first + 8 < N) ? a : 0.0; }
+  }
+  __syncthreads();
+  // ---- level 2: local 3
+  if (t < NX) lds.bt[3][t] -= lds.gl[3][t] + lds.gr[3][t];
+  __syncthreads();
+  solve_rows(1, [](int) { return 3; }, false);
+  if (t >= 64 && t < 64 + 2 * NX) {
+    const int u = t - 64, side = u / NX, c = u % NX;
+    const double* f = lds.f1[1] + side * NN;
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) a = fma(f[i * NX + c], lds.bt[3][i], a);
+    if (side == 0) lds.outl[2][c] = (first > 0) ? a : 0.0; else lds.outr[2][c] = (first + 8 < N) ? a : 0.0;
+  }
+  __syncthreads();
+  // ---- what this block adds to gR of separator first - 1 and to gL of separator first + 7
+  if (t < 2 * NX) {
+    const int side = t / NX, c = t % NX;
+    const double v = side == 0 ? lds.outl[0][c] + lds.outl[1][c] + lds.outl[2][c] : lds.outr[0][c] + lds.outr[1][c] + lds.outr[2][c];
+    fsum[(((size_t)b * (N >> 3) + blockIdx.x) * 2 + side) * NX + c] = v;
+  }
+}
+
+// levels >= 3 of one problem + the top-down sweep. LDS: bt | gl | gr | ytop, each [N / 8][NX] (entry m: separator 8 m + 7).
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void rb_forward_top(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
+                                                      const double* __restrict__ rhs, double* __restrict__ recs,
+                                                      const double* __restrict__ fsum, double* __restrict__ ytop) {
+  constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX;
+  extern __shared__ double sm[];
+  const int N = d.N, K = d.K, b = blockIdx.x, t = threadIdx.x, M = N >> 3;
+  double* bt = sm;
+  double* gl = bt + M * NX;
+  double* gr = gl + M * NX;
+  double* yt = gr + M * NX;
+  // ---- leafb of every separator 8 m + 7 minus what the blocks of rb_forward pushed to it (block m: gL, block m + 1: gR)
+  for (int e = t; e < (M - 1) * NX; e += 256) {
+    const int mq = e / NX, r = e - mq * NX, s = 8 * mq + 7;
+    const double* arow = AB + (((size_t)b * N + s) * NX + r) * W;
+    const double* qr = QR + ((size_t)b * N + s) * W;
+    const double* r0 = rhs + ((size_t)b * N + s) * ROWS;
+    double v = 0.0;
+    for (int c = 0; c < W; ++c) v = fma(arow[c], r0[NX + c] / qr[c], v);  // (s >= 7: never the first knot)
+    v -= r0[ROWS + r] + r0[ROWS + NX + r] / qr[W + r];
+    v -= fsum[(((size_t)b * M + mq) * 2 + 1) * NX + r] + fsum[(((size_t)b * M + mq + 1) * 2 + 0) * NX + r];
+    bt[e] = v;
+    gl[e] = 0.0;
+    gr[e] = 0.0;
+  }
+  __syncthreads();
+  for (int L = 3; L < K; ++L) {
+    const int T = 2 << L, nsep = N >> (L + 1);
+    // b~ and z_sep = (L L')^-1 b~ of the level's separators, one per 16-lane DPP row, sixteen per round
+    for (int q0 = 0; q0 < nsep; q0 += 16) {
+      const int j = t >> 4, r15 = t & 15, rc = r15 < NX ? r15 : NX - 1;
+      const int qq = q0 + j < nsep ? q0 + j : nsep - 1;
+      const int s = qq * T + (T >> 1) - 1, mq = s >> 3;
+      const double* Lf = rb_lrec<NX>((const double*)recs, d, b, s);
+      double lrow[NX], lcol[NX];
+      const double dinv = 1.0 / Lf[rc * NX + rc];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        lrow[c] = (c < r15 && r15 < NX) ? Lf[rc * NX + c] : 0.0;
+        lcol[c] = (c > r15 && r15 < NX) ? Lf[c * NX + rc] : 0.0;
+      }
+      const double bv = bt[mq * NX + rc] - gl[mq * NX + rc] - gr[mq * NX + rc];
+      const double x = rb_llt_solve<NX>(bv, lrow, lcol, dinv);
+      if (r15 < NX && q0 + j < nsep) {
+        bt[mq * NX + r15] = bv;
+        recs[((size_t)b * N + s) * REC + 2 * NN + r15] = x;
+      }
+    }
+    __syncthreads();
+    // pushes of the level: f_a' b~ -> gR of the separator left of the subtree, f_bb' b~ -> gL of the one right of it
+    for (int e = t; e < nsep * 2 * NX; e += 256) {
+      const int qq = e / (2 * NX), side = (e / NX) & 1, c = e % NX;
+      const int base = qq * T, s = base + (T >> 1) - 1;
+      const int nb = side == 0 ? base - 1 : base + T - 1;
+      if (nb < 0 || nb >= N - 1) continue;
+      const double* f = recs + ((size_t)b * N + s) * REC + side * NN;
+      const double* bs = bt + (s >> 3) * NX;
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) a = fma(f[i * NX + c], bs[i], a);
+      (side == 0 ? gr : gl)[(nb >> 3) * NX + c] += a;  // (one contributor per level and side: no race)
+    }
+    __syncthreads();
+  }
+  backsub_top_body<NX>(d, b, t, recs, ytop, yt);
+}
+
+
 }  // namespace ndlqr

@@ -47,22 +47,26 @@ static SmallPlan plan_small(const NdlqrHipCtx* c) {
       // tree schedule for small batches (at most half a resident round of bottom wavefronts): three
       // launches instead of K + 1; measured cross-over at batch x N / 4 ~ 4096 wavefronts
       p.tree = c->tree_cnt && (c->tree == 1 || (c->tree < 0 && (size_t)d.batch * (d.N >> 2) <= 2048));
-      // compact level-0 records (S-bar^-1 only): not what a record-based re-solve reads, and the tree
-      // schedule keeps the one-kernel back-substitution; rb_backsub's thread roles need 8 (2 nx + nu) <= 256
-      // (and rb_backsub_top's sweep array, N / 8 multipliers, has to fit the LDS of its one workgroup per problem)
-      p.compact = !p.tree && !p.store_l && d.N >= 16 && 8 * (2 * NX + NU) <= 256 &&
-                  sizeof(double) * (size_t)(d.N >> 3) * NX <= 160 * 1024;
+      // compact level-0 records (L of S-bar only) and the two-launch back-substitution: the tree schedule keeps the
+      // one-kernel back-substitution; rb_backsub's thread roles need 8 (2 nx + nu) <= 256 (and rb_backsub_top's sweep
+      // array, N / 8 multipliers, has to fit the LDS of its one workgroup per problem). With KEEP_RECORDS (round 4): the
+      // same schedule, which then also keeps the factors of the separators of level >= 1 in the slack of the level-0
+      // record slots (store_l = 2; the record-based re-solve rb_forward / rb_forward_top works on that: four sweep
+      // arrays in the LDS of its one workgroup per problem)
+      p.compact = !p.tree && d.N >= 16 && 8 * (2 * NX + NU) <= 256 &&
+                  sizeof(double) * (size_t)(d.N >> 3) * NX * (p.store_l ? 4 : 1) <= 160 * 1024;
+      if (p.compact && p.store_l) p.store_l = 2;
       // row-broadcast bottom kernel (one DPP row holds the rows of S-bar and of [A | B]'): its cost falls
       // with the block size, the matrix-core kernel's does not (16x16 tiles whatever n is). Measured bottom
       // kernel, N = 256 x 1024: (6,3) 0.105 vs 0.170 ms, (8,4) 0.144 vs 0.190, (9,3) 0.202 vs 0.244,
       // (10,4) 0.230 vs 0.271, (12,4) 0.301 vs 0.290 in round 2. Round 3 (paired Cholesky pass that carries the panel):
       // (10,4) 0.230 vs 0.207, (9,3) 0.203 vs 0.187, (8,4) 0.143 vs 0.152, (6,3) 0.104 vs 0.134 -- so it serves n <= 8
       // (NDLQR_ROWBCAST=0/1 overrides)
-      p.rowbcast = p.compact && NX <= 16 && NX + NU <= 16 && (c->rowbcast == 1 || (c->rowbcast < 0 && NX <= 8));
+      p.rowbcast = p.compact && !p.store_l && NX <= 16 && NX + NU <= 16 && (c->rowbcast == 1 || (c->rowbcast < 0 && NX <= 8));
     }
   }
-  // the separator-only schedule touches F only to park the factors of KEEP_RECORDS
-  p.needs_F = !(p.reduced && !p.store_l);
+  // the separator-only schedule touches F only to park the factors of KEEP_RECORDS under its full-record forms
+  p.needs_F = !(p.reduced && p.store_l != 1);
   return p;
 }
 
@@ -83,7 +87,8 @@ static int launch_small(NdlqrHipCtx* c) {
       // compact level-0 records + the two-launch back-substitution (kernels_rowbcast.hpp), unless the
       // records have to serve a record-based re-solve (KEEP_RECORDS) or the tree schedule runs
       const bool compact = plan.compact;
-      c->schedule = tree ? "reduced-tree" : (compact ? "reduced" : "reduced-records");
+      c->schedule = tree ? "reduced-tree" : (compact ? (store_l ? "reduced-compact-records" : "reduced") : "reduced-records");
+      c->rec_compact = compact && store_l == 2;
       bool fuse2 = false;
       {
         ScopedSlot t(c, SLOT_BOTTOM);
@@ -177,6 +182,31 @@ static int launch_small(NdlqrHipCtx* c) {
 template <int NX, int NU>
 static void launch_rhs_records(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
+  if constexpr (ndlqr::P1OnMatrixCores<NX, NU>::value && 8 * (2 * NX + NU) <= 256) {
+    if (c->rec_compact) {
+      // the compact records of the default schedule (round 4): forward pass over the separators with the right-hand-side
+      // column alone, then the back-substitution of a full solve. c->red (the accumulator slots, idle here) holds what
+      // the eight-knot blocks push to the separators between them: [batch][N / 8][2][NX].
+      {
+        ScopedSlot t(c, SLOT_SEP);
+        hipLaunchKernelGGL((ndlqr::rb_forward<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB, c->QR,
+                           c->rhs, c->rec, c->red);
+      }
+      {
+        ScopedSlot t(c, SLOT_UPPER);
+        const size_t lds = sizeof(double) * 4 * (size_t)(d.N >> 3) * NX;
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ndlqr::rb_forward_top<NX, NU>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ndlqr::rb_forward_top<NX, NU>), dim3(d.batch), dim3(256), lds, c->stream, d, c->AB, c->QR,
+                           c->rhs, c->rec, (const double*)c->red, c->ytop);
+      }
+      ScopedSlot t(c, SLOT_APPLY);
+      hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB, c->QR,
+                         c->rhs, c->rec, c->ytop, c->z);
+      return;
+    }
+  }
   {
     ScopedSlot t(c, SLOT_SEP);
     hipLaunchKernelGGL((ndlqr::rhs_forward_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(64), 0, c->stream, d, c->AB,

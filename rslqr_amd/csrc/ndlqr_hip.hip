@@ -103,7 +103,7 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   c->AB = c->QR = c->rhs = c->F = c->z = c->rec = c->red = nullptr; c->info = nullptr; c->tree_cnt = nullptr;
   c->pipeline = getenv("NDLQR_PIPELINE") ? atoi(getenv("NDLQR_PIPELINE")) : 2;
   c->solve_count = 0; c->in_alt = false; c->z_latest = nullptr; c->stream_latest = nullptr; c->h_fail_other = nullptr;
-  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->xfer = nullptr; c->h_stage[0] = c->h_stage[1] = nullptr; c->ev_inputs = nullptr; c->ev_step[0] = c->ev_step[1] = nullptr; c->step_count = 0; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false; c->graph_schedule = "none";
+  c->state_dirty = false; c->fail_base = 0; c->ytop = nullptr; c->schedule = "none"; c->kkt_out = nullptr; c->xfer = nullptr; c->h_stage[0] = c->h_stage[1] = nullptr; c->ev_inputs = nullptr; c->ev_step[0] = c->ev_step[1] = nullptr; c->step_count = 0; c->h_fail = nullptr; c->rec_complete = false; c->graph_rec_complete = false; c->graph_schedule = "none"; c->rec_compact = false; c->graph_rec_compact = false;
 
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->rowbcast = getenv("NDLQR_ROWBCAST") ? (atoi(getenv("NDLQR_ROWBCAST")) != 0 ? 1 : 0) : -1;  // -1: by block size
@@ -195,6 +195,7 @@ static void swap_slot(NdlqrHipCtx* c) {
   std::swap(c->tree_cnt, a.tree_cnt); std::swap(c->h_fail, a.h_fail); std::swap(c->stream, a.stream);
   std::swap(c->graph_exec, a.graph_exec); std::swap(c->graph_flags, a.graph_flags);
   std::swap(c->graph_stream, a.graph_stream); std::swap(c->graph_rec_complete, a.graph_rec_complete);
+  std::swap(c->graph_rec_compact, a.graph_rec_compact);
   std::swap(c->graph_schedule, a.graph_schedule);
   std::swap(c->ev_start, a.ev_start); std::swap(c->ev_stop, a.ev_stop);
   c->in_alt = !c->in_alt;
@@ -829,6 +830,7 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   int err = NDLQR_OK;
   bool done = false;
   c->rec_complete = false;
+  c->rec_compact = false;
   done = try_launch_small(c, strict, &err);
   if (!done) {
     const ReducedGenericPlan rp = plan_reduced_generic(c);
@@ -923,11 +925,13 @@ static int launch_solve(NdlqrHipCtx* c) {
       if (e != hipSuccess) { c->graph_exec = nullptr; return fail("hipGraphInstantiate", e); }
       c->graph_flags = c->flags;
       c->graph_stream = c->stream;
-      c->graph_rec_complete = c->rec_complete;  // what the captured sequence leaves behind
+      c->graph_rec_complete = c->rec_complete;
+      c->graph_rec_compact = c->rec_compact;  // what the captured sequence leaves behind
       c->graph_schedule = c->schedule;
     }
     HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
     c->rec_complete = c->graph_rec_complete;
+    c->rec_compact = c->graph_rec_compact;
     c->schedule = c->graph_schedule;
   }
   if (err) return err;
@@ -1048,10 +1052,12 @@ int ndlqr_hip_solve_staged(NdlqrHipCtx* c) {
       if (e != hipSuccess) { c->graph_staged = nullptr; return fail("hipGraphInstantiate", e); }
       c->graph_staged_flags = c->flags;
       c->graph_rec_complete = c->rec_complete;
+      c->graph_rec_compact = c->rec_compact;
       c->graph_schedule = c->schedule;
     }
     HIP_TRY(hipGraphLaunch(c->graph_staged, c->stream));
     c->rec_complete = c->graph_rec_complete;
+    c->rec_compact = c->graph_rec_compact;
     c->schedule = c->graph_schedule;
   }
   HIP_TRY(hipGetLastError());
@@ -1343,9 +1349,12 @@ static bool try_launch_rhs_records(NdlqrHipCtx* c) {
     return true;
   }
   if (c->flags & NDLQR_FLAG_GENERIC) return false;
-  if (d.N < 8 || (size_t)(d.N / 8) * d.n * sizeof(double) > 60 * 1024) return false;
   const SmallInstance* inst = find_small(d);
-  if (!inst || (d.K + 4) * inst->nx > 256) return false;
+  if (!inst) return false;
+  // (the full-record forms: sweep array of rhs_forward_upper within the default dynamic LDS, backsub_small's K + 4
+  //  separators of nx rows in one workgroup; the compact form -- rb_forward / rb_forward_top -- was checked by its plan)
+  if (!c->rec_compact && (d.N < 8 || (size_t)(d.N / 8) * d.n * sizeof(double) > 60 * 1024 || (d.K + 4) * inst->nx > 256))
+    return false;
   inst->rhs(c);
   return true;
 }

@@ -422,6 +422,44 @@ HARD_SHAPES = [(64, 16, 64, 1, "generic-reduced"), (32, 8, 128, 1, "generic-redu
                (4, 2, 128, 3, "knot-lean"), (5, 2, 64, 3, "knot-lean"), (2, 1, 64, 3, "knot-lean")]
 
 
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 256, 9), (12, 4, 16, 3), (13, 4, 64, 3), (9, 3, 32, 4), (10, 4, 128, 2),
+                                         (6, 3, 64, 5), (8, 4, 1024, 2), (11, 3, 64, 2), (12, 8, 16, 2), (15, 2, 32, 2),
+                                         (12, 4, 2048, 1)])
+@pytest.mark.parametrize("a_scale,q_scale,r_scale", [(1.0, 1.0, 1.0), (1.0, 1.0, 1e-4), (1.3, 1e-3, 1.0)])
+def test_resolve_on_compact_records(ndlqr, oracle, n, m, N, batch, a_scale, q_scale, r_scale, monkeypatch):
+    """NDLQR_FLAG_KEEP_RECORDS on the level-per-launch default schedule (round 4): the solve keeps its compact records --
+    L of the level-0 separators, f_a | f_bb of the upper ones and, in the slack of the level-0 slots, their factors; no
+    factor array -- and ndlqr_SolveBatchRhsOnly runs the right-hand-side column alone (rb_forward, rb_forward_top,
+    rb_backsub). New q, r, d AND x0 (the fixed state of knot 0), twice, each against the oracle's full solve."""
+    monkeypatch.setenv("NDLQR_TREE", "0")
+    gs, probs = zip(*[hard_problem(ndlqr, n, m, N, 600 + p, a_scale, q_scale, r_scale) for p in range(batch)])
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=ndlqr.FLAG_KEEP_RECORDS)
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0
+    assert bs.schedule() == "reduced-compact-records", bs.schedule()
+    sol = bs.solutions()
+    for p in sorted(set([0, batch - 1])):
+        ref = oracle.solve(probs[p], 8)[0][: probs[p].nvars]
+        assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
+    for rnd in range(2):
+        other = [hard_problem(ndlqr, n, m, N, 700 + 50 * rnd + p, a_scale, q_scale, r_scale)[1] for p in range(batch)]
+        mixed = [Problem(n, m, N, a.A, a.B, a.Q, a.R, o.q, o.r, o.d, o.x0) for a, o in zip(probs, other)]
+        bs.set_rhs_flat(*[np.stack([getattr(q, f) for q in mixed]) for f in ("q", "r", "d", "x0")])
+        for rep in range(2):  # (the re-solve leaves the cached factorisation as it found it)
+            assert bs.solve_rhs_only() == 0
+            sol = bs.solutions()
+            for p in sorted(set([0, batch // 2, batch - 1])):
+                ref = oracle.solve(mixed[p], 8)[0][: mixed[p].nvars]
+                rel = np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref)
+                assert rel <= REL_TOL, (rnd, rep, p, rel)
+        res, bn = bs.kkt_residuals()
+        ores, obn = oracle.kkt_residual(mixed[0], oracle.solve(mixed[0], 8)[0][: mixed[0].nvars])
+        assert float((res / np.maximum(1.0, bn)).max()) <= 10.0 * ores / max(1.0, obn) + 1e-11
+    # a full solve afterwards still works (same records, same schedule)
+    assert bs.solve() == 0 and bs.schedule() == "reduced-compact-records"
+    bs.close()
+
+
 @pytest.mark.parametrize("n,m,N,batch,want", HARD_SHAPES)
 @pytest.mark.parametrize("a_scale,q_scale,r_scale", HARD_FAMILIES)
 def test_harder_families_large_and_padded_paths(ndlqr, oracle, n, m, N, batch, want, a_scale, q_scale, r_scale):
