@@ -201,9 +201,13 @@ __device__ __forceinline__ void sep_panel_solve(const SepGeom& g, const double* 
 // blocks are resident -- 67 KB at n = 64 instead of 116 KB for the whole panel, so that two
 // workgroups share a CU and the barriers of one overlap with the products of the other.
 //   grid (N >> (l+1), batch), block 64 * nwave, dynamic LDS = n (n + 1) + n (16 min(CT, ctl) + 1) + 17 n doubles.
+// scratch != nullptr (blocks beyond 112 states, round 4): S-bar / L lives in global memory -- per workgroup
+// `scratch_pitch` doubles at scratch + workgroup index * scratch_pitch, in the L2 of its XCD -- and the LDS holds the panel
+// chunk and the inverses of the diagonal blocks alone (n (16 min(CT, ctl) + 1) + 17 n doubles: 135 KB at n = 256).
 template <int CT>
 __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, double* F, double* z,
-                               int* __restrict__ info, double* __restrict__ rec) {
+                               int* __restrict__ info, double* __restrict__ rec, double* scratch = nullptr,
+                               const size_t scratch_pitch = 0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = d.n, w = d.w, N = d.N;
   const int b = blockIdx.y;
@@ -212,8 +216,8 @@ __global__ void separator_mfma(Dims d, int l, const double* __restrict__ AB, dou
   outer_columns(base, l, N, a, bb);
   const int ns = n + 1, tiles = n >> 4, ctl = 2 * tiles + 1;  // column tiles: f_a, f_bb, [z_sep | padding]
   const int ctc = ctl < CT ? ctl : CT, xs = 16 * ctc + 1;
-  double* S = sm;
-  double* X = S + n * ns;
+  double* S = scratch ? scratch + ((size_t)b * gridDim.x + blockIdx.x) * scratch_pitch : sm;
+  double* X = scratch ? sm : S + n * ns;
   double* Wd = X + (size_t)n * xs;  // n / 16 blocks of 16 x 17: inverses of the diagonal blocks of L
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwave = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;

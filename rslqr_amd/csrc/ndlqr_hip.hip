@@ -639,11 +639,14 @@ static GenericSepPlan plan_generic_sep(const NdlqrHipCtx* c, const bool strict) 
   if (p.mfma) {  // separator_mfma: a wavefront per tile of a block row of W, at most three panel tiles per wavefront
     const int need = (d.n / 16) > ((d.n / 16) * ctc + 2) / 3 ? (d.n / 16) : ((d.n / 16) * ctc + 2) / 3;
     if (p.threads < 64 * need) p.threads = 64 * need;
-    if (p.threads > 1024 || lds_mfma > 160 * 1024) p.mfma = false;
+    if (p.threads > 1024) p.mfma = false;
   }
   if (p.mfma) {
-    p.lds = lds_mfma;
-    return p;
+    // (beyond 112 states S-bar / L goes to global memory: the panel chunk and the inverses of the diagonal blocks stay)
+    const size_t lds_no_s = lds_mfma - sizeof(double) * (size_t)d.n * (d.n + 1);
+    if (lds_mfma <= 160 * 1024) { p.lds = lds_mfma; return p; }
+    if (lds_no_s <= 160 * 1024) { p.lds = lds_no_s; p.scratch = true; return p; }
+    p.mfma = false;
   }
   p.scratch = lds_generic > 160 * 1024;
   p.lds = p.scratch ? 0 : lds_generic;
@@ -681,7 +684,8 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
       ScopedSlot t(c, SLOT_SEP);
       if (p1mfma)
         hipLaunchKernelGGL((ndlqr::separator_mfma<kSepChunkTiles>), dim3(nsub, d.batch), dim3(sep_threads), lds,
-                           c->stream, d, l, c->AB, c->F, c->z, c->info, rec);
+                           c->stream, d, l, c->AB, c->F, c->z, c->info, rec, sep_scratch,
+                           (size_t)d.n * (d.n + 1) + (size_t)d.n * (2 * d.n + 1));
       else
         hipLaunchKernelGGL((ndlqr::separator_generic<STRICT>), dim3(nsub, d.batch), dim3(sep_threads), lds,
                            c->stream, d, l, c->AB, c->F, c->z, c->info, rec, sep_scratch);

@@ -219,7 +219,8 @@ def test_separator_only_schedule_large_blocks(ndlqr, oracle, n, m, N, batch, mon
 
 
 @pytest.mark.parametrize("n,m,N,batch", [(144, 16, 8, 2), (130, 5, 4, 1), (160, 16, 16, 1), (150, 10, 8, 2), (200, 8, 4, 1),
-                                         (256, 32, 4, 1), (96, 16, 8, 1), (112, 16, 4, 1), (128, 16, 4, 1)])
+                                         (256, 32, 4, 1), (96, 16, 8, 1), (112, 16, 4, 1), (128, 16, 4, 1), (176, 14, 4, 1),
+                                         (240, 16, 8, 1)])
 def test_blocks_beyond_the_lds(ndlqr, oracle, n, m, N, batch):
     """Block sizes whose S-bar and right-hand-side panel do not fit the LDS of the knot-based separator kernel -- every
     block beyond 128 states in every mode, strict mode and KEEP_FACT beyond ~82 -- run that kernel with both arrays in
@@ -245,9 +246,9 @@ def test_blocks_beyond_the_lds(ndlqr, oracle, n, m, N, batch):
                 assert np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= REL_TOL
                 ok, detail = _kkt_ok(oracle, prob, sol[p])
                 assert ok, detail
-                # (the matrix-core separator of the tile-filling blocks up to 112 states leaves other leftovers than the
-                #  reference in the never-read upper triangles of the Cholesky factors: compared where separator_generic runs)
-                if (flags & ndlqr.FLAG_KEEP_FACT) and not (n % 16 == 0 and (n + m) % 4 == 0 and n <= 112):
+                # (the matrix-core separator of the tile-filling blocks leaves other leftovers than the reference in the
+                #  never-read upper triangles of the Cholesky factors: compared where separator_generic runs)
+                if (flags & ndlqr.FLAG_KEEP_FACT) and not (n % 16 == 0 and (n + m) % 4 == 0):
                     got = bs.factors(p)
                     assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
         if flags & ndlqr.FLAG_KEEP_FACT:  # new right-hand side against the kept factor array
