@@ -248,7 +248,8 @@ def test_blocks_beyond_the_lds(ndlqr, oracle, n, m, N, batch):
                 assert ok, detail
                 # (the matrix-core separator of the tile-filling blocks leaves other leftovers than the reference in the
                 #  never-read upper triangles of the Cholesky factors: compared where separator_generic runs)
-                if (flags & ndlqr.FLAG_KEEP_FACT) and not (n % 16 == 0 and (n + m) % 4 == 0):
+                # (beyond 128 states every block runs padded to the next tile-filling size: no separator_generic there)
+                if (flags & ndlqr.FLAG_KEEP_FACT) and not (n > 128 or (n % 16 == 0 and (n + m) % 4 == 0)):
                     got = bs.factors(p)
                     assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
         if flags & ndlqr.FLAG_KEEP_FACT:  # new right-hand side against the kept factor array

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rslqr_amd as R  # noqa: E402
 
-for (n, m, N, batch) in [(128, 16, 64, 8), (144, 16, 64, 8), (160, 16, 64, 8), (192, 16, 64, 4), (256, 32, 32, 4)]:
+for (n, m, N, batch) in [(128, 16, 64, 8), (144, 16, 64, 8), (150, 10, 64, 8), (160, 16, 64, 8), (192, 16, 64, 4), (200, 8, 32, 4),
+                         (256, 32, 32, 4)]:
     for flags in (0, R.FLAG_STRICT_FP, R.FLAG_KEEP_FACT):
         try:
             bs = R.BatchSolver(n, m, N, batch, flags=flags)
