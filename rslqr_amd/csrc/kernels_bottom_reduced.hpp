@@ -1093,15 +1093,18 @@ __device__ __forceinline__ void bottom_group_mc(const Dims& d, const int k0, con
   SEG(36);
 }
 
-template <int NX, int NU, bool TREE>
+// COMPACT: the instantiation of the default schedule (compact level-0 records: `compact0` is taken as 1 and the
+// full-record path is not compiled in -- 104 instead of 126 VGPRs at (12,4), no spills at (13,4) and (15,2)).
+template <int NX, int NU, bool TREE, bool COMPACT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bottom_reduced_mc(
     Dims d, const double* __restrict__ AB, const double* __restrict__ QR, const double* __restrict__ rhs,
     double* red, double* __restrict__ rec, double* F, int* __restrict__ info, const int store_l, int* cnt,
     const int compact0) {
+  static_assert(!(TREE && COMPACT), "the tree schedule keeps full records");
   __shared__ ReducedLds<NX, NU> lds;
   const int lane = threadIdx.x, b = blockIdx.y, N = d.N, k0 = (blockIdx.x + d.xoff) * 4;
-  bottom_group_mc<NX, NU, TREE, false>(d, k0, b, lane, AB, QR, rhs, red, rec, F, info, store_l, compact0, lds, nullptr,
-                                       nullptr);
+  bottom_group_mc<NX, NU, TREE, false>(d, k0, b, lane, AB, QR, rhs, red, rec, F, info, store_l, COMPACT ? 1 : compact0, lds,
+                                       nullptr, nullptr);
 
   if constexpr (TREE) {
     int l = 1, base = k0;  // finished: the level-l separator of subtree [base, base + 2^(l+1))

@@ -112,9 +112,12 @@ static int launch_small(NdlqrHipCtx* c) {
         } else if (tree)
           hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, true>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream,
                              d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, c->tree_cnt, 0);
+        else if (compact)
+          hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, false, true>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream,
+                             d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, nullptr, 1);
         else
           hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, false>), dim3(d.N >> 2, d.batch), dim3(64), 0, c->stream,
-                             d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, nullptr, compact ? 1 : 0);
+                             d, c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, store_l, nullptr, 0);
       }
       // upper levels: one launch per level while a level has more than four separators per problem, then the
       // last three levels in one launch (reduced_top_mc; NDLQR_NO_TOP=1: a launch per level to the root)
@@ -264,7 +267,7 @@ static int launch_time_shard(NdlqrHipCtx* c, const int phase, const int g, const
         ScopedSlot t(c, SLOT_BOTTOM);
         const int cnt = (d.N >> 2) / G;
         d.xoff = g * cnt;
-        hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, false>), dim3(cnt, d.batch), dim3(64), 0, c->stream, d,
+        hipLaunchKernelGGL((ndlqr::bottom_reduced_mc<NX, NU, false, true>), dim3(cnt, d.batch), dim3(64), 0, c->stream, d,
                            c->AB, c->QR, c->rhs, c->red, c->rec, c->F, c->info, 0, nullptr, 1);
       }
       for (int l = 2; l < ltop; ++l) {
