@@ -611,6 +611,46 @@ def config4_leg(rslqr_amd, sharding, dist, torch, rank, world, device, backend, 
         bs.close()
 
 
+def multi_rhs_mode(rslqr_amd, n, m, N, device, seed0, nrhs=1024):
+    """ndlqr_SolveBatchMultiRhs: ONE problem, `nrhs` right-hand sides against its one kept factorisation (SURVEY 8f-2
+    "multiple right-hand sides"; the reference's NdData holds a single one): device time of the solve kernels, and the whole
+    call with its (pageable) transfers."""
+    os.environ["NDLQR_TREE"] = "0"  # (the level-per-launch schedule keeps the compact records at batch 1 too)
+    try:
+        bs = rslqr_amd.BatchSolver(n, m, N, 1, device=device, flags=rslqr_amd.FLAG_KEEP_RECORDS)
+    finally:
+        del os.environ["NDLQR_TREE"]
+    try:
+        bs.initialize_synthetic(seed0)
+        if bs.solve() != 0 or bs.schedule() != "reduced-compact-records":
+            return {"error": "no compact records for this shape (%s)" % bs.schedule()}
+        rng = np.random.default_rng(5)
+        q, d = rng.standard_normal((nrhs, 1, N, n)), 0.1 * rng.standard_normal((nrhs, 1, N, n))
+        r, x0 = rng.standard_normal((nrhs, 1, N, m)), rng.standard_normal((nrhs, 1, n))
+        out = np.empty((nrhs, 1, bs.nvars))
+        bs.solve_multi_rhs(q, r, d, x0, out=out)
+        best, wall = 1e9, 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            bs.solve_multi_rhs(q, r, d, x0, out=out)
+            wall = min(wall, (time.perf_counter() - t0) * 1e3)
+            best = min(best, bs.solve_ms())
+        # one of them against a plain solve of the same problem with that right-hand side
+        chk = rslqr_amd.BatchSolver(n, m, N, 1, device=device)
+        try:
+            chk.initialize_synthetic(seed0)
+            chk.set_rhs_flat(q[7], r[7], d[7], x0[7])
+            chk.solve()
+            ref = chk.solutions()[0]
+        finally:
+            chk.close()
+        return {"workload": "1 problem x %d right-hand sides" % nrhs, "kernel_ms": best, "solves_per_s": nrhs / best * 1e3,
+                "call_ms_incl_pageable_transfers": wall,
+                "rel_err_vs_plain_solve": float(np.linalg.norm(out[7, 0] - ref) / np.linalg.norm(ref))}
+    finally:
+        bs.close()
+
+
 def time_mode(rslqr_amd, n, m, N, batch, device, seed0, flags, steps, rhs_only=False):
     """ms per step of one more mode of the same workload (own solver, same synthetic problems)."""
     bs = rslqr_amd.BatchSolver(n, m, N, batch, device=device, flags=flags)
@@ -899,6 +939,10 @@ def main():
             bs.close()  # the second solver of this leg needs the memory at the large-block sizes
             result["modes"]["rhs_only (flags=16 records kept, new right-hand side per step)"] = \
                 time_mode(rslqr_amd, n, m, N, batch, local_rank, seed0, 16, msteps, rhs_only=True)
+            if not big:
+                log("secondary mode (one problem, 1024 right-hand sides)")
+                result["modes"]["multi_rhs (flags=16, ndlqr_SolveBatchMultiRhs)"] = \
+                    multi_rhs_mode(rslqr_amd, n, m, N, local_rank, seed0)
         if config4 is not None:
             result.setdefault("configs", {})["config4: (12,4,1024) x %d per GPU x %d GPUs" % (args.config4_batch, world)] = config4
         if not args.no_cpu:  # (rank 0 at any N: the other ranks wait at the closing barrier meanwhile)

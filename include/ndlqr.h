@@ -386,6 +386,14 @@ int ndlqr_SolveBatch(NdLqrBatchSolver* bs);      /* launch + wait */
 int ndlqr_BatchSetRhsFlat(NdLqrBatchSolver* bs, const double* q, const double* r, const double* d,
                           const double* x0);
 int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs);
+/* additive: nrhs sets of right-hand sides for the whole batch against the factorisation kept by the last ndlqr_SolveBatch
+ * with NDLQR_FLAG_KEEP_RECORDS -- q, d [nrhs][batch][N][n], r [nrhs][batch][N][m], x0 [nrhs][batch][n] (the flat layout above
+ * with a leading [nrhs]) in, solutions [nrhs][batch][nvars] out (host arrays; blocking). The reference solves one
+ * right-hand side per factorisation (src/nddata.h:70-75); here e.g. ONE problem of (12,4,256) takes 1024 right-hand sides
+ * (sampled initial states / cost offsets of one model) at the rate its right-hand sides and solutions move through the
+ * HBM. Size-specialised shapes on the level-per-launch schedule (batch x N / 4 > 2048, or NDLQR_TREE=0 in the environment). */
+int ndlqr_SolveBatchMultiRhs(NdLqrBatchSolver* bs, int nrhs, const double* q, const double* r, const double* d,
+                             const double* x0, double* soln);
 int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs); /* enqueue on the solver's stream */
 int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
 /* One MPC step, asynchronous: new q, r, d, x0 (flat host layout as above) up, factor + solve against the resident

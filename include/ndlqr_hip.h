@@ -96,6 +96,14 @@ int ndlqr_hip_pipeline_depth(const NdlqrHipCtx* ctx);
 int ndlqr_hip_upload_rhs(NdlqrHipCtx* ctx, int p0, int count, const double* rhs);
 int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* ctx);
 double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
+/* Several right-hand sides per problem against one kept factorisation each (the reference's NdData holds a single
+ * right-hand side, src/nddata.h:70-75): nrhs sets of right-hand sides for the whole batch, flat HOST arrays in the layout of
+ * ndlqr_BatchSetRhsFlat with a leading [nrhs] -- q, d [nrhs][batch][N][n], r [nrhs][batch][N][m], x0 [nrhs][batch][n] --,
+ * solutions [nrhs][batch][nvars] into soln. Needs the records of a solve with NDLQR_FLAG_KEEP_RECORDS on a size-specialised
+ * shape in the level-per-launch form (batch x N / 4 > 2048 or NDLQR_TREE=0), else NDLQR_ERR_INVALID. Blocking;
+ * ndlqr_hip_last_solve_ms then reports the device time of the solve kernels alone. */
+int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* ctx, int nrhs, const double* q, const double* r, const double* d,
+                              const double* x0, double* soln);
 
 /* One MPC step, asynchronous: a new right-hand side up (flat host arrays in the reference's layout: q, d
  * [batch][N][n], r [batch][N][m], x0 [batch][n] -- what ndlqr_InitializeWithLQRProblem reads from the problem,

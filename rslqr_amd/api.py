@@ -223,6 +223,7 @@ def lib():
     proto("ndlqr_SolveBatch", ci, vp)
     proto("ndlqr_BatchSetRhsFlat", ci, vp, dp, dp, dp, dp)
     proto("ndlqr_SolveBatchRhsOnly", ci, vp)
+    proto("ndlqr_SolveBatchMultiRhs", ci, vp, ci, dp, dp, dp, dp, dp)
     proto("ndlqr_SolveBatchAsync", ci, vp)
     proto("ndlqr_BatchStepAsync", ci, vp, dp, dp, dp, dp, dp)
     proto("ndlqr_BatchSynchronizePrevious", ci, vp)
@@ -370,6 +371,21 @@ class BatchSolver:
         """Solution sweep against the cached factorisation (needs FLAG_KEEP_FACT, or FLAG_KEEP_RECORDS
         in fast mode on a size-specialised shape, on the solve)."""
         return self.L.ndlqr_SolveBatchRhsOnly(self.h)
+
+    def solve_multi_rhs(self, q, r, d, x0, out=None):
+        """nrhs sets of right-hand sides for the whole batch against the records kept by the last solve (FLAG_KEEP_RECORDS,
+        level-per-launch schedule): q, d [nrhs][batch][N][n], r [nrhs][batch][N][m], x0 [nrhs][batch][n] ->
+        solutions [nrhs][batch][nvars]. Blocking; solve_ms() afterwards = device time of the solve kernels alone."""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (q, r, d, x0)]
+        nrhs = arrs[3].shape[0]
+        assert arrs[0].shape == (nrhs, self.batch, self.N, self.n) and arrs[1].shape == (nrhs, self.batch, self.N, self.m)
+        assert arrs[2].shape == (nrhs, self.batch, self.N, self.n) and arrs[3].shape == (nrhs, self.batch, self.n)
+        if out is None:
+            out = np.empty((nrhs, self.batch, self.nvars))
+        err = self.L.ndlqr_SolveBatchMultiRhs(self.h, nrhs, *[_ptr(a) for a in arrs], _ptr(out))
+        if err:
+            raise RuntimeError("ndlqr_SolveBatchMultiRhs failed: %d (%s)" % (err, self.L.ndlqr_hip_last_error().decode()))
+        return out
 
     def solve_async(self):
         return self.L.ndlqr_SolveBatchAsync(self.h)

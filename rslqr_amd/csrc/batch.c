@@ -260,6 +260,11 @@ int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs) {
   return ndlqr_hip_synchronize(bs->ctx);
 }
 
+int ndlqr_SolveBatchMultiRhs(NdLqrBatchSolver* bs, int nrhs, const double* q, const double* r, const double* d,
+                             const double* x0, double* soln) {
+  return bs ? ndlqr_hip_solve_multi_rhs(bs->ctx, nrhs, q, r, d, x0, soln) : NDLQR_ERR_INVALID;
+}
+
 int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs) {
   return bs ? ndlqr_hip_solve_async(bs->ctx) : NDLQR_ERR_INVALID;
 }

@@ -96,6 +96,9 @@ struct NdlqrHipCtx {
   const char* schedule;  // name of the launch sequence the last solve used (ndlqr_hip_schedule)
   int* h_fail;      // pinned host word: the batch-wide failure count, copied behind the last kernel of a solve
   double* kkt_out;  // [2 batch] scratch of ndlqr_hip_kkt_residual (allocated on first use)
+  // several right-hand sides per problem (ndlqr_hip_solve_multi_rhs): buffers for `multi_cap` right-hand sides, grown on demand
+  size_t multi_cap;
+  double *multi_rhs, *multi_z, *multi_zsep, *multi_fsum, *multi_ytop, *multi_in, *multi_out;
   double* sep_scratch;  // S-bar and panel of every level-0 separator in global memory: blocks beyond the LDS of separator_generic (allocated on first use)
   double* xfer;     // transfer staging of the current buffer set (see NdlqrAltSlot::xfer; allocated on first use)
   double* h_stage[2];  // pinned bounce buffers of the downloads into pageable host memory (allocated on first use)

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void b
 template <int NX>
 __device__ __forceinline__ void backsub_top_body(const Dims& d, const int b, const int t,
                                                  const double* __restrict__ recs, double* __restrict__ ytop,
-                                                 double* ytop_lds);
+                                                 double* ytop_lds, const int bp = -1, const double* zsep = nullptr);
 template <int NX, int NU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void reduced_top_mc(Dims d, const int l0, const double* __restrict__ AB,
                                                       const double* __restrict__ QR, const double* __restrict__ rhs,
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
   }
   // (the records of this launch were stored by wavefronts of this workgroup, acknowledged and behind a barrier; nobody
   //  on this CU has read those lines before: the plain loads of the sweep fetch them from L2)
-  if (ytop) backsub_top_body<NX>(d, b, threadIdx.x, rec, ytop, reinterpret_cast<double*>(&lds[0]));
+  if (ytop) backsub_top_body<NX>(d, b, threadIdx.x, rec, ytop, reinterpret_cast<double*>(&lds[0]), -1, nullptr);
 }
 
 //   grid (N / 4, batch), block 64; N >= 8; instances with matrix-core products only.

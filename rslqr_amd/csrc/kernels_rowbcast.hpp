@@ -474,19 +474,22 @@ __global__ __launch_bounds__(64, 2) void rb_bottom(Dims d, const double* __restr
 //   rb_backsub_top: grid (batch), block 256, dynamic LDS (N / 8) * NX doubles; N >= 16.
 // (device function: called by the kernel below and, since round 3, by reduced_top_mc right behind the last tree
 //  level -- the workgroup of a problem's last three levels goes straight on to that problem's top-down sweep)
+// (bp, zsep: multiple right-hand sides per problem, rb_forward_top<.., MULTI> -- the records are those of problem bp, the
+//  z_sep of this right-hand side live in zsep[b][N][NX])
 template <int NX>
 __device__ __forceinline__ void backsub_top_body(const Dims& d, const int b, const int t,
                                                  const double* __restrict__ recs, double* __restrict__ ytop,
-                                                 double* ytop_lds) {
+                                                 double* ytop_lds, const int bp, const double* zsep) {
   constexpr int NN = NX * NX, REC = 2 * NN + NX;
   const int N = d.N, K = d.K;
+  const int br = bp >= 0 ? bp : b;
   for (int L = K - 1; L >= 3; --L) {
     const int T = 2 << L, nsep = N >> (L + 1);
     for (int it = t; it < nsep * NX; it += 256) {
       const int q = it / NX, r = it - q * NX;
       const int base = q * T, s = base + (T >> 1) - 1;
-      const double* rc = recs + ((size_t)b * N + s) * REC;
-      double acc = rc[2 * NN + r];
+      const double* rc = recs + ((size_t)br * N + s) * REC;
+      double acc = zsep ? zsep[((size_t)b * N + s) * NX + r] : rc[2 * NN + r];
       if (base > 0) {
         double f[NX];
         load_row<NX>(rc + r * NX, f);
@@ -535,23 +538,27 @@ struct alignas(16) RbBacksubLds {
   double vs[4][NX];       // v of the four level-0 separators
 };
 
-template <int NX, int NU>
+// MULTI (several right-hand sides per problem, kernels below): grid.y counts right-hand sides, b % nprob is the problem whose
+// inputs and records are read, z_sep of the level-1 / 2 separators come from zsep[b][N][NX] instead of the records.
+template <int NX, int NU, bool MULTI = false>
 __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                                                   const double* __restrict__ rhs, const double* __restrict__ recs,
-                                                  const double* __restrict__ ytop, double* __restrict__ z) {
+                                                  const double* __restrict__ ytop, double* __restrict__ z,
+                                                  const int nprob = 0, const double* __restrict__ zsep = nullptr) {
   using Lds = RbBacksubLds<NX, NU>;
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP;
   constexpr int R0 = Lds::R0;
   static_assert(9 * NX <= 256 && KPB * ROWS <= 256, "thread roles fit the workgroup");
   __shared__ Lds lds;
   const int N = d.N, b = blockIdx.y, first = (blockIdx.x + d.xoff) * KPB;
+  const int bp = MULTI ? b % nprob : b;  // the problem whose inputs and records this right-hand side is solved against
   auto sep_slot = [&](int s) -> int { return s < first ? 7 : (s >= first + 7 ? 8 : s - first); };
   const int t = threadIdx.x;
 
   // ---- one round of loads
   {
-    const double* abm = AB + ((size_t)b * N + first) * NX * W;
-    const double* rc0 = recs + ((size_t)b * N + first) * REC;
+    const double* abm = AB + ((size_t)bp * N + first) * NX * W;
+    const double* rc0 = recs + ((size_t)bp * N + first) * REC;
     // 16-byte loads wherever the pieces are 16-byte granules: the eight knots' [A | B] always (8 NX W doubles from
     // a tile boundary), the records when NX is even (REC and R0 even)
     constexpr int NA = KPB * NX * W / 2, IA = (NA + 255) / 256;                // [A | B] in 16-byte words
@@ -592,8 +599,13 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
       if constexpr (WIDE) { const double2 v = *reinterpret_cast<const double2*>(src); t1[it][0] = v.x; t1[it][1] = v.y; }
       else t1[it][0] = *src;
     }
-    const double tq = QR[((size_t)b * N + first) * W + (t < NQ ? t : NQ - 1)];
+    const double tq = QR[((size_t)bp * N + first) * W + (t < NQ ? t : NQ - 1)];
     const double tr = rhs[((size_t)b * N + first) * ROWS + (t < NR ? t : NR - 1)];
+    double tz = 0.0;
+    if constexpr (MULTI) {  // z_sep of separators first + 1, + 3, + 5 of THIS right-hand side
+      const int e = t < 3 * NX ? t : 3 * NX - 1, j = e / NX;
+      tz = zsep[((size_t)b * N + first + 2 * j + 1) * NX + (e - j * NX)];
+    }
     double ty = 0.0;
     if (t < 2 * NX) {  // the two multipliers next to the workgroup's subtree
       const int sx = t < NX ? first - 1 : first + 7;
@@ -629,6 +641,10 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
     (&lds.qs[0][0])[t < NQ ? t : NQ - 1] = 1.0 / tq;
     (&lds.rs[0][0])[t < NR ? t : NR - 1] = tr;
     if (t < 2 * NX) lds.ys[t < NX ? 7 : 8][t < NX ? t : t - NX] = ty;
+    if constexpr (MULTI) {
+      __syncthreads();  // (the staged records carry the z_sep of whatever right-hand side was solved last)
+      if (t < 3 * NX) lds.rec1[t / NX][2 * NN + t % NX] = tz;
+    }
   }
   __syncthreads();
 
@@ -739,7 +755,7 @@ __global__ __launch_bounds__(256) void rb_backsub(Dims d, const double* __restri
   const double* yp = lds.ys[sep_slot(i > 0 ? i - 1 : 0)];            // y_{i-1} (unused for knot 0)
   if (needs_ab && !odd_state) dot = ab_dot(yi);
   if (lam) {
-    out = (i == 0) ? fma(-QR[(size_t)b * N * W + rr], rv, -lds.rs[0][NX + rr]) + dot : yp[rr];
+    out = (i == 0) ? fma(-QR[(size_t)bp * N * W + rr], rv, -lds.rs[0][NX + rr]) + dot : yp[rr];
   } else if (rr < 2 * NX) {
     out = (i == 0) ? -lds.rs[0][rr - NX] : (rv - dot + yp[rr - NX]) * lds.qs[kn][rr - NX];
   } else {
@@ -800,21 +816,23 @@ struct alignas(16) RbForwardLds {
   double outl[3][NX], outr[3][NX];  // contributions to first - 1 (from first, first + 1, first + 3) / first + 7 (first + 6, + 5, + 3)
 };
 
-template <int NX, int NU>
+template <int NX, int NU, bool MULTI = false>
 __global__ __launch_bounds__(256) void rb_forward(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                                                   const double* __restrict__ rhs, double* __restrict__ recs,
-                                                  double* __restrict__ fsum) {
+                                                  double* __restrict__ fsum, const int nprob = 0,
+                                                  double* __restrict__ zsep = nullptr) {
   using Lds = RbForwardLds<NX, NU>;
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, WP = Lds::WP, R0 = Lds::R0;
   static_assert(7 * NX <= 256 && KPB * ROWS <= 256 && KPB * W <= 256, "thread roles fit the workgroup");
   __shared__ Lds lds;
   const int N = d.N, b = blockIdx.y, first = blockIdx.x * KPB, t = threadIdx.x;
+  const int bp = MULTI ? b % nprob : b;  // (MULTI: see rb_backsub)
   // ---- staging: [A | B] of the eight knots, weights, right-hand sides, the seven separators' factors and records --
   //      every load is requested before the first store (16-byte words wherever the pieces are 16-byte granules, like
   //      rb_backsub's)
   {
-    const double* abm = AB + ((size_t)b * N + first) * NX * W;
-    const double* rc0 = recs + ((size_t)b * N + first) * REC;
+    const double* abm = AB + ((size_t)bp * N + first) * NX * W;
+    const double* rc0 = recs + ((size_t)bp * N + first) * REC;
     constexpr bool WIDE = NX % 2 == 0 && R0 % 2 == 0 && (NX * W) % 2 == 0;
     constexpr int G = WIDE ? 2 : 1;
     constexpr int NA = KPB * NX * W / G, IA = (NA + 255) / 256;
@@ -842,7 +860,7 @@ __global__ __launch_bounds__(256) void rb_forward(Dims d, const double* __restri
       const int e = t + 256 * it, ec = e < NF ? e : NF - 1, j = ec / (2 * NN / G), w_ = ec - j * (2 * NN / G);
       ld(rc0 + (size_t)(2 * j + 1) * REC + G * w_, tf[it]);
     }
-    const double tq = QR[((size_t)b * N + first) * W + (t < KPB * W ? t : KPB * W - 1)];
+    const double tq = QR[((size_t)bp * N + first) * W + (t < KPB * W ? t : KPB * W - 1)];
     const double tr = rhs[((size_t)b * N + first) * ROWS + (t < KPB * ROWS ? t : KPB * ROWS - 1)];
 #pragma unroll
     for (int it = 0; it < IA; ++it) {
@@ -922,6 +940,7 @@ __global__ __launch_bounds__(256) void rb_forward(Dims d, const double* __restri
       const double x = rb_llt_solve<NX>(lds.bt[sl][rc], lrow, lcol, dinv);
       if (r15 < NX && j < nrows) {
         if (packed) lds.zs[sl >> 1][r15] = x;
+        else if constexpr (MULTI) zsep[((size_t)b * N + first + sl) * NX + r15] = x;
         else recs[((size_t)b * N + first + sl) * REC + 2 * NN + r15] = x;  // z_sep of a separator of level 1 / 2
       }
     }
@@ -986,13 +1005,15 @@ __global__ __launch_bounds__(256) void rb_forward(Dims d, const double* __restri
 }
 
 // levels >= 3 of one problem + the top-down sweep. LDS: bt | gl | gr | ytop, each [N / 8][NX] (entry m: separator 8 m + 7).
-template <int NX, int NU>
+template <int NX, int NU, bool MULTI = false>
 __global__ __launch_bounds__(256) void rb_forward_top(Dims d, const double* __restrict__ AB, const double* __restrict__ QR,
                                                       const double* __restrict__ rhs, double* __restrict__ recs,
-                                                      const double* __restrict__ fsum, double* __restrict__ ytop) {
+                                                      const double* __restrict__ fsum, double* __restrict__ ytop,
+                                                      const int nprob = 0, double* __restrict__ zsep = nullptr) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX;
   extern __shared__ double sm[];
   const int N = d.N, K = d.K, b = blockIdx.x, t = threadIdx.x, M = N >> 3;
+  const int bp = MULTI ? b % nprob : b;  // (MULTI: see rb_backsub)
   double* bt = sm;
   double* gl = bt + M * NX;
   double* gr = gl + M * NX;
@@ -1000,8 +1021,8 @@ __global__ __launch_bounds__(256) void rb_forward_top(Dims d, const double* __re
   // ---- leafb of every separator 8 m + 7 minus what the blocks of rb_forward pushed to it (block m: gL, block m + 1: gR)
   for (int e = t; e < (M - 1) * NX; e += 256) {
     const int mq = e / NX, r = e - mq * NX, s = 8 * mq + 7;
-    const double* arow = AB + (((size_t)b * N + s) * NX + r) * W;
-    const double* qr = QR + ((size_t)b * N + s) * W;
+    const double* arow = AB + (((size_t)bp * N + s) * NX + r) * W;
+    const double* qr = QR + ((size_t)bp * N + s) * W;
     const double* r0 = rhs + ((size_t)b * N + s) * ROWS;
     double v = 0.0;
     for (int c = 0; c < W; ++c) v = fma(arow[c], r0[NX + c] / qr[c], v);  // (s >= 7: never the first knot)
@@ -1019,7 +1040,7 @@ __global__ __launch_bounds__(256) void rb_forward_top(Dims d, const double* __re
       const int j = t >> 4, r15 = t & 15, rc = r15 < NX ? r15 : NX - 1;
       const int qq = q0 + j < nsep ? q0 + j : nsep - 1;
       const int s = qq * T + (T >> 1) - 1, mq = s >> 3;
-      const double* Lf = rb_lrec<NX>((const double*)recs, d, b, s);
+      const double* Lf = rb_lrec<NX>((const double*)recs, d, bp, s);
       double lrow[NX], lcol[NX];
       const double dinv = 1.0 / Lf[rc * NX + rc];
 #pragma unroll
@@ -1031,7 +1052,8 @@ __global__ __launch_bounds__(256) void rb_forward_top(Dims d, const double* __re
       const double x = rb_llt_solve<NX>(bv, lrow, lcol, dinv);
       if (r15 < NX && q0 + j < nsep) {
         bt[mq * NX + r15] = bv;
-        recs[((size_t)b * N + s) * REC + 2 * NN + r15] = x;
+        if constexpr (MULTI) zsep[((size_t)b * N + s) * NX + r15] = x;
+        else recs[((size_t)b * N + s) * REC + 2 * NN + r15] = x;
       }
     }
     __syncthreads();
@@ -1041,7 +1063,7 @@ __global__ __launch_bounds__(256) void rb_forward_top(Dims d, const double* __re
       const int base = qq * T, s = base + (T >> 1) - 1;
       const int nb = side == 0 ? base - 1 : base + T - 1;
       if (nb < 0 || nb >= N - 1) continue;
-      const double* f = recs + ((size_t)b * N + s) * REC + side * NN;
+      const double* f = recs + ((size_t)bp * N + s) * REC + side * NN;
       const double* bs = bt + (s >> 3) * NX;
       double a = 0.0;
 #pragma unroll
@@ -1050,7 +1072,8 @@ __global__ __launch_bounds__(256) void rb_forward_top(Dims d, const double* __re
     }
     __syncthreads();
   }
-  backsub_top_body<NX>(d, b, t, recs, ytop, yt);
+  if constexpr (MULTI) backsub_top_body<NX>(d, b, t, recs, ytop, yt, bp, zsep);
+  else backsub_top_body<NX>(d, b, t, recs, ytop, yt);
 }
 
 

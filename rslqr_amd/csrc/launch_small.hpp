@@ -228,6 +228,32 @@ static void launch_rhs_records(NdlqrHipCtx* c) {
   }
 }
 
+// Several right-hand sides per problem against the compact records (SURVEY.md 8(f)-2 "multiple right-hand sides";
+// ndlqr_hip_solve_multi_rhs): `count` right-hand sides in all, right-hand side j belongs to problem j % batch; rhs / zsep /
+// fsum / ytop / z are arrays of `count` entries, the inputs and records those of the context. Returns false when the
+// shape has no such form.
+template <int NX, int NU>
+static bool launch_multi_rhs(NdlqrHipCtx* c, const int count, const double* rhs, double* zsep, double* fsum, double* ytop,
+                             double* z) {
+  if constexpr (ndlqr::P1OnMatrixCores<NX, NU>::value && 8 * (2 * NX + NU) <= 256) {
+    const ndlqr::Dims& d = c->d;
+    const size_t lds = sizeof(double) * 4 * (size_t)(d.N >> 3) * NX;
+    if (lds > 160 * 1024) return false;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ndlqr::rb_forward_top<NX, NU, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ndlqr::rb_forward<NX, NU, true>), dim3(d.N / 8, count), dim3(256), 0, c->stream, d, c->AB, c->QR, rhs,
+                       c->rec, fsum, d.batch, zsep);
+    hipLaunchKernelGGL((ndlqr::rb_forward_top<NX, NU, true>), dim3(count), dim3(256), lds, c->stream, d, c->AB, c->QR, rhs,
+                       c->rec, (const double*)fsum, ytop, d.batch, zsep);
+    hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU, true>), dim3(d.N / 8, count), dim3(256), 0, c->stream, d, c->AB, c->QR, rhs,
+                       (const double*)c->rec, (const double*)ytop, z, d.batch, (const double*)zsep);
+    return true;
+  } else {
+    return false;
+  }
+}
+
 // Time-axis sharding of the separator-only schedule: the horizon is cut into G
 // chunks of N / G knots, rank g works on chunk g. The tree levels 0 .. K - log2(G) - 1 lie inside a chunk; what a
 // chunk exposes to the rest of the tree is what any subtree exposes: the blocks it adds to the slots of the G - 1

@@ -124,6 +124,8 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   c->h_io = nullptr; c->graph_staged = nullptr; c->graph_staged_flags = 0;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;
   c->sep_scratch = nullptr;
+  c->multi_cap = 0;
+  c->multi_rhs = c->multi_z = c->multi_zsep = c->multi_fsum = c->multi_ytop = c->multi_in = c->multi_out = nullptr;
   memset(c->slot_ms, 0, sizeof(c->slot_ms));
   memset(c->slot_launches, 0, sizeof(c->slot_launches));
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -181,6 +183,8 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
   (void)hipFree(c->AB); (void)hipFree(c->QR); (void)hipFree(c->rhs); (void)hipFree(c->F);
   (void)hipFree(c->z); (void)hipFree(c->rec); (void)hipFree(c->red); (void)hipFree(c->tree_cnt); (void)hipFree(c->info);
   (void)hipFree(c->sep_scratch);
+  (void)hipFree(c->multi_rhs); (void)hipFree(c->multi_z); (void)hipFree(c->multi_zsep); (void)hipFree(c->multi_fsum);
+  (void)hipFree(c->multi_ytop); (void)hipFree(c->multi_in); (void)hipFree(c->multi_out);
   (void)hipFree(c->kkt_out); (void)hipFree(c->ytop); (void)hipFree(c->xfer); (void)hipFree(c->pad_stage);
   for (double* h : c->h_stage) if (h) (void)hipHostFree(h);
   if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
@@ -745,7 +749,8 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c);                               \
   int ndlqr_small_kpb_##NX_##_##NU_(void);                                          \
   int ndlqr_small_tshard_##NX_##_##NU_(NdlqrHipCtx* c, int phase, int g, int G);      \
-  int ndlqr_small_slot_##NX_##_##NU_(void);
+  int ndlqr_small_slot_##NX_##_##NU_(void);                                          \
+  int ndlqr_small_multi_##NX_##_##NU_(NdlqrHipCtx* c, int count, const double* rhs, double* zsep, double* fsum, double* ytop, double* z);
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 
@@ -757,6 +762,7 @@ struct SmallInstance {
   int (*kpb)(void);
   int (*tshard)(NdlqrHipCtx*, int, int, int);
   int (*slot)(void);
+  int (*multi)(NdlqrHipCtx*, int, const double*, double*, double*, double*, double*);
 };
 #ifdef NDLQR_SINGLE_TU
 #define NDLQR_SMALL_INSTANCE(NX_, NU_)                                                              \
@@ -771,7 +777,8 @@ struct SmallInstance {
   void ndlqr_small_rhs_##NX_##_##NU_(NdlqrHipCtx* c) { launch_rhs_records<NX_, NU_>(c); }           \
   int ndlqr_small_kpb_##NX_##_##NU_(void) { return ndlqr::SchurShape<NX_, NU_>::KPB; }              \
   int ndlqr_small_tshard_##NX_##_##NU_(NdlqrHipCtx* c, int phase, int g, int G) { return launch_time_shard<NX_, NU_>(c, phase, g, G); } \
-  int ndlqr_small_slot_##NX_##_##NU_(void) { return (int)ndlqr::RedSlot<NX_>::SIZE; }
+  int ndlqr_small_slot_##NX_##_##NU_(void) { return (int)ndlqr::RedSlot<NX_>::SIZE; }              \
+  int ndlqr_small_multi_##NX_##_##NU_(NdlqrHipCtx* c, int count, const double* rhs, double* zsep, double* fsum, double* ytop, double* z) { return launch_multi_rhs<NX_, NU_>(c, count, rhs, zsep, fsum, ytop, z) ? 1 : 0; }
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 #endif
@@ -779,7 +786,8 @@ struct SmallInstance {
 static const SmallInstance kSmallInstances[] = {
 #define NDLQR_SMALL_INSTANCE(NX_, NU_) \
   {NX_, NU_, ndlqr_small_solve_##NX_##_##NU_, ndlqr_small_needs_F_##NX_##_##NU_, ndlqr_small_rhs_##NX_##_##NU_, \
-   ndlqr_small_kpb_##NX_##_##NU_, ndlqr_small_tshard_##NX_##_##NU_, ndlqr_small_slot_##NX_##_##NU_},
+   ndlqr_small_kpb_##NX_##_##NU_, ndlqr_small_tshard_##NX_##_##NU_, ndlqr_small_slot_##NX_##_##NU_,            \
+   ndlqr_small_multi_##NX_##_##NU_},
 #include "small_instances.def"
 #undef NDLQR_SMALL_INSTANCE
 };
@@ -1413,6 +1421,97 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
   c->timing_pending = true;
   c->z_latest = c->z;
   c->stream_latest = c->stream;
+  return NDLQR_OK;
+}
+
+// Several right-hand sides per problem against ONE kept factorisation each (SURVEY.md 8(f)-2 "multiple right-hand
+// sides"; the reference's NdData holds a single one, src/nddata.h:70-75): nrhs x batch right-hand sides, flat host arrays
+// q, d [nrhs][batch][N][n], r [nrhs][batch][N][m], x0 [nrhs][batch][n] in the layout of ndlqr_BatchSetRhsFlat, solutions
+// [nrhs][batch][nvars] into `soln`. Needs the compact records of a solve with NDLQR_FLAG_KEEP_RECORDS on the
+// level-per-launch schedule (rec_compact). The right-hand sides are solved in chunks of at most 65 535 / batch sets;
+// right-hand side j of a chunk reads the inputs and records of problem j % batch (they stay in the caches when batch is
+// small: one problem x 1024 right-hand sides moves the right-hand sides and solutions and little else), its z_sep go to
+// an array of their own. Blocking; the device time of the kernels alone is what ndlqr_hip_last_solve_ms reports afterwards.
+int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* c, int nrhs, const double* q, const double* r, const double* dd,
+                              const double* x0, double* soln) {
+  if (!c || nrhs <= 0 || !q || !r || !dd || !x0 || !soln) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(sync_all(c));
+  if (c->in_alt) swap_slot(c);
+  const SmallInstance* inst = pick_small(c);
+  if (!inst || !c->rec_complete || !c->rec_compact) {
+    g_last_error = "multiple right-hand sides need the compact records of a solve with NDLQR_FLAG_KEEP_RECORDS on a "
+                   "size-specialised shape (level-per-launch schedule: batch x N / 4 > 2048, or NDLQR_TREE=0)";
+    fprintf(stderr, "ndlqr_hip: %s\n", g_last_error.c_str());
+    return NDLQR_ERR_INVALID;
+  }
+  const ndlqr::Dims& d = c->d;
+  const ndlqr::Dims& u = c->du;
+  const size_t nvars = (size_t)u.rows * u.N - u.m;
+  // sets of right-hand sides per chunk: the chunk's count rides on gridDim.y, and its buffers stay within ~2 GB
+  size_t per_set = (size_t)d.batch;
+  size_t sets = 65535 / per_set;
+  const size_t bytes_per = sizeof(double) * (size_t)d.N * (2 * d.rows + d.n + 2 * u.rows);
+  while (sets > 1 && sets * per_set * bytes_per > ((size_t)2 << 30)) sets >>= 1;
+  if (sets > (size_t)nrhs) sets = (size_t)nrhs;
+  if (sets == 0) return NDLQR_ERR_INVALID;
+  const size_t cap = sets * per_set;
+  if (c->multi_cap < cap) {
+    (void)hipFree(c->multi_rhs); (void)hipFree(c->multi_z); (void)hipFree(c->multi_zsep); (void)hipFree(c->multi_fsum);
+    (void)hipFree(c->multi_ytop); (void)hipFree(c->multi_in); (void)hipFree(c->multi_out);
+    c->multi_rhs = c->multi_z = c->multi_zsep = c->multi_fsum = c->multi_ytop = c->multi_in = c->multi_out = nullptr;
+    c->multi_cap = 0;
+    const size_t nz = cap * d.N * d.rows;
+    const size_t nin = cap * ((size_t)u.N * (2 * u.n + u.m) + u.n);
+    bool ok = hipMalloc(&c->multi_rhs, sizeof(double) * nz) == hipSuccess &&
+              hipMalloc(&c->multi_z, sizeof(double) * nz) == hipSuccess &&
+              hipMalloc(&c->multi_zsep, sizeof(double) * cap * d.N * d.n) == hipSuccess &&
+              hipMalloc(&c->multi_fsum, sizeof(double) * cap * (d.N / 8) * 2 * d.n) == hipSuccess &&
+              hipMalloc(&c->multi_ytop, sizeof(double) * cap * (d.N / 8) * d.n) == hipSuccess &&
+              hipMalloc(&c->multi_in, sizeof(double) * nin) == hipSuccess &&
+              hipMalloc(&c->multi_out, sizeof(double) * cap * nvars) == hipSuccess;
+    // (padded shapes: the pad entries of the right-hand side are zero and stay zero -- the pack kernel never touches them)
+    ok = ok && hipMemsetAsync(c->multi_rhs, 0, sizeof(double) * nz, c->stream) == hipSuccess &&
+         hipMemsetAsync(c->multi_z, 0, sizeof(double) * nz, c->stream) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      g_last_error = "buffers of the multiple right-hand sides do not fit on the device";
+      return NDLQR_ERR_INVALID;
+    }
+    c->multi_cap = cap;
+  }
+  double total_ms = 0.0;
+  for (size_t s0 = 0; s0 < (size_t)nrhs; s0 += sets) {
+    const size_t ns = (size_t)nrhs - s0 < sets ? (size_t)nrhs - s0 : sets, count = ns * per_set;
+    ndlqr::Dims uc = u, dc = d;
+    uc.batch = dc.batch = (int)count;  // (the pack kernels index problems by their position alone)
+    const size_t nq = count * u.N * u.n, nr = count * u.N * u.m, nx = count * u.n;
+    double* in = c->multi_in;
+    HIP_TRY(hipMemcpyAsync(in, q + s0 * per_set * u.N * u.n, sizeof(double) * nq, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(in + nq, r + s0 * per_set * u.N * u.m, sizeof(double) * nr, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(in + nq + nr, dd + s0 * per_set * u.N * u.n, sizeof(double) * nq, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(in + 2 * nq + nr, x0 + s0 * per_set * u.n, sizeof(double) * nx, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ndlqr::pack_rhs_stream_generic, dim3(512), dim3(256), 0, c->stream, uc, dc, (const double*)in,
+                       (const double*)(in + nq), (const double*)(in + nq + nr), (const double*)(in + 2 * nq + nr), c->multi_rhs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    if (!inst->multi(c, (int)count, c->multi_rhs, c->multi_zsep, c->multi_fsum, c->multi_ytop, c->multi_z)) {
+      g_last_error = "multiple right-hand sides: this shape / horizon has no such form";
+      return NDLQR_ERR_INVALID;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, (unsigned)count), dim3(64), 0, c->stream, uc, dc,
+                       (const double*)c->multi_z, c->multi_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(soln + s0 * per_set * nvars, c->multi_out, sizeof(double) * count * nvars, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) total_ms += ms;
+  }
+  c->last_ms = total_ms;
+  c->timing_pending = false;
   return NDLQR_OK;
 }
 

@@ -7,6 +7,7 @@
 //   ndlqr_small_kpb_<nx>_<nu>()                         knots per workgroup of its Schur kernels
 //   ndlqr_small_tshard_<nx>_<nu>(ctx, phase, g, G)      time-axis sharding: chunk g of G, phase 0 / 1 (launch_time_shard)
 //   ndlqr_small_slot_<nx>_<nu>()                        doubles per accumulator slot
+//   ndlqr_small_multi_<nx>_<nu>(ctx, count, rhs, zsep, fsum, ytop, z)   several right-hand sides per problem (launch_multi_rhs)
 #include "launch_small.hpp"
 
 #if !defined(NDLQR_INST_NX) || !defined(NDLQR_INST_NU)
@@ -40,3 +41,8 @@ int NDLQR_INST_NAME(ndlqr_small_tshard_)(NdlqrHipCtx* c, int phase, int g, int G
 }
 
 int NDLQR_INST_NAME(ndlqr_small_slot_)(void) { return (int)ndlqr::RedSlot<NX>::SIZE; }
+
+int NDLQR_INST_NAME(ndlqr_small_multi_)(NdlqrHipCtx* c, int count, const double* rhs, double* zsep, double* fsum,
+                                        double* ytop, double* z) {
+  return launch_multi_rhs<NX, NU>(c, count, rhs, zsep, fsum, ytop, z) ? 1 : 0;
+}

@@ -462,6 +462,50 @@ def test_resolve_on_compact_records(ndlqr, oracle, n, m, N, batch, a_scale, q_sc
     bs.close()
 
 
+@pytest.mark.parametrize("n,m,N,batch,nrhs", [(12, 4, 256, 1, 40), (12, 4, 64, 3, 7), (6, 3, 32, 2, 5), (13, 4, 128, 1, 9),
+                                              (11, 3, 64, 2, 4), (10, 4, 16, 5, 3), (12, 4, 16, 300, 300)])
+def test_multiple_right_hand_sides(ndlqr, oracle, n, m, N, batch, nrhs, monkeypatch):
+    """ndlqr_SolveBatchMultiRhs (SURVEY 8f-2 "multiple right-hand sides"): nrhs sets of q, r, d, x0 per problem against the
+    ONE factorisation a KEEP_RECORDS solve left, every solution against the oracle's full solve of that problem with that
+    right-hand side; the plain re-solve and a full solve afterwards still work (the z_sep of the many right-hand sides
+    never touch the records). More sets than fit one launch (65 535 right-hand sides) go in chunks."""
+    monkeypatch.setenv("NDLQR_TREE", "0")
+    probs = [synth(ndlqr, n, m, N, 5100 + p) for p in range(batch)]
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=ndlqr.FLAG_KEEP_RECORDS)
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0 and bs.schedule() == "reduced-compact-records"
+    first = bs.solutions().copy()
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((nrhs, batch, N, n))
+    r = rng.standard_normal((nrhs, batch, N, m))
+    d = 0.1 * rng.standard_normal((nrhs, batch, N, n))
+    x0 = rng.standard_normal((nrhs, batch, n))
+    sol = bs.solve_multi_rhs(q, r, d, x0)
+    assert sol.shape == (nrhs, batch, bs.nvars)
+    checks = [(0, 0), (nrhs - 1, batch - 1), (nrhs // 2, batch // 2)] if nrhs * batch > 60 else \
+        [(j, p) for j in range(nrhs) for p in range(batch)]
+    for j, p in checks:
+        a = probs[p]
+        prob = Problem(n, m, N, a.A, a.B, a.Q, a.R, q[j, p], r[j, p], d[j, p], x0[j, p])
+        ref = oracle.solve(prob, 4)[0][: prob.nvars]
+        rel = np.linalg.norm(sol[j, p] - ref) / np.linalg.norm(ref)
+        assert rel <= REL_TOL, (j, p, rel)
+    # the resident problem is untouched: its own re-solve and a full solve reproduce the first solution
+    assert bs.solve_rhs_only() == 0
+    again = bs.solutions()
+    assert np.linalg.norm(again - first) / np.linalg.norm(first) <= 1e-12
+    assert bs.solve() == 0
+    assert np.array_equal(bs.solutions(), first)
+    bs.close()
+    # without the kept records the call is refused
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    bs.initialize_flat(*stack(probs))
+    assert bs.solve() == 0
+    with pytest.raises(RuntimeError):
+        bs.solve_multi_rhs(q[:1], r[:1], d[:1], x0[:1])
+    bs.close()
+
+
 @pytest.mark.parametrize("n,m,N,batch,want", HARD_SHAPES)
 @pytest.mark.parametrize("a_scale,q_scale,r_scale", HARD_FAMILIES)
 def test_harder_families_large_and_padded_paths(ndlqr, oracle, n, m, N, batch, want, a_scale, q_scale, r_scale):
