@@ -276,6 +276,38 @@ def test_blocks_beyond_the_lds(ndlqr, oracle, n, m, N, batch):
         bs.close()
 
 
+@pytest.mark.parametrize("n,m,N", [(130, 5, 8), (144, 16, 4), (40, 7, 16), (7, 9, 16)])
+def test_dropin_solve_any_block_size(ndlqr, oracle, n, m, N):
+    """The reference's call sequence (ndlqr_NewLQRProblem / InitializeLQRData / InitializeWithLQRProblem / ndlqr_Solve /
+    ndlqr_CopySolution, src/solve.h:20-32) at block sizes that run zero-padded on the device (beyond 128 states; a
+    small bucket shape) or on the runtime-sized schedule: the staged one-graph solve against the oracle, twice."""
+    L = ndlqr.lib()
+    g = ndlqr.generate_synthetic(n, m, N, 77)
+    pyprob = Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+    ref = oracle.solve(pyprob, 4)[0][: pyprob.nvars]
+    prob = L.ndlqr_NewLQRProblem(n, m, N)
+    assert prob
+    dptr = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    keep = []
+    for k in range(N):
+        arrs = [np.ascontiguousarray(g[f][k], dtype=np.float64) for f in ("Q", "R", "q", "r")]
+        A = np.ascontiguousarray(g["A"][k]); B = np.ascontiguousarray(g["B"][k]); d = np.ascontiguousarray(g["d"][k])
+        keep += arrs + [A, B, d]
+        assert L.ndlqr_InitializeLQRData(prob.contents.lqrdata[k], dptr(arrs[0]), dptr(arrs[1]), dptr(arrs[2]), dptr(arrs[3]),
+                                         0.0, dptr(A), dptr(B), dptr(d)) == 0
+    x0 = np.ascontiguousarray(g["x0"], dtype=np.float64)
+    assert L.ndlqr_InitializeLQRProblem(prob, dptr(x0), prob.contents.lqrdata) == 0
+    solver = L.ndlqr_NewNdLqrSolver(n, m, N)
+    for rep in range(2):
+        assert L.ndlqr_InitializeWithLQRProblem(prob, solver) == 0
+        assert L.ndlqr_Solve(solver) == 0
+        x = np.zeros(pyprob.nvars)
+        assert L.ndlqr_CopySolution(solver, x.ctypes.data_as(C.POINTER(C.c_double))) == pyprob.nvars
+        assert np.linalg.norm(x - ref) / np.linalg.norm(ref) <= REL_TOL, rep
+    L.ndlqr_FreeNdLqrSolver(solver)
+    L.ndlqr_FreeLQRProblem(prob)
+
+
 def test_generic_flag_switch_on_specialised_shape(ndlqr, oracle):
     """A context of a size-specialised shape comes with the (smaller) accumulator array of ITS separator-only
     schedule; NDLQR_FLAG_GENERIC sends it through the runtime-sized schedule, which needs its own, larger one:
