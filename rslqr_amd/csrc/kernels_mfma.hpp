@@ -455,4 +455,100 @@ __global__ __launch_bounds__(256) void schur_mfma(Dims d, int l, double* F, doub
   }
 }
 
+// The same update for blocks beyond 64 states (round 4: the knot-based path serves every block size, DESIGN.md section 3
+// "any block size"), runtime-sized: n a multiple of 16, any number of rows (the last row tile is clamped / masked). No LDS:
+// a wavefront takes a 16-row tile of the knot through column tiles four at a time, the operand fragments of E and of f
+// straight from global memory (f is shared by the boundary knots of a subtree and stays in L2), eight k-steps per round of
+// loads. Semantics of schur_mfma / schur_generic (lambda rows, created blocks, rhs entry) unchanged.
+//   grid (N, batch) -- or (2 * (N >> (l+1)), batch) in boundary mode --, block 256.
+static __global__ __launch_bounds__(256) void schur_mfma_rt(Dims d, int l, double* F, double* z, int boundary,
+                                                            const double* recs = nullptr) {
+  const int N = d.N, rows = d.rows, n = d.n, b = blockIdx.y;
+  const int i = boundary ? (blockIdx.x >> 1) * (2 << l) + ((blockIdx.x & 1) ? (2 << l) - 1 : 0) : blockIdx.x;
+  const int half = 1 << l;
+  const int base = (i >> (l + 1)) << (l + 1), s = base + half - 1;
+  int a, bb;
+  outer_columns(base, l, N, a, bb);
+  const bool left = i <= s;
+  const bool calc_lambda = (i == 0) || (i & (half - 1)) != 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const double* E = Fblk(F, d, b, l, i);
+  const int RT = (rows + 15) / 16, CTN = n / 16, KS = n / 4;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int col = pass == 0 ? a : bb;
+    if (col < 0) continue;  // uniform
+    const bool created = pass == 0 ? !left : left;
+    const double* f = recs ? recs + ((size_t)b * N + s) * (2 * (size_t)n * n + n) + (pass == 0 ? 0 : (size_t)n * n)
+                           : Fblk(F, d, b, col, s + 1);
+    double* g = Fblk(F, d, b, col, i);
+    for (int t = wave; t < RT; t += 4) {
+      const bool lamtile = 16 * t < n;  // n % 16 == 0: a tile is entirely lambda rows or not
+      if (lamtile && recs) continue;
+      if (lamtile && !calc_lambda) {
+        if (created && i != s + 1) {  // explicit zeros, like schur_generic
+          for (int e = lane; e < 16 * n; e += 64) g[(size_t)(16 * t) * n + e] = 0.0;
+        }
+        continue;
+      }
+      const int ra = 16 * t + li < rows ? 16 * t + li : rows - 1;  // (A operand row of this lane, clamped)
+      const double* Erow = E + (size_t)ra * n + lk;
+      for (int c0 = 0; c0 < CTN; c0 += 4) {
+        mfma_acc_t acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ct = c0 + j < CTN ? c0 + j : CTN - 1;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int r = 16 * t + lk + 4 * gq;
+            acc[j][gq] = (created || r >= rows) ? 0.0 : g[(size_t)r * n + 16 * ct + li];
+          }
+        }
+        for (int q0 = 0; q0 < KS; q0 += 8) {
+          double af[8], bf[4][8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u < KS ? q0 + u : KS - 1;
+            af[u] = q0 + u < KS ? -Erow[4 * q] : 0.0;  // g -= E f
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ct = c0 + j < CTN ? c0 + j : CTN - 1;
+              bf[j][u] = f[(size_t)(4 * q + lk) * n + 16 * ct + li];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[j][u], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (c0 + j >= CTN) continue;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int r = 16 * t + lk + 4 * gq;
+            if (r < rows) g[(size_t)r * n + 16 * (c0 + j) + li] = acc[j][gq];
+          }
+        }
+      }
+    }
+  }
+  // rhs entry per row: z(i)[r] -= E(r,:) . z_sep
+  const double* zsep = z + ((size_t)b * N + s + 1) * rows;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    if (r < n && (recs || !calc_lambda)) continue;
+    double* zp = z + ((size_t)b * N + i) * rows + r;
+    const double* Erow = E + (size_t)r * n;
+    double acc = *zp;
+    for (int k0 = 0; k0 < n; k0 += 16) {  // sixteen operand pairs per load round, same order of summation
+      double ev[16], zv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { ev[u] = Erow[k0 + u]; zv[u] = zsep[k0 + u]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fma(-ev[u], zv[u], acc);
+    }
+    *zp = acc;
+  }
+}
+
 }  // namespace ndlqr

@@ -721,6 +721,9 @@ static int launch_generic(NdlqrHipCtx* c, bool lean) {
       else if (mfma && d.n == 16)
         hipLaunchKernelGGL((ndlqr::schur_mfma<1>), dim3(gx, d.batch), dim3(256), flds, c->stream, d, l, c->F, c->z, bnd,
                            (const double*)rec);
+      else if (!STRICT && d.n % 16 == 0 && d.n > 64 && !c->no_mfma)  // (runtime-sized matrix-core form: blocks beyond 64 states)
+        hipLaunchKernelGGL(ndlqr::schur_mfma_rt, dim3(gx, d.batch), dim3(256), 0, c->stream, d, l, c->F, c->z, bnd,
+                           (const double*)rec);
       else {
         const long work = (long)gx * d.rows * d.n;
         hipLaunchKernelGGL((ndlqr::schur_generic<STRICT>), dim3((unsigned)((work + 255) / 256), d.batch),
