@@ -488,6 +488,7 @@ static ReducedGenericPlan plan_reduced_generic(const NdlqrHipCtx* c) {
   ReducedGenericPlan p = {false, 0, 0, 0, false, false};
   if (c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT)) return p;
   if (c->no_mfma || d.n > 128 || d.N < 2) return p;
+  if (getenv("NDLQR_DEV_NO_REDUCED_GENERIC")) return p;  // (developer: A/B against the knot-based runtime-sized schedule)
   p.keep = (c->flags & NDLQR_FLAG_KEEP_RECORDS) != 0;  // W of every separator kept for rhs-only re-solves
   p.nb = (d.n + 15) / 16;
   const int npad = 16 * p.nb, wpad = (d.w + 3) / 4 * 4;

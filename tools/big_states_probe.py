@@ -16,10 +16,16 @@ for (n, m, N, batch) in [(128, 16, 64, 8), (144, 16, 64, 8), (150, 10, 64, 8), (
             bs = R.BatchSolver(n, m, N, batch, flags=flags)
             bs.initialize_synthetic(3)
             rc = bs.solve()
-            t0 = time.perf_counter()
-            bs.solve_async()
+            for _ in range(2):  # (both buffer sets of the pipeline and their captured sequences exist before the clock starts)
+                bs.solve_async()
             bs.synchronize()
-            ms = (time.perf_counter() - t0) * 1e3
+            ms = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    bs.solve_async()
+                bs.synchronize()
+                ms = min(ms, (time.perf_counter() - t0) / 2 * 1e3)
             res, bn = bs.kkt_residuals()
             print((n, m, N, batch), "flags", flags, bs.schedule(), "rc", rc, "%.2f ms per step, %.1f solves/s" % (ms, batch / ms * 1e3),
                   "kkt %.1e" % (res / np.maximum(1, bn)).max(), flush=True)
