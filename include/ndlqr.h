@@ -349,7 +349,8 @@ typedef struct NdLqrBatchSolver NdLqrBatchSolver;
                                      records + Cholesky factors, ~3.5 KB per knot at (12,4)) without
                                      materialising the factor array: ndlqr_SolveBatchRhsOnly works,
                                      ndlqr_CopyBatchFactors does not. Size-specialised shapes and every
-                                     other one up to 128 states. */
+                                     other one up to 128 states; beyond (the knot-based kernels) the factor
+                                     array is kept instead, as with NDLQR_FLAG_KEEP_FACT. */
 /* Reach of the modes by block size (runtime-sized kernels; the size-specialised instances of
  * rslqr_amd/csrc/small_instances.def support every mode): EVERY mode works for every block size the device memory holds
  * (round 4; tested up to (256,32)). What changes with the size is the speed: the default fast mode and

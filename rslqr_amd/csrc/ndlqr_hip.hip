@@ -845,6 +845,13 @@ static bool solve_needs_F(const NdlqrHipCtx* c) {
   return inst->needs_F(c, (c->flags & NDLQR_FLAG_STRICT_FP) != 0, (c->flags & NDLQR_FLAG_KEEP_FACT) != 0) != 0;
 }
 
+// NDLQR_FLAG_KEEP_RECORDS where no schedule keeps records -- the knot-based runtime-sized path: blocks beyond 128 states,
+// inputs wider than a workgroup -- keeps the factor array instead: the right-hand-side re-solve is the factor-based sweep
+static bool records_kept_as_factors(const NdlqrHipCtx* c) {
+  return (c->flags & NDLQR_FLAG_KEEP_RECORDS) && !(c->flags & NDLQR_FLAG_STRICT_FP) && !pick_small(c) &&
+         !plan_reduced_generic(c).ok;
+}
+
 // Enqueue leaf/bottom + per-level + apply launches on the context's stream.
 static int enqueue_solve(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
@@ -857,7 +864,7 @@ static int enqueue_solve(NdlqrHipCtx* c) {
   done = try_launch_small(c, strict, &err);
   if (!done) {
     const ReducedGenericPlan rp = plan_reduced_generic(c);
-    const bool lean = !strict && !(c->flags & NDLQR_FLAG_KEEP_FACT);
+    const bool lean = !strict && !(c->flags & NDLQR_FLAG_KEEP_FACT) && !records_kept_as_factors(c);
     if (rp.ok) err = launch_reduced_generic(c, rp);
     else err = strict ? launch_generic<true>(c, false) : launch_generic<false>(c, lean);
   }
@@ -962,7 +969,7 @@ static int launch_solve(NdlqrHipCtx* c) {
   c->z_latest = c->z;
   c->stream_latest = c->stream;
   // a complete factor array is on the device with KEEP, and on the strict runtime-sized path
-  c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 ||
+  c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 || records_kept_as_factors(c) ||
                   ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
   return NDLQR_OK;
 }
@@ -1087,7 +1094,7 @@ int ndlqr_hip_solve_staged(NdlqrHipCtx* c) {
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->z_latest = c->z;
   c->stream_latest = c->stream;
-  c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 ||
+  c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 || records_kept_as_factors(c) ||
                   ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
   c->timing_pending = true;
   c->state_dirty = false;

@@ -229,12 +229,15 @@ def test_blocks_beyond_the_lds(ndlqr, oracle, n, m, N, batch):
     states), a non-positive weight reported. (Round 3: a solve beyond 128 states returned NDLQR_ERR_INVALID.)"""
     probs = [synth(ndlqr, n, m, N, 4100 + p) for p in range(batch)]
     full = [oracle.solve(prob, 8, want_fact=True) for prob in probs]
-    for flags in (ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT, ndlqr.FLAG_KEEP_FACT, 0):
+    # (NDLQR_FLAG_KEEP_RECORDS beyond 128 states: no schedule keeps records there, the factor array is kept instead)
+    for flags in (ndlqr.FLAG_STRICT_FP | ndlqr.FLAG_KEEP_FACT, ndlqr.FLAG_KEEP_FACT, ndlqr.FLAG_KEEP_RECORDS, 0):
         bs = ndlqr.BatchSolver(n, m, N, batch, flags=flags)
         bs.initialize_flat(*stack(probs))
         assert bs.solve() == 0
         if flags == 0:
             assert bs.schedule() == ("generic-lean" if n > 128 else "generic-reduced")
+        if flags == ndlqr.FLAG_KEEP_RECORDS:
+            assert bs.schedule() == ("generic-keep" if n > 128 else "generic-reduced-records")
         sol = bs.solutions()
         for p, prob in enumerate(probs):
             z, fact = full[p][0], full[p][1]
@@ -252,7 +255,7 @@ def test_blocks_beyond_the_lds(ndlqr, oracle, n, m, N, batch):
                 if (flags & ndlqr.FLAG_KEEP_FACT) and not (n > 128 or (n % 16 == 0 and (n + m) % 4 == 0)):
                     got = bs.factors(p)
                     assert np.linalg.norm(got - fact) / np.linalg.norm(fact) <= REL_TOL
-        if flags & ndlqr.FLAG_KEEP_FACT:  # new right-hand side against the kept factor array
+        if flags & (ndlqr.FLAG_KEEP_FACT | ndlqr.FLAG_KEEP_RECORDS):  # new right-hand side against what was kept
             other = [synth(ndlqr, n, m, N, 4200 + p) for p in range(batch)]
             mixed = [Problem(n, m, N, a.A, a.B, a.Q, a.R, o.q, o.r, o.d, o.x0) for a, o in zip(probs, other)]
             bs.set_rhs_flat(*[np.stack([getattr(q, f) for q in mixed]) for f in ("q", "r", "d", "x0")])
@@ -403,11 +406,18 @@ def test_resolve_with_records_only(ndlqr, oracle, n, m, N):
     with pytest.raises(RuntimeError):  # no factor array in this mode
         bs.factors(0)
     bs.close()
-    # on the knot-based runtime-sized kernels (inputs wider than a workgroup) a re-solve needs the factor array: NDLQR_FLAG_KEEP_FACT
+    # on the knot-based runtime-sized kernels (inputs wider than a workgroup, blocks beyond 128 states) no schedule keeps
+    # records: the flag keeps the factor array there, and the re-solve is the factor-based sweep
+    g = ndlqr.generate_synthetic(16, 300, 4, 5)
+    o = ndlqr.generate_synthetic(16, 300, 4, 6)
     bs = ndlqr.BatchSolver(16, 300, 4, 1, flags=ndlqr.FLAG_KEEP_RECORDS)
-    bs.initialize_synthetic(5)
-    assert bs.solve() == 0
-    assert bs.solve_rhs_only() == -1
+    bs.initialize_flat(*[g[k][None] for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")])
+    assert bs.solve() == 0 and bs.schedule() == "generic-keep"
+    bs.set_rhs_flat(*[o[k][None] for k in ("q", "r", "d", "x0")])
+    assert bs.solve_rhs_only() == 0
+    prob = Problem(16, 300, 4, g["A"], g["B"], g["Q"], g["R"], o["q"], o["r"], o["d"], o["x0"])
+    ref = oracle.solve(prob, 1)[0][: prob.nvars]
+    assert np.linalg.norm(bs.solution(0) - ref) / np.linalg.norm(ref) <= REL_TOL
     bs.close()
 
 
