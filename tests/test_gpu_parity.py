@@ -311,6 +311,18 @@ def test_dropin_solve_any_block_size(ndlqr, oracle, n, m, N):
     L.ndlqr_FreeLQRProblem(prob)
 
 
+def test_fuzz_parity_short():
+    """Twenty seconds of tools/fuzz_parity.py (random shapes, batches, flags, schedules and call sequences against the
+    oracle; a fresh process: it switches NDLQR_TREE between cases) with a fixed seed: no mismatch, no exception."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20", "11"], capture_output=True,
+                         text=True, timeout=600)
+    tail = out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.returncode == 0 and "0 failures" in out.stdout, tail
+
+
 def test_generic_flag_switch_on_specialised_shape(ndlqr, oracle):
     """A context of a size-specialised shape comes with the (smaller) accumulator array of ITS separator-only
     schedule; NDLQR_FLAG_GENERIC sends it through the runtime-sized schedule, which needs its own, larger one:
