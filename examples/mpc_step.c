@@ -6,7 +6,10 @@
  * (src/solve.h:20-32), for `batch` independent problems at once.
  *
  *   gcc -Iinclude examples/mpc_step.c -Lrslqr_amd -lrslqr_amd -Wl,-rpath,$PWD/rslqr_amd -lm -o mpc_step
- *   ./mpc_step [nstates ninputs nhorizon batch steps]
+ *   ./mpc_step [nstates ninputs nhorizon batch steps [keep]]
+ *
+ * keep = 1: NDLQR_FLAG_KEEP_RECORDS -- a step never changes A, B, Q, R, so only the first one factors and every further
+ * step is the right-hand-side re-solve on the kept records (0.51 instead of 0.68 ms per step of 1024 x (12,4,256)).
  *
  * Each step starts every problem from x_1 = A_0 x_0 + B_0 u_0 + d_0 of the step before the previous one (the loop runs
  * one step behind the solver: the freshest u_0 it may read is that of step it - 1 while step it is in flight).
@@ -29,9 +32,11 @@ int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 12, m = argc > 2 ? atoi(argv[2]) : 4;
   const int N = argc > 3 ? atoi(argv[3]) : 64, batch = argc > 4 ? atoi(argv[4]) : 256;
   const int steps = argc > 5 ? atoi(argv[5]) : 20;
+  const int keep = argc > 6 ? atoi(argv[6]) : 0;
 
   NdLqrBatchSolver* bs = ndlqr_NewBatchSolver(n, m, N, batch, -1);
   if (!bs) { fprintf(stderr, "no solver (is a HIP device visible?)\n"); return 2; }
+  if (keep && ndlqr_BatchSetFlags(bs, NDLQR_FLAG_KEEP_RECORDS) != 0) return 2;
   const size_t sA = (size_t)N * n * n, sB = (size_t)N * n * m, sn = (size_t)N * n, sm = (size_t)N * m;
   double* A = malloc(sizeof(double) * batch * sA); double* B = malloc(sizeof(double) * batch * sB);
   double* Q = malloc(sizeof(double) * batch * sn); double* R = malloc(sizeof(double) * batch * sm);

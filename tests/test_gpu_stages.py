@@ -166,7 +166,8 @@ def test_mpc_batch_example(ndlqr, tmp_path, args):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [[], ["6", "3", "32", "7", "5"], ["7", "9", "16", "3", "4"], ["20", "6", "16", "4", "3"]])
+@pytest.mark.parametrize("args", [[], ["6", "3", "32", "7", "5"], ["7", "9", "16", "3", "4"], ["20", "6", "16", "4", "3"],
+                                  ["12", "4", "64", "300", "6", "1"], ["6", "3", "32", "7", "5", "1"]])
 def test_mpc_step_example(ndlqr, tmp_path, args):
     """examples/mpc_step.c: the asynchronous MPC step in plain C -- x0 up, factor + solve, u of knot 0 down
     (ndlqr_BatchSetStepSelection), two steps in flight on pinned host memory; the program checks the KKT residual of
