@@ -1,7 +1,8 @@
 """Developer tool (GPU box): random shapes, batches, flags and call sequences against the oracle.
     python tools/fuzz_parity.py [seconds] [seed]
 Every case: full solve (twice: both buffer sets), optionally a right-hand-side re-solve / an MPC step / multiple
-right-hand sides, solutions against the oracle (bit-exact in strict mode, <= 1e-9 relative otherwise)."""
+right-hand sides, solutions against the oracle (bit-exact in strict mode, <= 1e-9 relative otherwise; on draws so
+ill-conditioned that the oracle's own KKT residual exceeds 1e-11: a KKT residual within 10x the oracle's)."""
 import os
 import sys
 import time
@@ -41,6 +42,13 @@ while time.time() < t_end:
     desc = "(%d,%d,%d)x%d flags %d tree %s seed %d" % (n, m, N, batch, flags, tree, seed)
     try:
         gens = [R.generate_synthetic(n, m, N, seed + p) for p in range(batch)]
+        fam = [(1.0, 1.0, 1.0)] * 3 + [(1.15, 1.0, 1.0), (1.0, 1e-4, 1.0), (1.3, 1e-3, 1.0), (1.0, 1.0, 1e-4)]
+        a_s, q_s, r_s = fam[rng.integers(0, len(fam))]  # (the ill-conditioned families of tests/test_gpu_parity.py)
+        if N > 64 and a_s > 1.0:
+            a_s = 1.0  # (unstable dynamics over long horizons: the oracle itself loses digits)
+        for g in gens:
+            g["A"] = g["A"] * a_s; g["Q"] = g["Q"] * q_s; g["R"] = g["R"] * r_s
+        desc += " fam (%g,%g,%g)" % (a_s, q_s, r_s)
         probs = [Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"]) for g in gens]
         flat = [np.stack([g[k] for g in gens]) for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
         bs = R.BatchSolver(n, m, N, batch, flags=flags)
@@ -55,6 +63,16 @@ while time.time() < t_end:
                     ok = np.array_equal(sol[p], ref)
                 else:
                     ok = np.linalg.norm(sol[p] - ref) / np.linalg.norm(ref) <= 1e-9
+                    if not ok:
+                        # an ill-conditioned draw (unstable dynamics, one weak input): the oracle's own solution is off
+                        # by more than the tolerance -- then the bar is the KKT residual, within 10x the oracle's (the bar
+                        # of tests/test_gpu_parity.py::test_harder_families_*)
+                        ores, obn = orc.kkt_residual(ps[p], ref)
+                        res, bn = orc.kkt_residual(ps[p], sol[p])
+                        if ores / max(1.0, obn) > 1e-11 and res / max(1.0, bn) <= 10.0 * ores / max(1.0, obn):
+                            ok = True
+                            print("note: ill-conditioned draw", desc, what, "oracle KKT %.1e, device KKT %.1e" % (
+                                ores / max(1.0, obn), res / max(1.0, bn)), flush=True)
                 if not ok:
                     fails += 1
                     print("MISMATCH", desc, what, "problem", p, bs.schedule(),
