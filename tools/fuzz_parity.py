@@ -21,7 +21,11 @@ orc = Oracle()
 INST = [(12, 4), (6, 3), (13, 4), (8, 4), (4, 2), (10, 4), (9, 3), (5, 2), (4, 1), (2, 1), (8, 16), (12, 8), (15, 2)]
 t_end = time.time() + budget
 cases = fails = 0
+t_note = time.time()
 while time.time() < t_end:
+    if time.time() - t_note > 45:
+        t_note = time.time()
+        print("progress: %d cases, %d failures" % (cases, fails), flush=True)
     kind = rng.integers(0, 10)
     if kind < 5:
         n, m = INST[rng.integers(0, len(INST))]
