@@ -81,7 +81,7 @@ struct NdlqrHipCtx {
   size_t red_bytes;
   int rowbcast;  // bottom levels of the separator-only schedule on the row-broadcast core (rb_bottom): NDLQR_ROWBCAST=1 always, 0 never (bottom_reduced_mc), unset (-1): by block size
   int tree;  // tree schedule (bottom_reduced_mc<TREE>: one launch for the whole factorisation, wavefronts climbing on arrival counters): NDLQR_TREE=1 always, 0 never, unset (-1): when all bottom wavefronts are resident at once (small batches: fewer launches win; large ones: a launch per level is faster)
-  int fuse2;  // NDLQR_FUSE2=1: tree level 2 inside the bottom launch (bottom8_reduced_mc) instead of as a launch of its own; default 0
+  int fuse2;  // tree level 2 inside the bottom launch (bottom8_reduced_mc) instead of as a launch of its own: NDLQR_FUSE2=1 always, 0 never, unset (-1): where it measured faster -- the (12,4) instance (launch_small.hpp)
   int* tree_cnt;  // arrival counters of the separators of level >= 2, [batch][N / 4]; zero between solves (reset by the root's wavefront)
   NdlqrAltSlot alt;       // the other buffer set / stream of the two-deep solve pipeline
   int pipeline;           // 1: stream-ordered solves; 2 (default, NDLQR_PIPELINE): consecutive solves alternate slots

@@ -100,10 +100,13 @@ static int launch_small(NdlqrHipCtx* c) {
             launched = true;
           }
         }
-        // NDLQR_FUSE2=1: levels 0-2 in one launch (bottom8_reduced_mc: two wavefronts per eight knots, the level-2 slot
-        // in LDS). Not the default: 12 % less HBM traffic and one launch less per step, but the level-2 work costs inside
-        // the bottom launch what it costs outside -- step 0.572 -> 0.566 ms on one box (profiles/r04_fuse2_ab.txt)
-        fuse2 = !launched && !tree && compact && !store_l && c->fuse2 > 0;
+        // Levels 0-2 in one launch (bottom8_reduced_mc: two wavefronts per eight knots, the level-2 slot in LDS): 12 % less
+        // HBM traffic and one launch less per step; the level-2 work costs inside the bottom launch about what it costs
+        // outside, so the step gains little -- and only at the (12,4) instance, where it is the default (same box,
+        // profiles/r04_fuse2_ab.txt: (12,4,256) x 1024 0.587 -> 0.579 ms, (12,4,1024) x 512 1.20 -> 1.16, the padded (11,3)
+        // 0.578 -> 0.569; (12,8) +2.5 %, (13,4) +0.9 %, (9,3) / (10,4) / (15,2) +-0). NDLQR_FUSE2=0 / 1 overrides.
+        fuse2 = !launched && !tree && compact && !store_l && d.N >= 16 &&
+                (c->fuse2 > 0 || (c->fuse2 < 0 && NX == 12 && NU == 4));
         if (fuse2) c->schedule = "reduced-fused2";
         if (launched) {
         } else if (fuse2) {

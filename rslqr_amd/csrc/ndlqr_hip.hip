@@ -114,7 +114,7 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
 
   c->tree = getenv("NDLQR_TREE") ? (atoi(getenv("NDLQR_TREE")) != 0 ? 1 : 0) : -1;  // -1: by batch size
   c->rowbcast = getenv("NDLQR_ROWBCAST") ? (atoi(getenv("NDLQR_ROWBCAST")) != 0 ? 1 : 0) : -1;  // -1: by block size
-  c->fuse2 = getenv("NDLQR_FUSE2") ? atoi(getenv("NDLQR_FUSE2")) : 0;
+  c->fuse2 = getenv("NDLQR_FUSE2") ? (atoi(getenv("NDLQR_FUSE2")) != 0 ? 1 : 0) : -1;  // -1: by instance (launch_small)
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->no_top = getenv("NDLQR_NO_TOP") != nullptr;
   c->sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS")) : 0;

@@ -473,7 +473,7 @@ HARD_FAMILIES = [(1.15, 1.0, 1.0), (1.0, 1e-4, 1.0), (1.3, 1e-3, 1.0), (1.0, 1.0
 # buckets, and the level-per-launch `reduced` schedule at a batch that selects it
 HARD_SHAPES = [(64, 16, 64, 1, "generic-reduced"), (32, 8, 128, 1, "generic-reduced"), (96, 16, 16, 1, "generic-reduced"),
                (128, 16, 8, 1, "generic-reduced"), (50, 10, 64, 1, "generic-reduced"), (7, 9, 64, 1, None),
-               (11, 3, 64, 1, None), (12, 4, 256, 40, "reduced"), (8, 4, 256, 40, "reduced"), (6, 3, 256, 48, "reduced"),
+               (11, 3, 64, 1, None), (12, 4, 256, 40, "reduced-fused2"), (8, 4, 256, 40, "reduced"), (6, 3, 256, 48, "reduced"),
                (13, 4, 128, 80, "reduced"), (12, 4, 256, 1, "reduced-tree"), (6, 3, 64, 2, "reduced-tree"),
                (4, 2, 128, 3, "knot-lean"), (5, 2, 64, 3, "knot-lean"), (2, 1, 64, 3, "knot-lean")]
 
@@ -716,7 +716,8 @@ def test_tree_schedule_fills_the_chip(ndlqr, oracle, n, m, N, batch):
 
 
 @pytest.mark.parametrize("n,m,N,batch,want", [(12, 4, 256, 8, "reduced-tree"), (6, 3, 256, 30, "reduced-tree"),
-                                              (12, 4, 128, 96, "reduced"), (64, 16, 32, 6, "generic-reduced")])
+                                              (12, 4, 128, 96, "reduced-fused2"), (10, 4, 128, 96, "reduced"),
+                                              (64, 16, 32, 6, "generic-reduced")])
 def test_repeated_solves_are_bitwise_identical(ndlqr, n, m, N, batch, want):
     """The hand-offs between wavefronts (arrival counters and write-through pushes of the tree schedule, atomic adds of
     the level launches, the two buffer sets of the pipeline) leave no room for run-to-run differences: every accumulator
@@ -1277,7 +1278,7 @@ def test_padded_shapes(ndlqr, oracle, n, m, N, batch, monkeypatch):
     bs.initialize_flat(*stack(probs))
     for _ in range(3):
         assert bs.solve() == 0
-    assert bs.schedule() in ("reduced", "reduced-tree")  # the instance's schedule, not the runtime-sized one
+    assert bs.schedule() in ("reduced", "reduced-fused2", "reduced-tree")  # the instance's schedule, not the runtime-sized one
     fast = bs.solutions()
     for p in sample:
         ref = refs[p][0][: probs[p].nvars]
@@ -1344,19 +1345,29 @@ def test_padded_shapes(ndlqr, oracle, n, m, N, batch, monkeypatch):
 
 @pytest.mark.parametrize("n,m", [(12, 4), (13, 4), (15, 2), (12, 8), (8, 16), (9, 3), (10, 4), (6, 3), (8, 4), (14, 2),
                                  (11, 3), (7, 9)])
-def test_level_per_launch_schedule_every_instance(ndlqr, oracle, n, m):
+def test_level_per_launch_schedule_every_instance(ndlqr, oracle, monkeypatch, n, m):
     """The level-per-launch separator-only schedule (compact level-0 records: the panel rides through the paired
     Cholesky pass of the matrix-core bottom kernel -- row-broadcast kernel up to 8 states --, L or S-bar^-1 in the
     record, the DPP substitution of rb_backsub, the last three levels + top-down sweep in one launch) at a batch
     that selects it, for every size-specialised instance incl. the buckets and three padded block sizes: three
     members against the oracle, every member's KKT residual on the device."""
     N, batch = 64, 160  # 160 x 16 = 2560 bottom wavefronts: beyond the tree schedule's range
+    monkeypatch.setenv("NDLQR_FUSE2", "0")  # (read when the solver is created; the (12,4) instance defaults to fused2)
     bs = ndlqr.BatchSolver(n, m, N, batch)
     bs.initialize_synthetic(31000)
     for _ in range(3):
         assert bs.solve() == 0
     assert bs.schedule() == "reduced"
     sol = bs.solutions()
+    if (n, m) in ((12, 4), (11, 3), (13, 4)):  # the default choice: level 2 inside the bottom launch at (12,4) only
+        monkeypatch.delenv("NDLQR_FUSE2")
+        bd = ndlqr.BatchSolver(n, m, N, batch)
+        bd.initialize_synthetic(31000)
+        for _ in range(2):
+            assert bd.solve() == 0
+        assert bd.schedule() == ("reduced" if n == 13 else "reduced-fused2")
+        assert np.abs(bd.solutions() - sol).max() <= 1e-9 * np.abs(sol).max()
+        bd.close()
     res, bn = bs.kkt_residuals()
     assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
     for p in (0, 77, batch - 1):

@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (csrc_sha)
 
-SLOTS = [("bottom", ("bottom_reduced_mc", "bottom_small", "rb_bottom")),
+SLOTS = [("bottom", ("bottom_reduced_mc", "bottom8_reduced_mc", "bottom_small", "rb_bottom")),
          ("upper", ("reduced_level_mc", "level_small")),
          ("top", ("reduced_top_mc",)),
          ("apply", ("backsub_small", "apply_small", "rb_backsub", "backsub_multipliers_generic", "backsub_multipliers_compact", "backsub_states_generic",
@@ -45,7 +45,7 @@ def main():
     # solves in the profiled process = launches of the once-per-solve kernel
     # (the two passes are separate processes whose untimed spin-up runs by the clock: each has its own solve count)
     def count(tab):
-        once = [c[0] for k, c in tab.items() if any(s in k for s in ("bottom_", "rb_bottom", "leaf_generic",
+        once = [c[0] for k, c in tab.items() if any(s in k for s in ("bottom_", "bottom8_", "rb_bottom", "leaf_generic",
                                                                      "backsub_states_generic", "backsub_level0_states_generic"))]
         return max(once) if once else 1
     solves, solves_w = count(fetch), count(write)
