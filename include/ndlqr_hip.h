@@ -163,7 +163,7 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* ctx, double* dst);
  * reference's KKT system (src/solver.c:122-194). batch doubles each. */
 int ndlqr_hip_kkt_residual(NdlqrHipCtx* ctx, double* res, double* bnorm);
 int ndlqr_hip_cholesky_failures(NdlqrHipCtx* ctx);
-/* Name of the launch sequence the last solve used (for reports): "reduced", "reduced-fused2" (NDLQR_FUSE2=1), "reduced-tree",
+/* Name of the launch sequence the last solve used (for reports): "reduced", "reduced-fused2" (the (12,4) instance; NDLQR_FUSE2=1/0), "reduced-tree",
  * "reduced-records", "knot-lean", "knot-strict", "knot-keep", "generic-reduced",
  * "generic-reduced-records", "generic-lean",
  * "generic-strict", "generic-keep" (DESIGN.md section 3). */

@@ -35,7 +35,7 @@ def main():
             c[0] += 1
             c[1] += float(row["Counter_Value"])
     # solves in the profiled process = launches of a once-per-solve kernel
-    once = [acc[k]["SQ_WAVES"][0] for k in acc if any(t in k for t in ("bottom_", "rb_bottom", "leaf_generic",
+    once = [acc[k]["SQ_WAVES"][0] for k in acc if any(t in k for t in ("bottom_", "bottom8_", "rb_bottom", "leaf_generic",
                                                                         "backsub_states_generic", "backsub_level0_states_generic"))]
     solves = max(once) if once else 1
     kernels = {}
