@@ -253,7 +253,8 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
                           "full_rhs: q, r, d, x0 read over the host link by the pack kernel, factor + solve, pack kernel, "
                           "solutions down; x0_only: the same with x0 alone replaced (the usual MPC iteration); "
                           "x0_only_u0: x0 up, and of the solutions only u of knot 0 down (ndlqr_BatchSetStepSelection: what "
-                          "an MPC loop applies; [batch][m] doubles)"}
+                          "an MPC loop applies; [batch][m] doubles); x0_only_u0_computed_alone: the same with "
+                          "NDLQR_SOLN_ONLY -- the step computes nothing but the eight knots around knot 0 in its last launch"}
     for name, full in (("full_rhs", True), ("x0_only", False)):
         run(4, full)
         t0 = time.perf_counter()
@@ -273,7 +274,19 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
                                 "d2h_bytes_per_step": 8 * batch * m,
                                 "equals_resident_solution": bool(np.array_equal(
                                     u0[(steps - 1) & 1][:, 0, :], sol[:, 2 * n:2 * n + m]))}
+    # ... and computes nothing else (NDLQR_SOLN_ONLY: the last launch of the back-substitution runs one workgroup per problem)
+    bs.set_step_selection(0, 1, rslqr_amd.SOLN_INPUT | rslqr_amd.SOLN_ONLY)
+    run(4, False, u0)
+    t0 = time.perf_counter()
+    run(steps, False, u0)
+    e2e = (time.perf_counter() - t0) / steps
+    end_to_end["x0_only_u0_computed_alone"] = {
+        "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 8 * batch * n,
+        "d2h_bytes_per_step": 8 * batch * m, "schedule": bs.schedule(),
+        "equals_resident_solution": bool(np.array_equal(u0[(steps - 1) & 1][:, 0, :], sol[:, 2 * n:2 * n + m]))}
     bs.set_step_selection()
+    if bs.solve() != 0:  # (the solver holds the whole solution vector again)
+        raise RuntimeError("ndlqr_SolveBatch failed")
     # the same loop with the factorisation kept (NDLQR_FLAG_KEEP_RECORDS): a step never changes A, B, Q, R, so every step
     # after the first is the right-hand-side re-solve on the compact records (stream-ordered: one step in flight)
     lti = rslqr_amd.BatchSolver(n, m, N, batch, flags=rslqr_amd.FLAG_KEEP_RECORDS)
@@ -293,6 +306,15 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         run_lti(steps)
         e2e = (time.perf_counter() - t0) / steps
         end_to_end["x0_only_u0_records_kept"] = {
+            "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 8 * batch * n,
+            "d2h_bytes_per_step": 8 * batch * m, "schedule": lti.schedule(),
+            "equals_resident_solution_to": float(np.abs(u0[(steps - 1) & 1][:, 0, :] - sol[:, 2 * n:2 * n + m]).max())}
+        lti.set_step_selection(0, 1, rslqr_amd.SOLN_INPUT | rslqr_amd.SOLN_ONLY)
+        run_lti(4)
+        t0 = time.perf_counter()
+        run_lti(steps)
+        e2e = (time.perf_counter() - t0) / steps
+        end_to_end["x0_only_u0_computed_alone_records_kept"] = {
             "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 8 * batch * n,
             "d2h_bytes_per_step": 8 * batch * m, "schedule": lti.schedule(),
             "equals_resident_solution_to": float(np.abs(u0[(steps - 1) & 1][:, 0, :] - sol[:, 2 * n:2 * n + m]).max())}

@@ -421,10 +421,19 @@ int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs);
  * NDLQR_SOLN_STATE + m for NDLQR_SOLN_INPUT. nknots = 0: back to every solution [batch][nvars] (the default; what
  * ndlqr_CopySolution hands back, src/solve.c:192-201). An MPC loop that applies u_0 asks for (0, 1, NDLQR_SOLN_INPUT):
  * 32 KB instead of 59 MB per 1024 problems of (12,4,256). ndlqr_CopyBatchSolutionSlices: the same slice of the most
- * recent solve, synchronously. */
+ * recent solve, synchronously.
+ * NDLQR_SOLN_ONLY (or-ed into `blocks`): the caller wants NOTHING but the selection, so a step may skip the part of the
+ * back-substitution that produces the other knots -- (0, 1, NDLQR_SOLN_INPUT | NDLQR_SOLN_ONLY) is the MPC step that
+ * computes u_0 alone: the forward pass over the whole horizon, the top-down sweep, and the eight knots around knot 0
+ * instead of all N (0.63 -> 0.43 ms per 1024 x (12,4,256), 0.48 -> 0.30 with NDLQR_FLAG_KEEP_RECORDS). After such a step
+ * the solver holds only that slice: ndlqr_CopyBatchSolutionSlices inside it works, everything that needs the whole
+ * vector (ndlqr_CopyBatchSolution(s), ndlqr_BatchKKTResidual, the device-side pack) returns -1 until the next solve or
+ * step without the bit. Schedules without a separate last launch (small batches on the tree schedule, blocks without
+ * a size-specialised instance) compute everything regardless. */
 #define NDLQR_SOLN_LAMBDA 1u
 #define NDLQR_SOLN_STATE 2u
 #define NDLQR_SOLN_INPUT 4u
+#define NDLQR_SOLN_ONLY 8u
 int ndlqr_BatchSetStepSelection(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks);
 int ndlqr_CopyBatchSolutionSlices(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out);
 /* Time-axis sharding: one problem (or a small batch) over G ranks, rank g on knots [g N / G, (g + 1) N / G) -- for jobs

@@ -19,6 +19,7 @@ from .api import (  # noqa: F401
     NdFactor,
     NdLqrSolver,
     SOLN_INPUT,
+    SOLN_ONLY,
     SOLN_LAMBDA,
     SOLN_STATE,
     device_count,

@@ -18,7 +18,7 @@ FLAG_GENERIC = 2
 FLAG_PROFILE = 4
 FLAG_KEEP_FACT = 8
 FLAG_KEEP_RECORDS = 16
-SOLN_LAMBDA, SOLN_STATE, SOLN_INPUT = 1, 2, 4
+SOLN_LAMBDA, SOLN_STATE, SOLN_INPUT, SOLN_ONLY = 1, 2, 4, 8
 
 ERR_INVALID = -1
 ERR_NO_DEVICE = -2
@@ -396,7 +396,9 @@ class BatchSolver:
 
     def set_step_selection(self, knot0=0, nknots=0, blocks=7):
         """ndlqr_BatchSetStepSelection: what step_async brings down -- knots [knot0, knot0 + nknots), blocks = SOLN_*
-        mask, packed [batch, nknots, width]; nknots = 0: every solution [batch, nvars] (default)."""
+        mask, packed [batch, nknots, width]; nknots = 0: every solution [batch, nvars] (default). With SOLN_ONLY in the
+        mask a step computes nothing but those knots (the rest of the solution is unavailable until the next complete
+        solve)."""
         err = self.L.ndlqr_BatchSetStepSelection(self.h, knot0, nknots, blocks)
         if err:
             raise ValueError("ndlqr_BatchSetStepSelection(%d, %d, %d): %d" % (knot0, nknots, blocks, err))

@@ -56,6 +56,7 @@ struct NdlqrAltSlot {
   bool graph_rec_complete = false;
   bool graph_rec_compact = false;
   const char* graph_schedule = "none";
+  unsigned graph_apply = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
@@ -123,7 +124,15 @@ struct NdlqrHipCtx {
   unsigned long long rhs_gen[2][4];
   // what an MPC step brings down (ndlqr_hip_set_step_selection): sel_nknots == 0: every solution, [batch][nvars]
   int sel_knot0, sel_nknots;
-  unsigned sel_blocks;
+  unsigned sel_blocks;  // NDLQR_SOLN_* bits; with NDLQR_SOLN_ONLY (8) a step computes nothing but the selected knots:
+  // the last launch of the back-substitution covers workgroups [apply_blk0, apply_blk0 + apply_nblk) of eight knots only
+  // (apply_nblk == 0: all; set by ndlqr_hip_step_async around its launches, honoured by the schedules that end in
+  // rb_backsub, part of the key of the captured launch sequence), and z_partial says that the latest solution is such a
+  // slice -- [z_blk0, z_blk0 + z_nblk) -- so that nothing else is handed out until the next complete solve
+  int apply_blk0, apply_nblk;
+  unsigned graph_apply;  // (apply_blk0 << 16 | apply_nblk) of the captured launch sequence of the current buffer set
+  bool z_partial;
+  int z_blk0, z_nblk;
   int step_set[2];   // buffer set (0 primary, 1 alternate) of the steps behind ev_step[0 / 1]
   // One-shot solve of a small batch from / into pinned host staging (ndlqr_hip_solve_staged; the drop-in ndlqr_Solve):
   // AB | QR | rhs going up, the solution blocks [batch][N][2n+m] coming down, all in the caller's block size; the whole

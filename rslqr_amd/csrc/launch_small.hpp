@@ -149,8 +149,11 @@ static int launch_small(NdlqrHipCtx* c) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)top_lds);
           hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256), top_lds, c->stream, d, c->rec, c->ytop);
         }
-        hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
-                           c->QR, c->rhs, c->rec, c->ytop, c->z);
+        // (an MPC step that asked for nothing but a knot range -- NDLQR_SOLN_ONLY -- runs the workgroups of that range)
+        ndlqr::Dims da = d;
+        if (c->apply_nblk > 0) da.xoff += c->apply_blk0;
+        hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8, d.batch),
+                           dim3(256), 0, c->stream, da, c->AB, c->QR, c->rhs, c->rec, c->ytop, c->z);
       } else {
         hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
                            c->QR, c->rhs, c->rec, c->z);
@@ -208,8 +211,10 @@ static void launch_rhs_records(NdlqrHipCtx* c) {
                            c->rhs, c->rec, (const double*)c->red, c->ytop);
       }
       ScopedSlot t(c, SLOT_APPLY);
-      hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB, c->QR,
-                         c->rhs, c->rec, c->ytop, c->z);
+      ndlqr::Dims da = d;
+      if (c->apply_nblk > 0) da.xoff += c->apply_blk0;
+      hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8, d.batch), dim3(256),
+                         0, c->stream, da, c->AB, c->QR, c->rhs, c->rec, c->ytop, c->z);
       return;
     }
   }

@@ -121,6 +121,7 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
   memset(c->rhs_latest, 0, sizeof(c->rhs_latest)); memset(c->rhs_gen, 0, sizeof(c->rhs_gen));
   c->sel_knot0 = 0; c->sel_nknots = 0; c->sel_blocks = 7u; c->step_set[0] = c->step_set[1] = 0;
+  c->apply_blk0 = c->apply_nblk = 0; c->graph_apply = 0; c->z_partial = false; c->z_blk0 = c->z_nblk = 0;
   c->h_io = nullptr; c->graph_staged = nullptr; c->graph_staged_flags = 0;
   c->graph_exec = nullptr; c->graph_flags = 0; c->graph_stream = nullptr;
   c->sep_scratch = nullptr;
@@ -198,6 +199,23 @@ void ndlqr_hip_destroy(NdlqrHipCtx* c) {
 
 // ------------------------------------------------------------------------------ two-deep solve pipeline
 
+// the current buffer set holds the most recent solution -- all of it, or (a step with NDLQR_SOLN_ONLY) the knots of the
+// workgroups its back-substitution ran
+static void note_solution(NdlqrHipCtx* c) {
+  c->z_latest = c->z;
+  c->stream_latest = c->stream;
+  c->z_partial = c->apply_nblk > 0;
+  c->z_blk0 = c->apply_blk0;
+  c->z_nblk = c->apply_nblk;
+}
+// consumers of the whole solution vector refuse a slice
+static int need_full_solution(const NdlqrHipCtx* c, const char* who) {
+  if (!c->z_partial) return NDLQR_OK;
+  g_last_error = std::string(who) + ": the last step computed only knots " + std::to_string(8 * c->z_blk0) + " .. " +
+                 std::to_string(8 * (c->z_blk0 + c->z_nblk) - 1) + " (NDLQR_SOLN_ONLY); run a solve or a step without it first";
+  return NDLQR_ERR_INVALID;
+}
+
 // exchange the context's per-solve buffers, stream, graph and events with the alternate set
 static void swap_slot(NdlqrHipCtx* c) {
   NdlqrAltSlot& a = c->alt;
@@ -207,7 +225,7 @@ static void swap_slot(NdlqrHipCtx* c) {
   std::swap(c->graph_exec, a.graph_exec); std::swap(c->graph_flags, a.graph_flags);
   std::swap(c->graph_stream, a.graph_stream); std::swap(c->graph_rec_complete, a.graph_rec_complete);
   std::swap(c->graph_rec_compact, a.graph_rec_compact);
-  std::swap(c->graph_schedule, a.graph_schedule);
+  std::swap(c->graph_schedule, a.graph_schedule); std::swap(c->graph_apply, a.graph_apply);
   std::swap(c->ev_start, a.ev_start); std::swap(c->ev_stop, a.ev_stop);
   c->in_alt = !c->in_alt;
 }
@@ -941,7 +959,8 @@ static int launch_solve(NdlqrHipCtx* c) {
   } else {
     // The sequence is a fixed chain of up to 1 + 2K short launches: capture it once as a hipGraph
     // and replay it (launch-bound single solves -- batch 1 -- gain the most).
-    const bool stale = !c->graph_exec || c->graph_flags != c->flags || c->graph_stream != c->stream;
+    const unsigned apply_key = ((unsigned)c->apply_blk0 << 16) | (unsigned)c->apply_nblk;  // (restricted back-substitution of a step)
+    const bool stale = !c->graph_exec || c->graph_flags != c->flags || c->graph_stream != c->stream || c->graph_apply != apply_key;
     if (stale) {
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       hipGraph_t graph = nullptr;
@@ -955,6 +974,7 @@ static int launch_solve(NdlqrHipCtx* c) {
       if (e != hipSuccess) { c->graph_exec = nullptr; return fail("hipGraphInstantiate", e); }
       c->graph_flags = c->flags;
       c->graph_stream = c->stream;
+      c->graph_apply = apply_key;
       c->graph_rec_complete = c->rec_complete;
       c->graph_rec_compact = c->rec_compact;  // what the captured sequence leaves behind
       c->graph_schedule = c->schedule;
@@ -966,8 +986,7 @@ static int launch_solve(NdlqrHipCtx* c) {
   }
   if (err) return err;
   HIP_TRY(hipGetLastError());
-  c->z_latest = c->z;
-  c->stream_latest = c->stream;
+  note_solution(c);
   // a complete factor array is on the device with KEEP, and on the strict runtime-sized path
   c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 || records_kept_as_factors(c) ||
                   ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
@@ -1092,8 +1111,7 @@ int ndlqr_hip_solve_staged(NdlqrHipCtx* c) {
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
-  c->z_latest = c->z;
-  c->stream_latest = c->stream;
+  note_solution(c);
   c->fact_valid = (c->flags & NDLQR_FLAG_KEEP_FACT) != 0 || records_kept_as_factors(c) ||
                   ((c->flags & NDLQR_FLAG_GENERIC) && (c->flags & NDLQR_FLAG_STRICT_FP));
   c->timing_pending = true;
@@ -1166,8 +1184,7 @@ static int time_shard_phase(NdlqrHipCtx* c, int phase, int g, int G) {
     HIP_TRY(hipMemcpyAsync(c->h_fail, c->info + c->d.batch, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
     c->timing_pending = true;
-    c->z_latest = c->z;
-    c->stream_latest = c->stream;
+    note_solution(c);
     c->fact_valid = false;
     c->rec_complete = false;
   }
@@ -1234,6 +1251,18 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
                      view[3], c->rhs);
   HIP_TRY(hipGetLastError());
   rhs_written_cur(c, written);
+  // NDLQR_SOLN_ONLY: nothing but the selected knots is wanted -- the last launch of the back-substitution runs the
+  // workgroups (eight knots each) that hold them (launch_small.hpp; schedules without that launch compute everything)
+  struct ApplyRange {
+    NdlqrHipCtx* c;
+    ApplyRange(NdlqrHipCtx* c_) : c(c_) {
+      if (c->sel_nknots > 0 && (c->sel_blocks & 8u)) {
+        c->apply_blk0 = c->sel_knot0 >> 3;
+        c->apply_nblk = ((c->sel_knot0 + c->sel_nknots - 1) >> 3) - c->apply_blk0 + 1;
+      }
+    }
+    ~ApplyRange() { c->apply_blk0 = c->apply_nblk = 0; }
+  } apply_range(c);
   // A step never changes A, B, Q, R. Under NDLQR_FLAG_KEEP_RECORDS the first step (or a solve before it) leaves the
   // compact records of the default schedule, and every further step is the right-hand-side re-solve on them (rb_forward,
   // rb_forward_top, rb_backsub: 0.46 instead of 0.59 ms per (12,4,256) x 1024) -- until new inputs are uploaded, which
@@ -1241,8 +1270,7 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   if ((c->flags & NDLQR_FLAG_KEEP_RECORDS) && !(c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT)) && c->rec_complete &&
       c->rec_compact && !c->in_alt && try_launch_rhs_records(c)) {
     HIP_TRY(hipGetLastError());
-    c->z_latest = c->z;
-    c->stream_latest = c->stream;
+    note_solution(c);
     c->schedule = "reduced-compact-records (re-solve)";
   } else {
     err = launch_solve(c);
@@ -1253,7 +1281,7 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   if (c->sel_nknots > 0) {
     const size_t width = ((c->sel_blocks & 1u) ? u.n : 0) + ((c->sel_blocks & 2u) ? u.n : 0) + ((c->sel_blocks & 4u) ? u.m : 0);
     hipLaunchKernelGGL(ndlqr::pack_selection_generic, dim3(c->sel_nknots, d.batch), dim3(64), 0, st, u, d, c->sel_knot0,
-                       c->sel_nknots, c->sel_blocks, (const double*)c->z, c->xfer);
+                       c->sel_nknots, c->sel_blocks & 7u, (const double*)c->z, c->xfer);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * width * c->sel_nknots * d.batch, hipMemcpyDeviceToHost, st));
   } else {
@@ -1297,7 +1325,7 @@ int ndlqr_hip_synchronize_previous(NdlqrHipCtx* c) {
 int ndlqr_hip_set_step_selection(NdlqrHipCtx* c, int knot0, int nknots, unsigned blocks) {
   if (!c) return NDLQR_ERR_INVALID;
   if (nknots == 0) { c->sel_knot0 = 0; c->sel_nknots = 0; c->sel_blocks = 7u; return NDLQR_OK; }
-  if (knot0 < 0 || nknots < 0 || knot0 + nknots > c->d.N || !(blocks & 7u) || (blocks & ~7u)) return NDLQR_ERR_INVALID;
+  if (knot0 < 0 || nknots < 0 || knot0 + nknots > c->d.N || !(blocks & 7u) || (blocks & ~15u)) return NDLQR_ERR_INVALID;
   c->sel_knot0 = knot0; c->sel_nknots = nknots; c->sel_blocks = blocks;
   return NDLQR_OK;
 }
@@ -1308,6 +1336,8 @@ int ndlqr_hip_download_selection(NdlqrHipCtx* c, int knot0, int nknots, unsigned
     return NDLQR_ERR_INVALID;
   const ndlqr::Dims& d = c->d;
   const ndlqr::Dims& u = c->du;
+  if (c->z_partial && (knot0 < 8 * c->z_blk0 || knot0 + nknots > 8 * (c->z_blk0 + c->z_nblk)))
+    return need_full_solution(c, "ndlqr_hip_download_selection");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
   const int xerr = ensure_xfer(c);
@@ -1430,8 +1460,7 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   c->timing_pending = true;
-  c->z_latest = c->z;
-  c->stream_latest = c->stream;
+  note_solution(c);
   return NDLQR_OK;
 }
 
@@ -1594,6 +1623,7 @@ static bool host_ptr_is_pinned(const void* p) {
 // hipMemcpy2D into pageable memory this replaces ran at 5.4 GB/s.
 int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln) {
   if (!c || !soln || p0 < 0 || count <= 0 || p0 + count > c->d.batch) return NDLQR_ERR_INVALID;
+  if (c->z_partial) return need_full_solution(c, "ndlqr_hip_download_solutions");
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
@@ -1645,6 +1675,7 @@ int ndlqr_hip_factors_valid(const NdlqrHipCtx* c) { return c && c->fact_valid ? 
 
 int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* c, double* dst) {
   if (!c || !dst) return NDLQR_ERR_INVALID;
+  if (c->z_partial) return need_full_solution(c, "ndlqr_hip_pack_solutions_device");
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   // on the stream of the latest solve: ordered behind it, asynchronous for the caller
@@ -1656,6 +1687,7 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* c, double* dst) {
 
 int ndlqr_hip_kkt_residual(NdlqrHipCtx* c, double* res, double* bnorm) {
   if (!c || !res) return NDLQR_ERR_INVALID;
+  if (c->z_partial) return need_full_solution(c, "ndlqr_hip_kkt_residual");
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   if (!c->kkt_out) HIP_TRY(hipMalloc(&c->kkt_out, sizeof(double) * 2 * (size_t)d.batch));
@@ -1674,6 +1706,7 @@ int ndlqr_hip_kkt_residual(NdlqrHipCtx* c, double* res, double* bnorm) {
 
 int ndlqr_hip_download_rhs_blocks(NdlqrHipCtx* c, int p, double* z_full) {
   if (!c || !z_full || p < 0 || p >= c->d.batch) return NDLQR_ERR_INVALID;
+  if (c->z_partial) return need_full_solution(c, "ndlqr_hip_download_rhs_blocks");
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   const size_t pitch = (size_t)d.rows * d.N;

@@ -1245,6 +1245,71 @@ def test_step_selection_and_slices(ndlqr, oracle, n, m, N, batch):
     bs.close()
 
 
+@pytest.mark.parametrize("n,m,N,batch,flags,want", [(12, 4, 64, 200, 0, "reduced-fused2"), (13, 4, 64, 160, 0, "reduced"),
+                                                     (6, 3, 64, 300, 0, "reduced"), (12, 4, 256, 40, 16, "reduced-compact-records"),
+                                                     (11, 3, 128, 80, 0, "reduced-fused2"), (12, 4, 64, 3, 0, "reduced-tree"),
+                                                     (7, 9, 16, 3, 0, None), (20, 6, 16, 4, 0, "generic-reduced")])
+def test_step_computes_selection_alone(ndlqr, oracle, n, m, N, batch, flags, want):
+    """NDLQR_SOLN_ONLY: a step whose caller wants nothing but a knot range runs the workgroups of the last launch of the
+    back-substitution that hold it (the MPC step that computes u of knot 0: one workgroup per problem instead of N / 8)
+    -- on the level-per-launch schedules, the re-solve on kept records, and, computing everything, the others. The slices
+    against the oracle with x0 replaced per step and steps in flight; afterwards the whole vector is refused until a
+    step without the bit has run (the reference hands back all of it: src/solve.c:192-201)."""
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=flags)
+    bs.initialize_synthetic(91)
+    g = [ndlqr.generate_synthetic(n, m, N, 91 + p) for p in range(batch)]
+    x0 = np.stack([gg["x0"] for gg in g])
+    zb = 2 * n + m
+    ONLY = ndlqr.SOLN_ONLY
+    cases = [(0, 1, ndlqr.SOLN_INPUT), (5, 6, ndlqr.SOLN_STATE | ndlqr.SOLN_INPUT), (N - 8, 8, 7), (N // 2 - 1, 2, 7)]
+    for k0, nk, blocks in cases:
+        bs.set_step_selection(k0, nk, blocks | ONLY)
+        xs = [ndlqr.pinned_empty(x0.shape) for _ in range(4)]
+        outs = [ndlqr.pinned_empty((batch, nk, bs.slice_width(blocks))) for _ in range(4)]
+        for s in range(4):
+            xs[s][...] = x0 * (1.0 - 0.5 * s)
+            assert bs.step_async(None, None, None, xs[s], outs[s]) == 0
+            if s >= 1:
+                assert bs.synchronize_previous() == 0
+        assert bs.synchronize() == 0
+        if want is not None and k0 == 0 and nk == 1:
+            assert bs.schedule().startswith(want), bs.schedule()
+        for s in (0, 3):
+            for p in (0, batch - 1):
+                prob = Problem(n, m, N, g[p]["A"], g[p]["B"], g[p]["Q"], g[p]["R"], g[p]["q"], g[p]["r"], g[p]["d"], xs[s][p])
+                ref = np.zeros(N * zb); ref[: prob.nvars] = oracle.solve(prob, 1)[0][: prob.nvars]
+                cols = ([*range(0, n)] if blocks & 1 else []) + ([*range(n, 2 * n)] if blocks & 2 else []) + \
+                       ([*range(2 * n, zb)] if blocks & 4 else [])
+                wantv = ref.reshape(N, zb)[k0:k0 + nk][:, cols]
+                assert np.linalg.norm(outs[s][p] - wantv) <= REL_TOL * max(1.0, np.linalg.norm(ref)), (k0, nk, s, p)
+        # the slice is what the solver holds: inside it downloads work, the whole vector and other knots are refused
+        assert np.array_equal(bs.solution_slices(k0, nk, blocks), outs[3])
+        with pytest.raises(RuntimeError):
+            bs.solutions()
+        with pytest.raises(RuntimeError):
+            bs.kkt_residuals()
+        outside = [kk for kk in range(0, N, 8) if kk + 8 <= k0 - k0 % 8 or kk > k0 + nk - 1]
+        if outside:
+            with pytest.raises(RuntimeError):
+                bs.solution_slices(outside[-1], 1, 7)
+    # a step without the bit (the same selection) leaves the whole vector again
+    bs.set_step_selection(0, 1, ndlqr.SOLN_INPUT)
+    x = ndlqr.pinned_empty(x0.shape); x[...] = x0
+    u0 = ndlqr.pinned_empty((batch, 1, m))
+    assert bs.step_async(None, None, None, x, u0) == 0 and bs.synchronize() == 0
+    full = bs.solutions()
+    res, bn = bs.kkt_residuals()
+    assert (res <= 1e-9 * np.maximum(1.0, bn)).all()
+    assert np.array_equal(u0[:, 0, :], full[:, 2 * n:zb])
+    # and a plain solve after an ONLY step as well
+    bs.set_step_selection(0, 1, ndlqr.SOLN_INPUT | ONLY)
+    assert bs.step_async(None, None, None, x, u0) == 0 and bs.synchronize() == 0
+    bs.set_step_selection()
+    assert bs.solve() == 0
+    assert np.linalg.norm(bs.solutions() - full) <= 1e-12 * np.linalg.norm(full)
+    bs.close()
+
+
 def test_large_download_through_bounce_buffers(ndlqr):
     """ndlqr_CopyBatchSolutions into pageable memory goes through two pinned 8 MB bounce buffers in chunks: a
     download larger than several chunks equals the pinned (single-copy) one and the per-problem one."""

@@ -167,11 +167,14 @@ def test_mpc_batch_example(ndlqr, tmp_path, args):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [[], ["6", "3", "32", "7", "5"], ["7", "9", "16", "3", "4"], ["20", "6", "16", "4", "3"],
-                                  ["12", "4", "64", "300", "6", "1"], ["6", "3", "32", "7", "5", "1"]])
+                                  ["12", "4", "64", "300", "6", "1"], ["6", "3", "32", "7", "5", "1"],
+                                  ["12", "4", "64", "300", "6", "0", "1"], ["12", "4", "64", "300", "6", "1", "1"],
+                                  ["6", "3", "32", "7", "5", "0", "1"], ["8", "4", "128", "100", "5", "1", "1"]])
 def test_mpc_step_example(ndlqr, tmp_path, args):
     """examples/mpc_step.c: the asynchronous MPC step in plain C -- x0 up, factor + solve, u of knot 0 down
     (ndlqr_BatchSetStepSelection), two steps in flight on pinned host memory; the program checks the KKT residual of
-    every problem on the device and the slice against the resident solution (specialised, padded and generic shapes)."""
+    every problem on the device and the slice against the resident solution (specialised, padded and generic shapes;
+    sixth argument: records kept, seventh: NDLQR_SOLN_ONLY -- the steps compute u of knot 0 alone)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "mpc_step")
