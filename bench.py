@@ -238,10 +238,11 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         q[p], r[p], d[p], x0[p] = g["q"], g["r"], g["d"], g["x0"]
     outs = [rslqr_amd.pinned_empty((batch, bs.nvars)) for _ in range(2)]
 
-    def run(k, full, dst=None):
+    def run(k, full, dst=None, x=None):
         dst = dst or outs
+        x = x0 if x is None else x
         for i in range(k):
-            err = bs.step_async(q, r, d, x0, dst[i & 1]) if full else bs.step_async(None, None, None, x0, dst[i & 1])
+            err = bs.step_async(q, r, d, x, dst[i & 1]) if full else bs.step_async(None, None, None, x, dst[i & 1])
             if err != 0:
                 raise RuntimeError("ndlqr_BatchStepAsync failed")
             if i >= 1:
@@ -254,7 +255,8 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
                           "solutions down; x0_only: the same with x0 alone replaced (the usual MPC iteration); "
                           "x0_only_u0: x0 up, and of the solutions only u of knot 0 down (ndlqr_BatchSetStepSelection: what "
                           "an MPC loop applies; [batch][m] doubles); x0_only_u0_computed_alone: the same with "
-                          "NDLQR_SOLN_ONLY -- the step computes nothing but the eight knots around knot 0 in its last launch"}
+                          "NDLQR_SOLN_ONLY -- the step computes nothing but the eight knots around knot 0 in its last launch; "
+                          "device_resident_*: x0 and u0 in device memory (ndlqr_DeviceAlloc), no transfer"}
     for name, full in (("full_rhs", True), ("x0_only", False)):
         run(4, full)
         t0 = time.perf_counter()
@@ -284,6 +286,17 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 8 * batch * n,
         "d2h_bytes_per_step": 8 * batch * m, "schedule": bs.schedule(),
         "equals_resident_solution": bool(np.array_equal(u0[(steps - 1) & 1][:, 0, :], sol[:, 2 * n:2 * n + m]))}
+    # ... with x0 and u0 in device memory (the loop around the solver lives on the GPU: nothing crosses the host link)
+    dx0 = rslqr_amd.DeviceArray((batch, n)).set(x0)
+    du0 = [rslqr_amd.DeviceArray((batch, 1, m)) for _ in range(2)]
+    run(4, False, du0, dx0)
+    t0 = time.perf_counter()
+    run(steps, False, du0, dx0)
+    e2e = (time.perf_counter() - t0) / steps
+    end_to_end["device_resident_x0_u0_computed_alone"] = {
+        "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 0, "d2h_bytes_per_step": 0,
+        "schedule": bs.schedule(),
+        "equals_resident_solution": bool(np.array_equal(du0[(steps - 1) & 1].get()[:, 0, :], sol[:, 2 * n:2 * n + m]))}
     bs.set_step_selection()
     if bs.solve() != 0:  # (the solver holds the whole solution vector again)
         raise RuntimeError("ndlqr_SolveBatch failed")

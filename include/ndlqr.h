@@ -446,6 +446,11 @@ int ndlqr_BatchTimeShardImportTop(NdLqrBatchSolver* bs, int G, const double* buf
 int ndlqr_BatchTimeShardFinish(NdLqrBatchSolver* bs, int g, int G);
 void* ndlqr_HostAlloc(size_t bytes); /* pinned host memory (NULL: no device / no memory) */
 void ndlqr_HostFree(void* p);
+/* Device memory, for loops that live on the GPU: ndlqr_BatchStepAsync takes q, r, d, x0 and soln in the solver's device
+ * memory as they are (no transfer at all; any mix with host pointers works). ndlqr_DeviceCopy: synchronous, any direction. */
+void* ndlqr_DeviceAlloc(size_t bytes);
+void ndlqr_DeviceFree(void* p);
+int ndlqr_DeviceCopy(void* dst, const void* src, size_t bytes);
 int ndlqr_BatchNumVars(const NdLqrBatchSolver* bs);
 int ndlqr_BatchSize(const NdLqrBatchSolver* bs);
 int ndlqr_CopyBatchSolution(NdLqrBatchSolver* bs, int p, double* soln);    /* nvars doubles */

@@ -116,6 +116,8 @@ int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* ctx, int nrhs, const double* q, const
  * steps). Everything is ordered on the stream of the
  * step's buffer set, so with the two-deep pipeline the copies of one step run beside the kernels of the other. Give
  * pinned host memory (ndlqr_hip_host_alloc): copies from / to pageable memory are staged by the runtime and block.
+ * Pointers into THIS device's memory are taken as they are -- the pack kernels read q, r, d, x0 and write `soln` there
+ * directly, nothing crosses the host link: the step of a loop whose states and inputs live on the GPU.
  * `soln` of a step is complete after ndlqr_hip_synchronize (every step) or, one step behind,
  * ndlqr_hip_synchronize_previous (the step before the most recent one; NDLQR_ERR_NOT_SPD when that step met a
  * non-positive pivot). */
@@ -148,6 +150,11 @@ int ndlqr_hip_time_shard_finish(NdlqrHipCtx* ctx, int g, int G);
  * rate of the host link. NULL when no device / no memory. */
 void* ndlqr_hip_host_alloc(size_t bytes);
 void ndlqr_hip_host_free(void* p);
+/* device memory of the current device / a synchronous copy between any two of host, pinned and device memory: for
+ * callers without HIP headers whose MPC loop lives on the GPU (ndlqr_hip_step_async takes device pointers) */
+void* ndlqr_hip_device_alloc(size_t bytes);
+void ndlqr_hip_device_free(void* p);
+int ndlqr_hip_copy(void* dst, const void* src, size_t bytes);
 
 /* D2H. soln: count*nvars doubles, nvars = (2n+m)N - m (src/solve.c:192-201).
  * fact: one problem, converted to the reference's NdData layout, N*K*(2n+m)*n doubles. */

@@ -7,6 +7,7 @@ C API, plus a numpy-friendly ``BatchSolver``.
 """
 from .api import (  # noqa: F401
     BatchSolver,
+    DeviceArray,
     FLAG_GENERIC,
     FLAG_KEEP_FACT,
     FLAG_KEEP_RECORDS,

@@ -236,6 +236,9 @@ def lib():
     proto("ndlqr_BatchTimeShardFinish", ci, vp, ci, ci)
     proto("ndlqr_HostAlloc", vp, C.c_size_t)
     proto("ndlqr_HostFree", None, vp)
+    proto("ndlqr_DeviceAlloc", vp, C.c_size_t)
+    proto("ndlqr_DeviceFree", None, vp)
+    proto("ndlqr_DeviceCopy", ci, vp, vp, C.c_size_t)
     proto("ndlqr_BatchSynchronize", ci, vp)
     proto("ndlqr_BatchNumVars", ci, vp)
     proto("ndlqr_BatchSize", ci, vp)
@@ -280,6 +283,35 @@ def pinned_empty(shape):
     arr = np.ctypeslib.as_array(buf)[:count].reshape(shape)
     weakref.finalize(buf, L.ndlqr_HostFree, C.c_void_p(ptr))
     return arr
+
+
+class DeviceArray:
+    """float64 values of `shape` in device memory (ndlqr_DeviceAlloc): what BatchSolver.step_async takes for q, r, d, x0
+    and soln when the loop around the solver lives on the GPU -- nothing crosses the host link then. set() / get() copy
+    from / to numpy arrays synchronously (ndlqr_DeviceCopy); `ptr` is the raw address for other device code."""
+
+    def __init__(self, shape):
+        import weakref
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.size = int(np.prod(self.shape))
+        L = lib()
+        self.ptr = L.ndlqr_DeviceAlloc(max(self.size, 1) * 8)
+        if not self.ptr:
+            raise MemoryError("ndlqr_DeviceAlloc(%d bytes) failed" % (self.size * 8))
+        weakref.finalize(self, L.ndlqr_DeviceFree, C.c_void_p(self.ptr))
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        assert arr.size == self.size
+        if lib().ndlqr_DeviceCopy(C.c_void_p(self.ptr), arr.ctypes.data_as(C.c_void_p), self.size * 8):
+            raise RuntimeError("ndlqr_DeviceCopy failed")
+        return self
+
+    def get(self):
+        out = np.empty(self.shape)
+        if lib().ndlqr_DeviceCopy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), self.size * 8):
+            raise RuntimeError("ndlqr_DeviceCopy failed")
+        return out
 
 
 def device_count():
@@ -417,15 +449,16 @@ class BatchSolver:
     def step_async(self, q, r, d, x0, soln):
         """ndlqr_BatchStepAsync: new right-hand side up, factor + solve, solutions down into `soln` ([batch, nvars], or
         the slice chosen with set_step_selection), asynchronously. Use pinned_empty() arrays (pageable ones make the
-        call block) and leave them untouched until the step has been synchronised; the solver holds references to the
+        call block) or DeviceArray objects (no transfer at all) and leave them untouched until the step has been synchronised; the solver holds references to the
         arrays of the two steps that can be in flight, so that dropping one early does not free pinned memory the GPU
         is still reading or writing."""
         n, m, N, bt = self.n, self.m, self.N, self.batch
         out_size = bt * self.nvars if self._sel is None else bt * self._sel[1] * self.slice_width(self._sel[2])
         for a, size in ((q, bt * N * n), (r, bt * N * m), (d, bt * N * n), (x0, bt * n), (soln, out_size)):
-            assert a is None or (a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.size == size)
+            assert a is None or (a.size == size if isinstance(a, DeviceArray) else
+                                 (a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.size == size))
         assert x0 is not None and soln is not None  # q, r, d may be None: unchanged
-        ptr = lambda a: None if a is None else _ptr(a)
+        ptr = lambda a: None if a is None else (C.cast(C.c_void_p(a.ptr), dp) if isinstance(a, DeviceArray) else _ptr(a))
         self._step_refs = self._step_refs[-1:] + [(q, r, d, x0, soln)]
         return self.L.ndlqr_BatchStepAsync(self.h, ptr(q), ptr(r), ptr(d), ptr(x0), ptr(soln))
 

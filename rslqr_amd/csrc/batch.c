@@ -301,6 +301,9 @@ int ndlqr_BatchTimeShardFinish(NdLqrBatchSolver* bs, int g, int G) {
 }
 void* ndlqr_HostAlloc(size_t bytes) { return ndlqr_hip_host_alloc(bytes); }
 void ndlqr_HostFree(void* p) { ndlqr_hip_host_free(p); }
+void* ndlqr_DeviceAlloc(size_t bytes) { return ndlqr_hip_device_alloc(bytes); }
+void ndlqr_DeviceFree(void* p) { ndlqr_hip_device_free(p); }
+int ndlqr_DeviceCopy(void* dst, const void* src, size_t bytes) { return ndlqr_hip_copy(dst, src, bytes); }
 
 int ndlqr_SolveBatch(NdLqrBatchSolver* bs) {
   if (!bs) return NDLQR_ERR_INVALID;

@@ -1201,11 +1201,13 @@ static int ensure_xfer(NdlqrHipCtx* c) {
   return NDLQR_OK;
 }
 
-// device-side address of `p` when it is pinned host memory (hipHostMalloc / hipHostRegister), else null
-static const double* pinned_device_view(const double* p) {
+// address under which kernels of device `device` read `p` directly: pinned host memory (hipHostMalloc / hipHostRegister)
+// through its device-side view, memory of that device as it is; else (pageable memory, another device's) null
+static const double* pinned_device_view(const double* p, int device) {
   if (!p) return nullptr;
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (a.type == hipMemoryTypeDevice) return a.device == device ? p : nullptr;
   if (a.type != hipMemoryTypeHost) return nullptr;
   void* dv = nullptr;
   if (hipHostGetDevicePointer(&dv, const_cast<double*>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -1240,9 +1242,9 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   const double* view[4];
   double* stage = c->xfer;
   for (int k = 0; k < 4; ++k) {
-    view[k] = pinned_device_view(src[k]);
+    view[k] = pinned_device_view(src[k], c->device);
     if (src[k] && !view[k]) {
-      HIP_TRY(hipMemcpyAsync(stage, src[k], sizeof(double) * cnt[k], hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(stage, src[k], sizeof(double) * cnt[k], hipMemcpyDefault, st));
       view[k] = stage;
     }
     stage += cnt[k];
@@ -1278,17 +1280,25 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   }
   // (the staging has been consumed by the pack kernel: it now takes the packed solutions -- all of them, or the slice
   //  chosen with ndlqr_hip_set_step_selection)
+  //  chosen with ndlqr_hip_set_step_selection); a `soln` in this device's memory is written by the pack kernel itself
+  double* packed = c->xfer;
+  {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, soln) == hipSuccess && a.type == hipMemoryTypeDevice && a.device == c->device) packed = soln;
+    else (void)hipGetLastError();
+  }
   if (c->sel_nknots > 0) {
     const size_t width = ((c->sel_blocks & 1u) ? u.n : 0) + ((c->sel_blocks & 2u) ? u.n : 0) + ((c->sel_blocks & 4u) ? u.m : 0);
     hipLaunchKernelGGL(ndlqr::pack_selection_generic, dim3(c->sel_nknots, d.batch), dim3(64), 0, st, u, d, c->sel_knot0,
-                       c->sel_nknots, c->sel_blocks & 7u, (const double*)c->z, c->xfer);
+                       c->sel_nknots, c->sel_blocks & 7u, (const double*)c->z, packed);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * width * c->sel_nknots * d.batch, hipMemcpyDeviceToHost, st));
+    if (packed != soln)
+      HIP_TRY(hipMemcpyAsync(soln, packed, sizeof(double) * width * c->sel_nknots * d.batch, hipMemcpyDefault, st));
   } else {
-    hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, u, d, c->z, c->xfer);
+    hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, u, d, c->z, packed);
     HIP_TRY(hipGetLastError());
     const size_t nvars = (size_t)u.rows * u.N - u.m;
-    HIP_TRY(hipMemcpyAsync(soln, c->xfer, sizeof(double) * nvars * d.batch, hipMemcpyDeviceToHost, st));
+    if (packed != soln) HIP_TRY(hipMemcpyAsync(soln, packed, sizeof(double) * nvars * d.batch, hipMemcpyDefault, st));
   }
   HIP_TRY(hipEventRecord(c->ev_stop, st));
   HIP_TRY(hipEventRecord(c->ev_step[c->step_count & 1u], st));
@@ -1361,6 +1371,24 @@ void* ndlqr_hip_host_alloc(size_t bytes) {
 }
 void ndlqr_hip_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+// device memory for callers without HIP headers of their own (the arrays a device-resident MPC loop hands to
+// ndlqr_hip_step_async), and a synchronous copy in any direction
+void* ndlqr_hip_device_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void ndlqr_hip_device_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+int ndlqr_hip_copy(void* dst, const void* src, size_t bytes) {
+  if (!dst || !src) return NDLQR_ERR_INVALID;
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+  return NDLQR_OK;
 }
 
 int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {

@@ -1310,6 +1310,48 @@ def test_step_computes_selection_alone(ndlqr, oracle, n, m, N, batch, flags, wan
     bs.close()
 
 
+@pytest.mark.parametrize("n,m,N,batch,flags", [(12, 4, 64, 200, 0), (6, 3, 32, 5, 0), (12, 4, 128, 80, 16), (7, 9, 16, 3, 0)])
+def test_step_on_device_pointers(ndlqr, oracle, n, m, N, batch, flags):
+    """ndlqr_BatchStepAsync with q, r, d, x0 and soln in the solver's device memory (ndlqr_DeviceAlloc): the pack kernels
+    read and write them where they are -- the step of a loop that lives on the GPU. Same results as the step on pinned
+    host arrays, bit for bit; whole vectors, a slice, and a mix of host and device pointers."""
+    bs = ndlqr.BatchSolver(n, m, N, batch, flags=flags)
+    bs.initialize_synthetic(57)
+    g = [ndlqr.generate_synthetic(n, m, N, 57 + p) for p in range(batch)]
+    q, r, d, x0 = (np.stack([gg[k] for gg in g]) for k in ("q", "r", "d", "x0"))
+    hq, hr, hd, hx = (ndlqr.pinned_empty(a.shape) for a in (q, r, d, x0))
+    hq[...], hr[...], hd[...], hx[...] = 0.5 * q, 2.0 * r, d, -x0
+    host_out = ndlqr.pinned_empty((batch, bs.nvars))
+    assert bs.step_async(hq, hr, hd, hx, host_out) == 0 and bs.synchronize() == 0
+    dq, dr, dd, dx = (ndlqr.DeviceArray(a.shape).set(a) for a in (hq, hr, hd, hx))
+    dev_out = ndlqr.DeviceArray((batch, bs.nvars))
+    for _ in range(2):  # (both buffer sets)
+        assert bs.step_async(dq, dr, dd, dx, dev_out) == 0
+    assert bs.synchronize() == 0
+    if flags == 0:
+        assert np.array_equal(dev_out.get(), host_out)
+    else:  # (records kept: the first step factored, the others are re-solves -- equal to rounding)
+        assert np.linalg.norm(dev_out.get() - host_out) <= 1e-12 * np.linalg.norm(host_out)
+    p = batch - 1
+    prob = Problem(n, m, N, g[p]["A"], g[p]["B"], g[p]["Q"], g[p]["R"], hq[p], hr[p], hd[p], hx[p])
+    ref = oracle.solve(prob, 1)[0][: prob.nvars]
+    assert np.linalg.norm(host_out[p] - ref) <= REL_TOL * np.linalg.norm(ref)
+    # x0 alone from the device, u of knot 0 into device memory, computed alone; then a mix: x0 on the device, slice on the host
+    hx2 = -0.25 * x0
+    dx.set(hx2)
+    bs.set_step_selection(0, 1, ndlqr.SOLN_INPUT | ndlqr.SOLN_ONLY)
+    du0 = ndlqr.DeviceArray((batch, 1, m))
+    hu0 = ndlqr.pinned_empty((batch, 1, m))
+    assert bs.step_async(None, None, None, dx, du0) == 0
+    assert bs.step_async(None, None, None, dx, hu0) == 0
+    assert bs.synchronize() == 0
+    assert np.array_equal(du0.get(), hu0)
+    prob = Problem(n, m, N, g[p]["A"], g[p]["B"], g[p]["Q"], g[p]["R"], hq[p], hr[p], hd[p], hx2[p])
+    ref = oracle.solve(prob, 1)[0][: prob.nvars]
+    assert np.linalg.norm(hu0[p, 0] - ref[2 * n:2 * n + m]) <= REL_TOL * np.linalg.norm(ref)
+    bs.close()
+
+
 def test_large_download_through_bounce_buffers(ndlqr):
     """ndlqr_CopyBatchSolutions into pageable memory goes through two pinned 8 MB bounce buffers in chunks: a
     download larger than several chunks equals the pinned (single-copy) one and the per-problem one."""
