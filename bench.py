@@ -679,9 +679,22 @@ def multi_rhs_mode(rslqr_amd, n, m, N, device, seed0, nrhs=1024):
             ref = chk.solutions()[0]
         finally:
             chk.close()
+        # u of knot 0 of every right-hand side alone (ndlqr_SolveBatchMultiRhsSlices)
+        u0 = np.empty((nrhs, 1, 1, m))
+        sel = (0, 1, rslqr_amd.SOLN_INPUT)
+        bs.solve_multi_rhs(q, r, d, x0, out=u0, selection=sel)
+        best_u0, wall_u0 = 1e9, 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            bs.solve_multi_rhs(q, r, d, x0, out=u0, selection=sel)
+            wall_u0 = min(wall_u0, (time.perf_counter() - t0) * 1e3)
+            best_u0 = min(best_u0, bs.solve_ms())
         return {"workload": "1 problem x %d right-hand sides" % nrhs, "kernel_ms": best, "solves_per_s": nrhs / best * 1e3,
                 "call_ms_incl_pageable_transfers": wall,
-                "rel_err_vs_plain_solve": float(np.linalg.norm(out[7, 0] - ref) / np.linalg.norm(ref))}
+                "rel_err_vs_plain_solve": float(np.linalg.norm(out[7, 0] - ref) / np.linalg.norm(ref)),
+                "u0_alone": {"kernel_ms": best_u0, "solves_per_s": nrhs / best_u0 * 1e3,
+                             "call_ms_incl_pageable_transfers": wall_u0,
+                             "equals_whole_vectors": bool(np.array_equal(u0[:, 0, 0, :], out[:, 0, 2 * n:2 * n + m]))}}
     finally:
         bs.close()
 

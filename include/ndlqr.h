@@ -395,6 +395,10 @@ int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs);
  * HBM. Size-specialised shapes on the level-per-launch schedule (batch x N / 4 > 2048, or NDLQR_TREE=0 in the environment). */
 int ndlqr_SolveBatchMultiRhs(NdLqrBatchSolver* bs, int nrhs, const double* q, const double* r, const double* d,
                              const double* x0, double* soln);
+/* The same for a slice of every solution -- knots [knot0, knot0 + nknots), blocks = NDLQR_SOLN_* (below) ->
+ * out [nrhs][batch][nknots][width]; only those knots are computed by the last launch and brought down. */
+int ndlqr_SolveBatchMultiRhsSlices(NdLqrBatchSolver* bs, int nrhs, const double* q, const double* r, const double* d,
+                                   const double* x0, int knot0, int nknots, unsigned blocks, double* out);
 int ndlqr_SolveBatchAsync(NdLqrBatchSolver* bs); /* enqueue on the solver's stream */
 int ndlqr_BatchSynchronize(NdLqrBatchSolver* bs);
 /* One MPC step, asynchronous: new q, r, d, x0 (flat host layout as above) up, factor + solve against the resident

@@ -104,6 +104,10 @@ double ndlqr_hip_last_solve_ms(NdlqrHipCtx* ctx); /* valid after synchronize */
  * ndlqr_hip_last_solve_ms then reports the device time of the solve kernels alone. */
 int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* ctx, int nrhs, const double* q, const double* r, const double* d,
                               const double* x0, double* soln);
+/* ... of which only knots [knot0, knot0 + nknots), blocks `blocks` (NDLQR_SOLN_*) are computed and brought down:
+ * out = [nrhs][batch][nknots][width] (u of knot 0 for a thousand sampled initial states of one model: 32 KB instead of 59 MB) */
+int ndlqr_hip_solve_multi_rhs_slices(NdlqrHipCtx* ctx, int nrhs, const double* q, const double* r, const double* d,
+                                     const double* x0, int knot0, int nknots, unsigned blocks, double* out);
 
 /* One MPC step, asynchronous: a new right-hand side up (flat host arrays in the reference's layout: q, d
  * [batch][N][n], r [batch][N][m], x0 [batch][n] -- what ndlqr_InitializeWithLQRProblem reads from the problem,

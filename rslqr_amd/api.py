@@ -224,6 +224,7 @@ def lib():
     proto("ndlqr_BatchSetRhsFlat", ci, vp, dp, dp, dp, dp)
     proto("ndlqr_SolveBatchRhsOnly", ci, vp)
     proto("ndlqr_SolveBatchMultiRhs", ci, vp, ci, dp, dp, dp, dp, dp)
+    proto("ndlqr_SolveBatchMultiRhsSlices", ci, vp, ci, dp, dp, dp, dp, ci, ci, C.c_uint, dp)
     proto("ndlqr_SolveBatchAsync", ci, vp)
     proto("ndlqr_BatchStepAsync", ci, vp, dp, dp, dp, dp, dp)
     proto("ndlqr_BatchSynchronizePrevious", ci, vp)
@@ -404,17 +405,26 @@ class BatchSolver:
         in fast mode on a size-specialised shape, on the solve)."""
         return self.L.ndlqr_SolveBatchRhsOnly(self.h)
 
-    def solve_multi_rhs(self, q, r, d, x0, out=None):
+    def solve_multi_rhs(self, q, r, d, x0, out=None, selection=None):
         """nrhs sets of right-hand sides for the whole batch against the records kept by the last solve (FLAG_KEEP_RECORDS,
         level-per-launch schedule): q, d [nrhs][batch][N][n], r [nrhs][batch][N][m], x0 [nrhs][batch][n] ->
-        solutions [nrhs][batch][nvars]. Blocking; solve_ms() afterwards = device time of the solve kernels alone."""
+        solutions [nrhs][batch][nvars], or with selection = (knot0, nknots, blocks) that slice of every solution,
+        [nrhs][batch][nknots][width] (ndlqr_SolveBatchMultiRhsSlices: nothing else is computed by the last launch).
+        Blocking; solve_ms() afterwards = device time of the solve kernels alone."""
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (q, r, d, x0)]
         nrhs = arrs[3].shape[0]
         assert arrs[0].shape == (nrhs, self.batch, self.N, self.n) and arrs[1].shape == (nrhs, self.batch, self.N, self.m)
         assert arrs[2].shape == (nrhs, self.batch, self.N, self.n) and arrs[3].shape == (nrhs, self.batch, self.n)
-        if out is None:
-            out = np.empty((nrhs, self.batch, self.nvars))
-        err = self.L.ndlqr_SolveBatchMultiRhs(self.h, nrhs, *[_ptr(a) for a in arrs], _ptr(out))
+        if selection is not None:
+            k0, nk, blocks = selection
+            if out is None:
+                out = np.empty((nrhs, self.batch, nk, self.slice_width(blocks)))
+            assert out.size == nrhs * self.batch * nk * self.slice_width(blocks)
+            err = self.L.ndlqr_SolveBatchMultiRhsSlices(self.h, nrhs, *[_ptr(a) for a in arrs], k0, nk, blocks, _ptr(out))
+        else:
+            if out is None:
+                out = np.empty((nrhs, self.batch, self.nvars))
+            err = self.L.ndlqr_SolveBatchMultiRhs(self.h, nrhs, *[_ptr(a) for a in arrs], _ptr(out))
         if err:
             raise RuntimeError("ndlqr_SolveBatchMultiRhs failed: %d (%s)" % (err, self.L.ndlqr_hip_last_error().decode()))
         return out

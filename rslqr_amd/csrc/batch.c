@@ -260,6 +260,10 @@ int ndlqr_SolveBatchRhsOnly(NdLqrBatchSolver* bs) {
   return ndlqr_hip_synchronize(bs->ctx);
 }
 
+int ndlqr_SolveBatchMultiRhsSlices(NdLqrBatchSolver* bs, int nrhs, const double* q, const double* r, const double* d,
+                                   const double* x0, int knot0, int nknots, unsigned blocks, double* out) {
+  return bs ? ndlqr_hip_solve_multi_rhs_slices(bs->ctx, nrhs, q, r, d, x0, knot0, nknots, blocks, out) : NDLQR_ERR_INVALID;
+}
 int ndlqr_SolveBatchMultiRhs(NdLqrBatchSolver* bs, int nrhs, const double* q, const double* r, const double* d,
                              const double* x0, double* soln) {
   return bs ? ndlqr_hip_solve_multi_rhs(bs->ctx, nrhs, q, r, d, x0, soln) : NDLQR_ERR_INVALID;

@@ -254,8 +254,11 @@ static bool launch_multi_rhs(NdlqrHipCtx* c, const int count, const double* rhs,
                        c->rec, fsum, d.batch, zsep);
     hipLaunchKernelGGL((ndlqr::rb_forward_top<NX, NU, true>), dim3(count), dim3(256), lds, c->stream, d, c->AB, c->QR, rhs,
                        c->rec, (const double*)fsum, ytop, d.batch, zsep);
-    hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU, true>), dim3(d.N / 8, count), dim3(256), 0, c->stream, d, c->AB, c->QR, rhs,
-                       (const double*)c->rec, (const double*)ytop, z, d.batch, (const double*)zsep);
+    ndlqr::Dims da = d;  // (a knot range alone: ndlqr_hip_solve_multi_rhs_slices)
+    if (c->apply_nblk > 0) da.xoff += c->apply_blk0;
+    hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU, true>), dim3(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8, count), dim3(256), 0,
+                       c->stream, da, c->AB, c->QR, rhs, (const double*)c->rec, (const double*)ytop, z, d.batch,
+                       (const double*)zsep);
     return true;
   } else {
     return false;

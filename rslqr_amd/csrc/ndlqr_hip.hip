@@ -1500,9 +1500,13 @@ int ndlqr_hip_solve_rhs_async(NdlqrHipCtx* c) {
 // right-hand side j of a chunk reads the inputs and records of problem j % batch (they stay in the caches when batch is
 // small: one problem x 1024 right-hand sides moves the right-hand sides and solutions and little else), its z_sep go to
 // an array of their own. Blocking; the device time of the kernels alone is what ndlqr_hip_last_solve_ms reports afterwards.
-int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* c, int nrhs, const double* q, const double* r, const double* dd,
-                              const double* x0, double* soln) {
+// nknots == 0: whole solution vectors [nrhs][batch][nvars]; else knots [knot0, knot0 + nknots), blocks of `blocks`,
+// [nrhs][batch][nknots][width] -- and only the workgroups of the last launch that hold them run (the rest of a vector is
+// never produced: nothing keeps these solutions on the device anyway)
+static int solve_multi_rhs(NdlqrHipCtx* c, int nrhs, const double* q, const double* r, const double* dd, const double* x0,
+                           int knot0, int nknots, unsigned blocks, double* soln) {
   if (!c || nrhs <= 0 || !q || !r || !dd || !x0 || !soln) return NDLQR_ERR_INVALID;
+  if (nknots < 0 || knot0 < 0 || knot0 + nknots > c->d.N || (nknots > 0 && (!(blocks & 7u) || (blocks & ~15u)))) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));
   if (c->in_alt) swap_slot(c);
@@ -1563,17 +1567,29 @@ int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* c, int nrhs, const double* q, const d
                        (const double*)(in + nq), (const double*)(in + nq + nr), (const double*)(in + 2 * nq + nr), c->multi_rhs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
-    if (!inst->multi(c, (int)count, c->multi_rhs, c->multi_zsep, c->multi_fsum, c->multi_ytop, c->multi_z)) {
+    if (nknots > 0) { c->apply_blk0 = knot0 >> 3; c->apply_nblk = ((knot0 + nknots - 1) >> 3) - c->apply_blk0 + 1; }
+    const bool launched = inst->multi(c, (int)count, c->multi_rhs, c->multi_zsep, c->multi_fsum, c->multi_ytop, c->multi_z);
+    c->apply_blk0 = c->apply_nblk = 0;
+    if (!launched) {
       g_last_error = "multiple right-hand sides: this shape / horizon has no such form";
       return NDLQR_ERR_INVALID;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
-    hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, (unsigned)count), dim3(64), 0, c->stream, uc, dc,
-                       (const double*)c->multi_z, c->multi_out);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(soln + s0 * per_set * nvars, c->multi_out, sizeof(double) * count * nvars, hipMemcpyDeviceToHost,
-                           c->stream));
+    if (nknots > 0) {
+      const size_t width = ((blocks & 1u) ? u.n : 0) + ((blocks & 2u) ? u.n : 0) + ((blocks & 4u) ? u.m : 0);
+      hipLaunchKernelGGL(ndlqr::pack_selection_generic, dim3(nknots, (unsigned)count), dim3(64), 0, c->stream, uc, dc, knot0,
+                         nknots, blocks & 7u, (const double*)c->multi_z, c->multi_out);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(soln + s0 * per_set * nknots * width, c->multi_out, sizeof(double) * count * nknots * width,
+                             hipMemcpyDeviceToHost, c->stream));
+    } else {
+      hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, (unsigned)count), dim3(64), 0, c->stream, uc, dc,
+                         (const double*)c->multi_z, c->multi_out);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(soln + s0 * per_set * nvars, c->multi_out, sizeof(double) * count * nvars, hipMemcpyDeviceToHost,
+                             c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) total_ms += ms;
@@ -1581,6 +1597,15 @@ int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* c, int nrhs, const double* q, const d
   c->last_ms = total_ms;
   c->timing_pending = false;
   return NDLQR_OK;
+}
+int ndlqr_hip_solve_multi_rhs(NdlqrHipCtx* c, int nrhs, const double* q, const double* r, const double* dd,
+                              const double* x0, double* soln) {
+  return solve_multi_rhs(c, nrhs, q, r, dd, x0, 0, 0, 7u, soln);
+}
+int ndlqr_hip_solve_multi_rhs_slices(NdlqrHipCtx* c, int nrhs, const double* q, const double* r, const double* dd,
+                                     const double* x0, int knot0, int nknots, unsigned blocks, double* out) {
+  if (nknots <= 0) return NDLQR_ERR_INVALID;
+  return solve_multi_rhs(c, nrhs, q, r, dd, x0, knot0, nknots, blocks, out);
 }
 
 int ndlqr_hip_synchronize(NdlqrHipCtx* c) {

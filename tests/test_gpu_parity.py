@@ -544,6 +544,17 @@ def test_multiple_right_hand_sides(ndlqr, oracle, n, m, N, batch, nrhs, monkeypa
         ref = oracle.solve(prob, 4)[0][: prob.nvars]
         rel = np.linalg.norm(sol[j, p] - ref) / np.linalg.norm(ref)
         assert rel <= REL_TOL, (j, p, rel)
+    # slices of every solution, computed alone (ndlqr_SolveBatchMultiRhsSlices): bit for bit those of the whole vectors
+    zb = 2 * n + m
+    padded = np.zeros((nrhs, batch, N * zb)); padded[:, :, : bs.nvars] = sol
+    Z = padded.reshape(nrhs, batch, N, zb)
+    for k0, nk, blocks in ((0, 1, ndlqr.SOLN_INPUT), (min(6, N - 4), 4, 7), (N - 1, 1, ndlqr.SOLN_LAMBDA | ndlqr.SOLN_STATE)):
+        cols = ([*range(0, n)] if blocks & 1 else []) + ([*range(n, 2 * n)] if blocks & 2 else []) + ([*range(2 * n, zb)] if blocks & 4 else [])
+        got = bs.solve_multi_rhs(q, r, d, x0, selection=(k0, nk, blocks))
+        assert got.shape == (nrhs, batch, nk, len(cols))
+        assert np.array_equal(got, Z[:, :, k0:k0 + nk, :][:, :, :, cols]), (k0, nk, blocks)
+    with pytest.raises(RuntimeError):
+        bs.solve_multi_rhs(q, r, d, x0, selection=(N - 1, 2, 7))
     # the resident problem is untouched: its own re-solve and a full solve reproduce the first solution
     assert bs.solve_rhs_only() == 0
     again = bs.solutions()
