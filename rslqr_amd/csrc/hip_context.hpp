@@ -104,6 +104,7 @@ struct NdlqrHipCtx {
   double* xfer;     // transfer staging of the current buffer set (see NdlqrAltSlot::xfer; allocated on first use)
   double* h_stage[2];  // pinned bounce buffers of the downloads into pageable host memory (allocated on first use)
   bool no_top;        // NDLQR_NO_TOP=1: the last three tree levels as launches of their own (A/B timing of reduced_top_mc)
+  int top_levels;     // tree levels inside reduced_top_mc (NDLQR_TOP_LEVELS, 3 .. 5): beyond three a wavefront takes several separators of the first ones in turn
   bool no_mfma;       // NDLQR_NO_MFMA=1: keep the scalar Schur kernel for large blocks (A/B timing)
   bool rec_complete;  // last factorisation left every separator record and factor (fast mode + KEEP / KEEP_RECORDS)
   bool rec_compact;   // ... in the compact form of the default schedule (level-0 records = L, the factors of the upper

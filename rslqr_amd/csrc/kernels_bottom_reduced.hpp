@@ -816,12 +816,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
                                                       double* __restrict__ ytop) {
   __shared__ ReducedLds<NX, NU, false> lds[4];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.x;
-  for (int l = l0; l < d.K; ++l) {
+  // (more than four separators on a level -- a launch that starts below the last three levels --: in turn; one flat
+  //  loop over (level, turn) so that the body is instantiated once)
+  for (int l = l0, s0 = 0; l < d.K;) {
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));  // (opaque per round: keeps the lane-dependent addresses of the body out of the loop's preheader)
-    if (wave < (d.N >> (l + 1)))
-      reduced_separator_mc<NX, NU, true>(d, l, wave * (2 << l), b, lane, AB, QR, rhs, red, rec, F, info, store_l,
+    const int cnt = d.N >> (l + 1);
+    if (wave + s0 < cnt)
+      reduced_separator_mc<NX, NU, true>(d, l, (wave + s0) * (2 << l), b, lane, AB, QR, rhs, red, rec, F, info, store_l,
                                          lds[wave]);
+    s0 += 4;
+    if (s0 < cnt) continue;  // (uniform: the same for every wavefront)
+    s0 = 0;
+    ++l;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pushes and record are acknowledged
     __syncthreads();
   }

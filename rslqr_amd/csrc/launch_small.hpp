@@ -124,7 +124,8 @@ static int launch_small(NdlqrHipCtx* c) {
       }
       // upper levels: one launch per level while a level has more than four separators per problem, then the
       // last three levels in one launch (reduced_top_mc; NDLQR_NO_TOP=1: a launch per level to the root)
-      const int ltop = (d.K >= 5 && !c->no_top) ? d.K - 3 : d.K;
+      const int top_levels = d.K - c->top_levels >= 3 ? c->top_levels : 3;
+      const int ltop = (d.K >= 5 && !c->no_top) ? d.K - top_levels : d.K;
       for (int l = fuse2 ? 3 : 2; l < ltop && !tree; ++l) {
         ScopedSlot t(c, SLOT_UPPER);
         hipLaunchKernelGGL((ndlqr::reduced_level_mc<NX, NU>), dim3(d.N >> (l + 1), d.batch), dim3(64), 0, c->stream,

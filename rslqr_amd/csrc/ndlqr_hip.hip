@@ -117,6 +117,8 @@ NdlqrHipCtx* ndlqr_hip_create_ex(int nstates, int ninputs, int nhorizon, int bat
   c->fuse2 = getenv("NDLQR_FUSE2") ? (atoi(getenv("NDLQR_FUSE2")) != 0 ? 1 : 0) : -1;  // -1: by instance (launch_small)
   c->no_mfma = getenv("NDLQR_NO_MFMA") != nullptr;
   c->no_top = getenv("NDLQR_NO_TOP") != nullptr;
+  c->top_levels = getenv("NDLQR_TOP_LEVELS") ? atoi(getenv("NDLQR_TOP_LEVELS")) : 3;
+  if (c->top_levels < 3 || c->top_levels > 5) c->top_levels = 3;
   c->sep_threads = getenv("NDLQR_SEP_THREADS") ? atoi(getenv("NDLQR_SEP_THREADS")) : 0;
   c->timing_pending = false; c->last_ms = 0; c->last_failures = 0; c->fact_valid = false;
   memset(c->rhs_latest, 0, sizeof(c->rhs_latest)); memset(c->rhs_gen, 0, sizeof(c->rhs_gen));
