@@ -858,13 +858,14 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
 // elimination), L and y~ from the record; y_A, y_B are final (higher levels) in the lambda rows of knots A + 1, B + 1.
 // One workgroup per separator: the rows of CA | CB are dealt to the wavefronts eight at a time (lanes along a row:
 // coalesced, sixteen loads in flight per lane), the two block substitutions run on the first wavefront.
-//   grid (N >> (l+1), batch), block 256, dynamic LDS = n (n + 1) / 2 + 2 n + 16 doubles.
+//   grid (N >> (l+1), batch), block 256, dynamic LDS = n (n + 1) / 2 + 2 n + 16 doubles. (A step that wants a knot range
+//   alone runs the separators above it: Dims::xoff = the first one's index on the level, a shorter grid.)
 static __global__ __launch_bounds__(256) void backsub_multipliers_compact(Dims d, int l, const double* __restrict__ red,
                                                                           const double* __restrict__ recs, double* z) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = d.n, nn = n * n, rows = d.rows, N = d.N, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = 2 << l, base = blockIdx.x * T, s = base + (1 << l) - 1;
+  const int T = 2 << l, base = (blockIdx.x + d.xoff) * T, s = base + (1 << l) - 1;
   const bool hasA = base > 0, hasB = base + T < N;
   double* Lp = sm;                     // L / inverses of its diagonal blocks, packed lower triangle
   double* tv = Lp + n * (n + 1) / 2;   // CA y_A + CB y_B, then the substitutions
@@ -946,7 +947,7 @@ static __global__ __launch_bounds__(256) void backsub_level0_states_generic(Dims
                                                                             double* z) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = d.n, w = d.w, N = d.N, rows = d.rows, nn = n * n;
-  const int b = blockIdx.y, s = 2 * blockIdx.x;
+  const int b = blockIdx.y, s = 2 * (blockIdx.x + d.xoff);
   const bool hasA = s > 0, hasB = s + 2 < N;
   double* Wp = sm;                      // L (the inverses of its diagonal blocks in their place), packed lower triangle
   double* yA = Wp + n * (n + 1) / 2;    // y_{s-1}, then y_{s-1} / Q_s

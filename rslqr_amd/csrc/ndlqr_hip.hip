@@ -570,13 +570,25 @@ static void launch_backsub_reduced_generic(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   ScopedSlot t(c, SLOT_APPLY);
   const size_t lds_m = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 2 * (size_t)d.n + 16);
-  for (int l = d.K - 1; l >= 1; --l)
-    hipLaunchKernelGGL(ndlqr::backsub_multipliers_compact, dim3(d.N >> (l + 1), d.batch), dim3(256), lds_m, c->stream, d, l,
+  // A step that wants knots [k0, k1] alone (NDLQR_SOLN_ONLY: apply_blk0 / apply_nblk in units of eight knots): of every
+  // level the separators whose subtree meets [k0 - 1, k1 + 2] -- a set closed under "needs the multipliers of the
+  // separators bounding its subtree" (those are ancestors: their subtrees contain it) --, of level 0 the pairs of the range
+  const bool part = c->apply_nblk > 0;
+  const int k0 = 8 * c->apply_blk0, k1 = 8 * (c->apply_blk0 + c->apply_nblk) - 1;
+  const int ka = k0 > 0 ? k0 - 1 : 0, kb = k1 + 2 < d.N ? k1 + 2 : d.N - 1;
+  for (int l = d.K - 1; l >= 1; --l) {
+    ndlqr::Dims dl = d;
+    int cnt = d.N >> (l + 1);
+    if (part) { dl.xoff = ka >> (l + 1); cnt = (kb >> (l + 1)) - dl.xoff + 1; }
+    hipLaunchKernelGGL(ndlqr::backsub_multipliers_compact, dim3(cnt, d.batch), dim3(256), lds_m, c->stream, dl, l,
                        c->red, c->rec, c->z);
+  }
   const int thr = d.n <= 16 ? 64 : (d.n <= 32 ? 128 : 256);  // (its y_s step wants n <= threads)
   const size_t lds = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 5 * (size_t)d.n + 4 * (size_t)d.w + 2 * (size_t)d.rows + thr);
-  hipLaunchKernelGGL(ndlqr::backsub_level0_states_generic, dim3(d.N >> 1, d.batch), dim3(thr), lds, c->stream, d, c->AB,
-                     c->QR, c->rhs, c->rec, c->z);
+  ndlqr::Dims d0 = d;
+  if (part) d0.xoff = k0 >> 1;
+  hipLaunchKernelGGL(ndlqr::backsub_level0_states_generic, dim3(part ? (k1 >> 1) - (k0 >> 1) + 1 : d.N >> 1, d.batch), dim3(thr),
+                     lds, c->stream, d0, c->AB, c->QR, c->rhs, c->rec, c->z);
 }
 
 static int launch_reduced_generic(NdlqrHipCtx* c, const ReducedGenericPlan& p) {
@@ -1271,11 +1283,14 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   // compact records of the default schedule, and every further step is the right-hand-side re-solve on them (rb_forward,
   // rb_forward_top, rb_backsub: 0.46 instead of 0.59 ms per (12,4,256) x 1024) -- until new inputs are uploaded, which
   // clears rec_complete. Stream-ordered on the primary buffer set like every solve with that flag.
+  // (the runtime-sized separator-only schedule likewise: 8.0 against 11.8 ms at (64,16,512) x 256. The full-record form
+  //  of the small shapes -- tree schedule -- re-solves no faster than it factors and keeps factoring.)
+  const bool generic_records = !pick_small(c);
   if ((c->flags & NDLQR_FLAG_KEEP_RECORDS) && !(c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT)) && c->rec_complete &&
-      c->rec_compact && !c->in_alt && try_launch_rhs_records(c)) {
+      (c->rec_compact || generic_records) && !c->in_alt && try_launch_rhs_records(c)) {
     HIP_TRY(hipGetLastError());
     note_solution(c);
-    c->schedule = "reduced-compact-records (re-solve)";
+    c->schedule = generic_records ? "generic-reduced-records (re-solve)" : "reduced-compact-records (re-solve)";
   } else {
     err = launch_solve(c);
     if (err) return err;

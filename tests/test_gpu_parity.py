@@ -1259,11 +1259,14 @@ def test_step_selection_and_slices(ndlqr, oracle, n, m, N, batch):
 @pytest.mark.parametrize("n,m,N,batch,flags,want", [(12, 4, 64, 200, 0, "reduced-fused2"), (13, 4, 64, 160, 0, "reduced"),
                                                      (6, 3, 64, 300, 0, "reduced"), (12, 4, 256, 40, 16, "reduced-compact-records"),
                                                      (11, 3, 128, 80, 0, "reduced-fused2"), (12, 4, 64, 3, 0, "reduced-tree"),
-                                                     (7, 9, 16, 3, 0, None), (20, 6, 16, 4, 0, "generic-reduced")])
+                                                     (7, 9, 16, 3, 0, None), (20, 6, 16, 4, 0, "generic-reduced"),
+                                                     (32, 8, 64, 6, 0, "generic-reduced"), (50, 10, 32, 3, 0, "generic-reduced"),
+                                                     (20, 6, 32, 4, 16, "generic-reduced-records")])
 def test_step_computes_selection_alone(ndlqr, oracle, n, m, N, batch, flags, want):
     """NDLQR_SOLN_ONLY: a step whose caller wants nothing but a knot range runs the workgroups of the last launch of the
     back-substitution that hold it (the MPC step that computes u of knot 0: one workgroup per problem instead of N / 8)
-    -- on the level-per-launch schedules, the re-solve on kept records, and, computing everything, the others. The slices
+    -- on the level-per-launch schedules, the re-solve on kept records, the runtime-sized separator-only schedule (of every
+    level the separators above the range) and, computing everything, the others. The slices
     against the oracle with x0 replaced per step and steps in flight; afterwards the whole vector is refused until a
     step without the bit has run (the reference hands back all of it: src/solve.c:192-201)."""
     bs = ndlqr.BatchSolver(n, m, N, batch, flags=flags)
