@@ -574,7 +574,8 @@ static void launch_backsub_reduced_generic(NdlqrHipCtx* c) {
   // level the separators whose subtree meets [k0 - 1, k1 + 2] -- a set closed under "needs the multipliers of the
   // separators bounding its subtree" (those are ancestors: their subtrees contain it) --, of level 0 the pairs of the range
   const bool part = c->apply_nblk > 0;
-  const int k0 = 8 * c->apply_blk0, k1 = 8 * (c->apply_blk0 + c->apply_nblk) - 1;
+  const int k0 = 8 * c->apply_blk0;  // (< N: the selection lies inside the horizon)
+  const int k1 = 8 * (c->apply_blk0 + c->apply_nblk) - 1 < d.N ? 8 * (c->apply_blk0 + c->apply_nblk) - 1 : d.N - 1;  // (horizons below 8 knots)
   const int ka = k0 > 0 ? k0 - 1 : 0, kb = k1 + 2 < d.N ? k1 + 2 : d.N - 1;
   for (int l = d.K - 1; l >= 1; --l) {
     ndlqr::Dims dl = d;

@@ -1261,7 +1261,8 @@ def test_step_selection_and_slices(ndlqr, oracle, n, m, N, batch):
                                                      (11, 3, 128, 80, 0, "reduced-fused2"), (12, 4, 64, 3, 0, "reduced-tree"),
                                                      (7, 9, 16, 3, 0, None), (20, 6, 16, 4, 0, "generic-reduced"),
                                                      (32, 8, 64, 6, 0, "generic-reduced"), (50, 10, 32, 3, 0, "generic-reduced"),
-                                                     (20, 6, 32, 4, 16, "generic-reduced-records")])
+                                                     (20, 6, 32, 4, 16, "generic-reduced-records"), (5, 2, 2, 5, 0, None),
+                                                     (13, 4, 4, 6, 0, None), (8, 4, 4, 3, 16, None), (36, 4, 2, 2, 0, None)])
 def test_step_computes_selection_alone(ndlqr, oracle, n, m, N, batch, flags, want):
     """NDLQR_SOLN_ONLY: a step whose caller wants nothing but a knot range runs the workgroups of the last launch of the
     back-substitution that hold it (the MPC step that computes u of knot 0: one workgroup per problem instead of N / 8)
@@ -1275,7 +1276,9 @@ def test_step_computes_selection_alone(ndlqr, oracle, n, m, N, batch, flags, wan
     x0 = np.stack([gg["x0"] for gg in g])
     zb = 2 * n + m
     ONLY = ndlqr.SOLN_ONLY
-    cases = [(0, 1, ndlqr.SOLN_INPUT), (5, 6, ndlqr.SOLN_STATE | ndlqr.SOLN_INPUT), (N - 8, 8, 7), (N // 2 - 1, 2, 7)]
+    ka = min(5, N - 1)  # (horizons below sixteen knots: the same cases, clipped)
+    cases = [(0, 1, ndlqr.SOLN_INPUT), (ka, min(6, N - ka), ndlqr.SOLN_STATE | ndlqr.SOLN_INPUT), (max(N - 8, 0), min(8, N), 7),
+             (N // 2 - 1, 2, 7)]
     for k0, nk, blocks in cases:
         bs.set_step_selection(k0, nk, blocks | ONLY)
         xs = [ndlqr.pinned_empty(x0.shape) for _ in range(4)]

@@ -106,6 +106,32 @@ while time.time() < t_end:
             assert bs.synchronize() == 0
             for s in range(3):
                 compare(outs[s], mixed, "step %d" % s)
+            if rng.integers(0, 2):
+                # a knot range computed alone (NDLQR_SOLN_ONLY), x0 from pinned or device memory, the slice into either
+                k0 = int(rng.integers(0, N)); nk = int(rng.integers(1, min(N - k0, 12) + 1))
+                blocks = int(rng.integers(1, 8))
+                bs.set_step_selection(k0, nk, blocks | R.SOLN_ONLY)
+                width = bs.slice_width(blocks)
+                xsrc = R.DeviceArray(pins[3].shape).set(pins[3]) if rng.integers(0, 2) else pins[3]
+                dsts = [R.DeviceArray((batch, nk, width)) if rng.integers(0, 2) else R.pinned_empty((batch, nk, width)) for _ in range(2)]
+                for dst in dsts:
+                    assert bs.step_async(None, None, None, xsrc, dst) == 0
+                assert bs.synchronize() == 0
+                zb = 2 * n + m
+                cols = ([*range(0, n)] if blocks & 1 else []) + ([*range(n, 2 * n)] if blocks & 2 else []) + \
+                       ([*range(2 * n, zb)] if blocks & 4 else [])
+                for dst in dsts:
+                    got = dst.get() if isinstance(dst, R.DeviceArray) else dst
+                    for pp in check:
+                        full = np.zeros(N * zb); full[: mixed[pp].nvars] = outs[2][pp]
+                        want = full.reshape(N, zb)[k0:k0 + nk][:, cols]
+                        # (against the full step of the same right-hand side: equal to rounding -- bit for bit unless the
+                        #  records are kept, where the full step was the factorisation and these are re-solves)
+                        if not np.allclose(got[pp], want, rtol=0, atol=1e-11 * max(1.0, np.abs(outs[2][pp]).max())):
+                            fails += 1
+                            print("MISMATCH", desc, "selection (%d,%d,%d) computed alone" % (k0, nk, blocks), pp, bs.schedule(),
+                                  np.abs(got[pp] - want).max(), flush=True)
+                bs.set_step_selection()
         if flags == R.FLAG_KEEP_RECORDS and bs.schedule().startswith("reduced-compact-records") and rng.integers(0, 2):
             nrhs = int(rng.integers(1, 4))
             q4 = np.stack([oflat[0]] * nrhs); r4 = np.stack([oflat[1]] * nrhs)
