@@ -432,8 +432,8 @@ int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs);
  * instead of all N (0.63 -> 0.43 ms per 1024 x (12,4,256), 0.48 -> 0.30 with NDLQR_FLAG_KEEP_RECORDS). After such a step
  * the solver holds only that slice: ndlqr_CopyBatchSolutionSlices inside it works, everything that needs the whole
  * vector (ndlqr_CopyBatchSolution(s), ndlqr_BatchKKTResidual, the device-side pack) returns -1 until the next solve or
- * step without the bit. ((64,16,512) x 256: 11.6 -> 9.4 ms, 8.0 -> 5.5 with NDLQR_FLAG_KEEP_RECORDS.) Small batches on the
- * tree schedule and the knot-based kernels (strict mode, KEEP_FACT, beyond 128 states) compute everything regardless. */
+ * step without the bit. ((64,16,512) x 256: 11.6 -> 9.4 ms, 8.0 -> 5.5 with NDLQR_FLAG_KEEP_RECORDS.) The knot-based
+ * kernels (strict mode, KEEP_FACT, beyond 128 states) compute everything regardless. */
 #define NDLQR_SOLN_LAMBDA 1u
 #define NDLQR_SOLN_STATE 2u
 #define NDLQR_SOLN_INPUT 4u

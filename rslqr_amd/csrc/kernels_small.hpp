@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void backsub_small(Dims d, const double* __res
                                                      const double* __restrict__ recs, double* __restrict__ z) {
   constexpr int W = NX + NU, ROWS = 2 * NX + NU, NN = NX * NX, REC = 2 * NN + NX, KPB = 8, MAXSLOT = 256 / NX;
   __shared__ double ys[MAXSLOT][NX];
-  const int N = d.N, K = d.K, b = blockIdx.y, first = blockIdx.x * KPB;
+  const int N = d.N, K = d.K, b = blockIdx.y, first = (blockIdx.x + d.xoff) * KPB;  // (xoff: a knot range alone, NDLQR_SOLN_ONLY)
   const int npath = K - 3, nslot = npath + 7;
   // slot -> separator: slots 0..npath-1 the path (level K-1 first), then the 7 local ones
   auto slot_sep = [&](int q, int& s, int& l) {

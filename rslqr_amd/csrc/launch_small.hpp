@@ -29,6 +29,17 @@ struct SmallPlan {
   bool needs_F;  // the schedule reads or writes the factor array
 };
 
+// An MPC step that wants nothing but a knot range (NDLQR_SOLN_ONLY): the last launch of a back-substitution whose workgroups
+// take eight knots each runs those of the range -- grid and Dims::xoff of that launch.
+static inline unsigned apply_grid(const NdlqrHipCtx* c, const ndlqr::Dims& d) {
+  return (unsigned)(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8);
+}
+static inline ndlqr::Dims apply_dims(const NdlqrHipCtx* c, const ndlqr::Dims& d) {
+  ndlqr::Dims da = d;
+  if (c->apply_nblk > 0) da.xoff += c->apply_blk0;
+  return da;
+}
+
 template <int NX, int NU, bool STRICT, bool KEEP>
 static SmallPlan plan_small(const NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
@@ -156,7 +167,7 @@ static int launch_small(NdlqrHipCtx* c) {
         hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8, d.batch),
                            dim3(256), 0, c->stream, da, c->AB, c->QR, c->rhs, c->rec, c->ytop, c->z);
       } else {
-        hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+        hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(apply_grid(c, d), d.batch), dim3(256), 0, c->stream, apply_dims(c, d), c->AB,
                            c->QR, c->rhs, c->rec, c->z);
       }
       return NDLQR_OK;
@@ -177,7 +188,7 @@ static int launch_small(NdlqrHipCtx* c) {
   ScopedSlot t(c, SLOT_APPLY);
   if (lean) {
     if constexpr (!STRICT && !KEEP)
-      hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+      hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(apply_grid(c, d), d.batch), dim3(256), 0, c->stream, apply_dims(c, d), c->AB,
                          c->QR, c->rhs, c->rec, c->z);
     return NDLQR_OK;
   }
@@ -232,7 +243,7 @@ static void launch_rhs_records(NdlqrHipCtx* c) {
   }
   {
     ScopedSlot t(c, SLOT_APPLY);
-    hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(d.N / 8, d.batch), dim3(256), 0, c->stream, d, c->AB,
+    hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(apply_grid(c, d), d.batch), dim3(256), 0, c->stream, apply_dims(c, d), c->AB,
                        c->QR, c->rhs, c->rec, c->z);
   }
 }

@@ -1262,12 +1262,14 @@ def test_step_selection_and_slices(ndlqr, oracle, n, m, N, batch):
                                                      (7, 9, 16, 3, 0, None), (20, 6, 16, 4, 0, "generic-reduced"),
                                                      (32, 8, 64, 6, 0, "generic-reduced"), (50, 10, 32, 3, 0, "generic-reduced"),
                                                      (20, 6, 32, 4, 16, "generic-reduced-records"), (5, 2, 2, 5, 0, None),
-                                                     (13, 4, 4, 6, 0, None), (8, 4, 4, 3, 16, None), (36, 4, 2, 2, 0, None)])
+                                                     (13, 4, 4, 6, 0, None), (8, 4, 4, 3, 16, None), (36, 4, 2, 2, 0, None),
+                                                     (4, 2, 64, 50, 0, "knot-lean"), (6, 3, 64, 3, 16, "reduced-tree"),
+                                                     (12, 4, 1024, 2, 0, "reduced-tree")])
 def test_step_computes_selection_alone(ndlqr, oracle, n, m, N, batch, flags, want):
     """NDLQR_SOLN_ONLY: a step whose caller wants nothing but a knot range runs the workgroups of the last launch of the
     back-substitution that hold it (the MPC step that computes u of knot 0: one workgroup per problem instead of N / 8)
     -- on the level-per-launch schedules, the re-solve on kept records, the runtime-sized separator-only schedule (of every
-    level the separators above the range) and, computing everything, the others. The slices
+    level the separators above the range) the tree and knot-lean schedules (self-contained workgroups of backsub_small) and, computing everything, the others. The slices
     against the oracle with x0 replaced per step and steps in flight; afterwards the whole vector is refused until a
     step without the bit has run (the reference hands back all of it: src/solve.c:192-201)."""
     bs = ndlqr.BatchSolver(n, m, N, batch, flags=flags)
