@@ -858,13 +858,14 @@ static __global__ __launch_bounds__(256) void rhs_reduced_generic(Dims d, int l,
 // elimination), L and y~ from the record; y_A, y_B are final (higher levels) in the lambda rows of knots A + 1, B + 1.
 // One workgroup per separator: the rows of CA | CB are dealt to the wavefronts eight at a time (lanes along a row:
 // coalesced, sixteen loads in flight per lane), the two block substitutions run on the first wavefront.
-//   grid (N >> (l+1), batch), block 256, dynamic LDS = n (n + 1) / 2 + 2 n + 16 doubles. (A step that wants a knot range
+//   grid (N >> (l+1), batch), block 64 / 128 / 256 (by block size: a workgroup of four wavefronts per 16 x 16 separator left
+//   three of them idle and the CU a quarter full), dynamic LDS = n (n + 1) / 2 + 2 n + 16 doubles. (A step that wants a knot range
 //   alone runs the separators above it: Dims::xoff = the first one's index on the level, a shorter grid.)
 static __global__ __launch_bounds__(256) void backsub_multipliers_compact(Dims d, int l, const double* __restrict__ red,
                                                                           const double* __restrict__ recs, double* z) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = d.n, nn = n * n, rows = d.rows, N = d.N, b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   const int T = 2 << l, base = (blockIdx.x + d.xoff) * T, s = base + (1 << l) - 1;
   const bool hasA = base > 0, hasB = base + T < N;
   double* Lp = sm;                     // L / inverses of its diagonal blocks, packed lower triangle
@@ -880,16 +881,16 @@ static __global__ __launch_bounds__(256) void backsub_multipliers_compact(Dims d
   double* out = z + ((size_t)b * N + s + 1) * rows;
   {  // the factor: every load in flight before the first LDS store
     const int np = n * (n + 1) / 2;
-    for (int e0 = 0; e0 < np; e0 += 8 * 256) {
+    for (int e0 = 0; e0 < np; e0 += 8 * nthr) {
       double t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; t[u] = rc[e < np ? e : np - 1]; }
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + nthr * u; t[u] = rc[e < np ? e : np - 1]; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; if (e < np) Lp[e] = t[u]; }
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + nthr * u; if (e < np) Lp[e] = t[u]; }
     }
-    if (tid < n) yt[tid] = rc[2 * (size_t)nn + tid];
+    for (int i = tid; i < n; i += nthr) yt[i] = rc[2 * (size_t)nn + i];
   }
-  for (int r0 = 8 * wave; r0 < n; r0 += 32) {
+  for (int r0 = 8 * wave; r0 < n; r0 += 8 * nwave) {
     double part[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) part[u] = 0.0;

@@ -570,6 +570,11 @@ static void launch_backsub_reduced_generic(NdlqrHipCtx* c) {
   const ndlqr::Dims& d = c->d;
   ScopedSlot t(c, SLOT_APPLY);
   const size_t lds_m = sizeof(double) * ((size_t)d.n * (d.n + 1) / 2 + 2 * (size_t)d.n + 16);
+  // (rows of CA | CB eight per wavefront. Four wavefronts per separator leave a CU a quarter full at small blocks: one up to
+  //  32 states, two up to 64, four beyond -- profiles/r04_mult_threads_ab.txt: (16,4,256) x 1024 2.30 -> 1.86 ms per solve,
+  //  (20,20) 1.32 -> 1.23, (48,16,512) 6.44 -> 6.27, (96,16) best at four; NDLQR_MULT_THREADS overrides)
+  static const int thr_env = getenv("NDLQR_MULT_THREADS") ? atoi(getenv("NDLQR_MULT_THREADS")) : 0;
+  const int thr_m = (thr_env == 64 || thr_env == 128 || thr_env == 256) ? thr_env : (d.n <= 32 ? 64 : (d.n <= 64 ? 128 : 256));
   // A step that wants knots [k0, k1] alone (NDLQR_SOLN_ONLY: apply_blk0 / apply_nblk in units of eight knots): of every
   // level the separators whose subtree meets [k0 - 1, k1 + 2] -- a set closed under "needs the multipliers of the
   // separators bounding its subtree" (those are ancestors: their subtrees contain it) --, of level 0 the pairs of the range
@@ -581,7 +586,7 @@ static void launch_backsub_reduced_generic(NdlqrHipCtx* c) {
     ndlqr::Dims dl = d;
     int cnt = d.N >> (l + 1);
     if (part) { dl.xoff = ka >> (l + 1); cnt = (kb >> (l + 1)) - dl.xoff + 1; }
-    hipLaunchKernelGGL(ndlqr::backsub_multipliers_compact, dim3(cnt, d.batch), dim3(256), lds_m, c->stream, dl, l,
+    hipLaunchKernelGGL(ndlqr::backsub_multipliers_compact, dim3(cnt, d.batch), dim3(thr_m), lds_m, c->stream, dl, l,
                        c->red, c->rec, c->z);
   }
   const int thr = d.n <= 16 ? 64 : (d.n <= 32 ? 128 : 256);  // (its y_s step wants n <= threads)
