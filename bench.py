@@ -297,7 +297,33 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 0, "d2h_bytes_per_step": 0,
         "schedule": bs.schedule(),
         "equals_resident_solution": bool(np.array_equal(du0[(steps - 1) & 1].get()[:, 0, :], sol[:, 2 * n:2 * n + m]))}
+    # ... and with the WHOLE right-hand side replaced from device memory (an outer loop -- ADMM, SQP -- that lives on the GPU)
+    dq, dr, dd = (rslqr_amd.DeviceArray(a.shape).set(a) for a in (q, r, d))
+
+    def run_dev(k, dst):
+        for i in range(k):
+            if bs.step_async(dq, dr, dd, dx0, dst[i & 1]) != 0:
+                raise RuntimeError("ndlqr_BatchStepAsync failed")
+            if i >= 1:
+                bs.synchronize_previous()
+        bs.synchronize()
+    run_dev(4, du0)
+    t0 = time.perf_counter()
+    run_dev(steps, du0)
+    e2e = (time.perf_counter() - t0) / steps
+    end_to_end["device_resident_full_rhs_u0_computed_alone"] = {
+        "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 0, "d2h_bytes_per_step": 0,
+        "equals_resident_solution": bool(np.array_equal(du0[(steps - 1) & 1].get()[:, 0, :], sol[:, 2 * n:2 * n + m]))}
     bs.set_step_selection()
+    dsol = [rslqr_amd.DeviceArray((batch, bs.nvars)) for _ in range(2)]
+    run_dev(4, dsol)
+    t0 = time.perf_counter()
+    run_dev(steps, dsol)
+    e2e = (time.perf_counter() - t0) / steps
+    end_to_end["device_resident_full_rhs"] = {
+        "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 0, "d2h_bytes_per_step": 0,
+        "equals_resident_solution": bool(np.array_equal(dsol[(steps - 1) & 1].get(), sol))}
+    del dq, dr, dd, dsol
     if bs.solve() != 0:  # (the solver holds the whole solution vector again)
         raise RuntimeError("ndlqr_SolveBatch failed")
     # the same loop with the factorisation kept (NDLQR_FLAG_KEEP_RECORDS): a step never changes A, B, Q, R, so every step
