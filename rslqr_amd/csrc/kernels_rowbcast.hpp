@@ -518,7 +518,9 @@ __global__ __launch_bounds__(256) void rb_backsub_top(Dims d, const double* __re
   backsub_top_body<NX>(d, blockIdx.x, threadIdx.x, recs, ytop, ytop_lds);
 }
 
-//   rb_backsub: grid (N / 8, batch), block 256; N >= 8.
+//   rb_backsub: grid (N / 8, batch), block 256; N >= 8. A workgroup needs nothing of its neighbours' (the two multipliers
+//   next to its subtree come from `ytop`): a step that wants a knot range alone launches the workgroups of that range
+//   (Dims::xoff = the first one, a shorter grid: NDLQR_SOLN_ONLY, launch_small.hpp).
 // Everything the workgroup needs ([A | B] of its eight knots, its seven records, weights, right-hand
 // sides: ~27 KB) arrives in ONE round of coalesced 16-byte loads and is staged in LDS; rows and columns
 // are read from there. (Row- and column-wise global loads per thread made the address units the

@@ -162,10 +162,8 @@ static int launch_small(NdlqrHipCtx* c) {
           hipLaunchKernelGGL((ndlqr::rb_backsub_top<NX>), dim3(d.batch), dim3(256), top_lds, c->stream, d, c->rec, c->ytop);
         }
         // (an MPC step that asked for nothing but a knot range -- NDLQR_SOLN_ONLY -- runs the workgroups of that range)
-        ndlqr::Dims da = d;
-        if (c->apply_nblk > 0) da.xoff += c->apply_blk0;
-        hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8, d.batch),
-                           dim3(256), 0, c->stream, da, c->AB, c->QR, c->rhs, c->rec, c->ytop, c->z);
+        hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(apply_grid(c, d), d.batch), dim3(256), 0, c->stream,
+                           apply_dims(c, d), c->AB, c->QR, c->rhs, c->rec, c->ytop, c->z);
       } else {
         hipLaunchKernelGGL((ndlqr::backsub_small<NX, NU>), dim3(apply_grid(c, d), d.batch), dim3(256), 0, c->stream, apply_dims(c, d), c->AB,
                            c->QR, c->rhs, c->rec, c->z);
@@ -223,10 +221,8 @@ static void launch_rhs_records(NdlqrHipCtx* c) {
                            c->rhs, c->rec, (const double*)c->red, c->ytop);
       }
       ScopedSlot t(c, SLOT_APPLY);
-      ndlqr::Dims da = d;
-      if (c->apply_nblk > 0) da.xoff += c->apply_blk0;
-      hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8, d.batch), dim3(256),
-                         0, c->stream, da, c->AB, c->QR, c->rhs, c->rec, c->ytop, c->z);
+      hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU>), dim3(apply_grid(c, d), d.batch), dim3(256), 0, c->stream,
+                         apply_dims(c, d), c->AB, c->QR, c->rhs, c->rec, c->ytop, c->z);
       return;
     }
   }
@@ -266,10 +262,9 @@ static bool launch_multi_rhs(NdlqrHipCtx* c, const int count, const double* rhs,
                        c->rec, fsum, d.batch, zsep);
     hipLaunchKernelGGL((ndlqr::rb_forward_top<NX, NU, true>), dim3(count), dim3(256), lds, c->stream, d, c->AB, c->QR, rhs,
                        c->rec, (const double*)fsum, ytop, d.batch, zsep);
-    ndlqr::Dims da = d;  // (a knot range alone: ndlqr_hip_solve_multi_rhs_slices)
-    if (c->apply_nblk > 0) da.xoff += c->apply_blk0;
-    hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU, true>), dim3(c->apply_nblk > 0 ? c->apply_nblk : d.N / 8, count), dim3(256), 0,
-                       c->stream, da, c->AB, c->QR, rhs, (const double*)c->rec, (const double*)ytop, z, d.batch,
+    // (a knot range alone: ndlqr_hip_solve_multi_rhs_slices)
+    hipLaunchKernelGGL((ndlqr::rb_backsub<NX, NU, true>), dim3(apply_grid(c, d), count), dim3(256), 0, c->stream,
+                       apply_dims(c, d), c->AB, c->QR, rhs, (const double*)c->rec, (const double*)ytop, z, d.batch,
                        (const double*)zsep);
     return true;
   } else {
