@@ -668,8 +668,8 @@ def test_env_variants_fast_mode(ndlqr, oracle):
                                          (11, 3, 64, 48)])
 def test_fused_bottom_launch(ndlqr, oracle, n, m, N, batch):
     """NDLQR_FUSE2=1: tree level 2 inside the bottom launch (bottom8_reduced_mc: two wavefronts per eight knots, the
-    level-2 separator's slot in LDS, its tail shared by the two wavefronts) -- an opt-in alternative of the level-per-launch
-    schedule (12 % less traffic, same kernel time). Same tolerance as the default; the weak-input-cost family too;
+    level-2 separator's slot in LDS, its tail shared by the two wavefronts) -- the default at the (12,4) instance, forced
+    here at the others (12 % less traffic, about the same kernel time). Same tolerance as the default; the weak-input-cost family too;
     horizons of 16 and 32 knots exercise the top launch starting at level 3 / the root as a level launch."""
     import subprocess, sys, json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -702,6 +702,25 @@ def test_fused_bottom_launch(ndlqr, oracle, n, m, N, batch):
             ref = oracle.solve(prob, 4)[0][: prob.nvars]
             got = np.array(out[fam]["sol"][row])
             assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= REL_TOL, (fam, p)
+
+
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 256, 40), (12, 4, 1024, 3), (6, 3, 128, 64), (13, 4, 64, 60), (12, 4, 32, 100),
+                                         (9, 3, 512, 8)])
+def test_more_levels_inside_the_top_launch(ndlqr, oracle, n, m, N, batch):
+    """NDLQR_TOP_LEVELS=4 / 5: reduced_top_mc starts one or two levels lower, a wavefront taking the eight or sixteen
+    separators of the launch's first levels in turn (a knob kept from the measurement of profiles/r04_top_levels_ab.txt).
+    Against the default (three levels) and the oracle; horizons where the request exceeds what the tree has fall back to
+    three."""
+    seed = 2600
+    base = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0"})
+    for levels in ("4", "5"):
+        got = _solve_in_subprocess(n, m, N, batch, seed, {"NDLQR_TREE": "0", "NDLQR_TOP_LEVELS": levels})
+        err = np.linalg.norm(got - base, axis=1) / np.linalg.norm(base, axis=1)
+        assert err.max() <= REL_TOL, (levels, err.max())
+        for b in (0, batch - 1):
+            prob = synth(ndlqr, n, m, N, seed + b)
+            ref = oracle.solve(prob, 8)[0][: prob.nvars]
+            assert np.linalg.norm(got[b] - ref) / np.linalg.norm(ref) <= REL_TOL, (levels, b)
 
 
 @pytest.mark.parametrize("n,m,N,batch", [(12, 4, 256, 32), (6, 3, 256, 48), (13, 4, 512, 24), (7, 9, 256, 40)])
