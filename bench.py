@@ -256,7 +256,9 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
                           "x0_only_u0: x0 up, and of the solutions only u of knot 0 down (ndlqr_BatchSetStepSelection: what "
                           "an MPC loop applies; [batch][m] doubles); x0_only_u0_computed_alone: the same with "
                           "NDLQR_SOLN_ONLY -- the step computes nothing but the eight knots around knot 0 in its last launch; "
-                          "device_resident_*: x0 and u0 in device memory (ndlqr_DeviceAlloc), no transfer"}
+                          "device_resident_*: x0 and u0 in device memory (ndlqr_DeviceAlloc), no transfer; "
+                          "device_resident_new_problem_*: A, B, Q, R, q, r, d, x0 packed from device memory every step "
+                          "(ndlqr_InitializeBatchFlatDevice + ndlqr_SolveBatchSlicesAsync)"}
     for name, full in (("full_rhs", True), ("x0_only", False)):
         run(4, full)
         t0 = time.perf_counter()
@@ -324,6 +326,28 @@ def transfer_legs(rslqr_amd, bs, n, m, N, batch, seed0, steps):
         "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 0, "d2h_bytes_per_step": 0,
         "equals_resident_solution": bool(np.array_equal(dsol[(steps - 1) & 1].get(), sol))}
     del dq, dr, dd, dsol
+    # ... and with A, B, Q, R replaced as well (a loop that re-linearises on the GPU): the pack kernel takes the eight flat
+    # arrays from device memory, ndlqr_SolveBatchSlicesAsync factors, solves and delivers u of knot 0 alone. The inputs are
+    # shared by the two buffer sets, so every iteration waits for the one before.
+    gens = [rslqr_amd.generate_synthetic(n, m, N, seed0 + p) for p in range(batch)]
+    dall = [rslqr_amd.DeviceArray((batch,) + gens[0][k].shape).set(np.stack([g[k] for g in gens]))
+            for k in ("A", "B", "Q", "R", "q", "r", "d", "x0")]
+    del gens
+
+    def run_new(k):
+        for i in range(k):
+            bs.initialize_flat_device(*[a.ptr for a in dall])
+            if bs.solve_slices_async(0, 1, rslqr_amd.SOLN_INPUT, du0[i & 1]) != 0:
+                raise RuntimeError("ndlqr_SolveBatchSlicesAsync failed")
+        bs.synchronize()
+    run_new(3)
+    t0 = time.perf_counter()
+    run_new(steps)
+    e2e = (time.perf_counter() - t0) / steps
+    end_to_end["device_resident_new_problem_u0_computed_alone"] = {
+        "ms_per_step": e2e * 1e3, "solves_per_s": batch / e2e, "h2d_bytes_per_step": 0, "d2h_bytes_per_step": 0,
+        "equals_resident_solution": bool(np.array_equal(du0[(steps - 1) & 1].get()[:, 0, :], sol[:, 2 * n:2 * n + m]))}
+    del dall
     if bs.solve() != 0:  # (the solver holds the whole solution vector again)
         raise RuntimeError("ndlqr_SolveBatch failed")
     # the same loop with the factorisation kept (NDLQR_FLAG_KEEP_RECORDS): a step never changes A, B, Q, R, so every step

@@ -439,6 +439,11 @@ int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs);
 #define NDLQR_SOLN_INPUT 4u
 #define NDLQR_SOLN_ONLY 8u
 int ndlqr_BatchSetStepSelection(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks);
+/* The same economy for a loop that replaces A, B, Q, R too (ndlqr_InitializeBatchFlat[Device] per iteration): factor +
+ * solve of the resident problems, computing and delivering knots [knot0, knot0 + nknots) alone -- out =
+ * [batch][nknots][width] in host, pinned or device memory; asynchronous like ndlqr_SolveBatchAsync (complete after
+ * ndlqr_BatchSynchronize), and like a step with NDLQR_SOLN_ONLY it leaves nothing but that slice behind. */
+int ndlqr_SolveBatchSlicesAsync(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out);
 int ndlqr_CopyBatchSolutionSlices(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out);
 /* Time-axis sharding: one problem (or a small batch) over G ranks, rank g on knots [g N / G, (g + 1) N / G) -- for jobs
  * with fewer problems than GPUs (details and limits: ndlqr_hip.h). Per solve, on every rank:

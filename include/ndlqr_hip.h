@@ -130,6 +130,8 @@ int ndlqr_hip_step_async(NdlqrHipCtx* ctx, const double* q, const double* r, con
 int ndlqr_hip_synchronize_previous(NdlqrHipCtx* ctx);
 /* What a step brings down (ndlqr.h: ndlqr_BatchSetStepSelection) / the same slice of the latest solve, synchronously. */
 int ndlqr_hip_set_step_selection(NdlqrHipCtx* ctx, int knot0, int nknots, unsigned blocks);
+/* Factor + solve of the resident problems delivering a slice alone (ndlqr.h: ndlqr_SolveBatchSlicesAsync). */
+int ndlqr_hip_solve_slices_async(NdlqrHipCtx* ctx, int knot0, int nknots, unsigned blocks, double* out);
 int ndlqr_hip_download_selection(NdlqrHipCtx* ctx, int knot0, int nknots, unsigned blocks, double* out);
 /* Time-axis sharding: ONE problem (or a small batch) solved by G ranks, each working on a chunk of
  * N / G consecutive knots of the horizon -- for jobs with fewer problems than GPUs; the batch axis stays the sharding

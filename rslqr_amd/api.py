@@ -230,6 +230,7 @@ def lib():
     proto("ndlqr_BatchSynchronizePrevious", ci, vp)
     proto("ndlqr_BatchSetStepSelection", ci, vp, ci, ci, C.c_uint)
     proto("ndlqr_CopyBatchSolutionSlices", ci, vp, ci, ci, C.c_uint, dp)
+    proto("ndlqr_SolveBatchSlicesAsync", ci, vp, ci, ci, C.c_uint, dp)
     proto("ndlqr_BatchTimeShardTopDoubles", ci, vp, ci)
     proto("ndlqr_BatchTimeShardFactor", ci, vp, ci, ci)
     proto("ndlqr_BatchTimeShardExportTop", ci, vp, ci, vp)
@@ -445,6 +446,16 @@ class BatchSolver:
         if err:
             raise ValueError("ndlqr_BatchSetStepSelection(%d, %d, %d): %d" % (knot0, nknots, blocks, err))
         self._sel = (knot0, nknots, blocks) if nknots else None
+
+    def solve_slices_async(self, knot0, nknots, blocks, out):
+        """ndlqr_SolveBatchSlicesAsync: factor + solve of the resident problems, computing and delivering knots
+        [knot0, knot0 + nknots) alone into `out` ([batch, nknots, width]: a pinned_empty array or a DeviceArray);
+        complete after synchronize()."""
+        size = self.batch * nknots * self.slice_width(blocks)
+        assert out.size == size and (isinstance(out, DeviceArray) or (out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]))
+        self._step_refs = self._step_refs[-1:] + [(out,)]
+        ptr = C.cast(C.c_void_p(out.ptr), dp) if isinstance(out, DeviceArray) else _ptr(out)
+        return self.L.ndlqr_SolveBatchSlicesAsync(self.h, knot0, nknots, blocks, ptr)
 
     def solution_slices(self, knot0, nknots, blocks, out=None):
         """ndlqr_CopyBatchSolutionSlices: [batch, nknots, width] of the latest solve."""

@@ -285,6 +285,9 @@ int ndlqr_BatchSynchronizePrevious(NdLqrBatchSolver* bs) {
 int ndlqr_BatchSetStepSelection(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks) {
   return bs ? ndlqr_hip_set_step_selection(bs->ctx, knot0, nknots, blocks) : NDLQR_ERR_INVALID;
 }
+int ndlqr_SolveBatchSlicesAsync(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out) {
+  return bs ? ndlqr_hip_solve_slices_async(bs->ctx, knot0, nknots, blocks, out) : NDLQR_ERR_INVALID;
+}
 int ndlqr_CopyBatchSolutionSlices(NdLqrBatchSolver* bs, int knot0, int nknots, unsigned blocks, double* out) {
   return bs ? ndlqr_hip_download_selection(bs->ctx, knot0, nknots, blocks, out) : NDLQR_ERR_INVALID;
 }

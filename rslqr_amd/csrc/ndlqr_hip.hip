@@ -210,6 +210,13 @@ static void note_solution(NdlqrHipCtx* c) {
   c->z_blk0 = c->apply_blk0;
   c->z_nblk = c->apply_nblk;
 }
+// Everything is idle (the caller has just waited for both streams) and the current buffer set has received a new right-hand
+// side: let the next pipelined solve start on THIS set instead of the other one, whose copy of the right-hand side would
+// have to be brought up to date first (copy_rhs_parts_generic: 62 us per 1024 x (12,4,256) in a loop that replaces the
+// problem every iteration).
+static void next_solve_on_current_set(NdlqrHipCtx* c) {
+  if (((c->solve_count & 1u) != 0) != c->in_alt) ++c->solve_count;
+}
 // consumers of the whole solution vector refuse a slice
 static int need_full_solution(const NdlqrHipCtx* c, const char* who) {
   if (!c->z_partial) return NDLQR_OK;
@@ -440,6 +447,7 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     rhs_written_cur(c, 0xFu);
+    next_solve_on_current_set(c);
     c->fact_valid = false;
     c->rec_complete = false;
     return NDLQR_OK;
@@ -450,6 +458,7 @@ int ndlqr_hip_upload_inputs(NdlqrHipCtx* c, int p0, int count, const double* AB,
   HIP_TRY(hipMemcpyAsync(c->rhs + p0 * sz, rhs, sizeof(double) * sz * count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host staging buffers are reused by the caller
   rhs_written_cur(c, 0xFu);
+  next_solve_on_current_set(c);
   c->fact_valid = false;  // new A, B, Q, R: a cached factorisation no longer matches the inputs
   c->rec_complete = false;
   return NDLQR_OK;
@@ -461,10 +470,14 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   if (!c || !A || !B || !Q || !R || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
+  // (330 us per 1024 x (12,4,256): 1 GB at 3 TB/s. Taking A_k | B_k through LDS -- whole lines in, transposed out -- made it
+  //  378, eight knots per workgroup changed nothing: left as it is; a loop that cannot afford it writes the device layout
+  //  itself, ndlqr_hip_device_pointers)
   hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q, R,
                      q, r, d, x0, c->AB, c->QR, c->rhs);
   HIP_TRY(hipGetLastError());
   rhs_written_cur(c, 0xFu);        // (the whole batch: nothing of the older copies is needed any more)
+  next_solve_on_current_set(c);
   HIP_TRY(other_stream_waits(c));  // the next solve may run on the other buffer set's stream
   c->fact_valid = false;  // new A, B, Q, R: neither a cached factor array nor cached records match
   c->rec_complete = false;
@@ -1332,6 +1345,45 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   return NDLQR_OK;
 }
 
+// Factor + solve of the resident problems, of which knots [knot0, knot0 + nknots) -- blocks `blocks` -- are computed by the
+// last launch and written to `out` ([batch][nknots][width]; host, pinned or this device's memory), asynchronously: the
+// solve of a loop that replaces A, B, Q, R as well (ndlqr_hip_pack_flat_device / uploads) and consumes u of knot 0.
+// Consecutive calls alternate between the buffer sets like ndlqr_hip_solve_async; complete after ndlqr_hip_synchronize.
+int ndlqr_hip_solve_slices_async(NdlqrHipCtx* c, int knot0, int nknots, unsigned blocks, double* out) {
+  if (!c || !out || knot0 < 0 || nknots <= 0 || knot0 + nknots > c->d.N || !(blocks & 7u) || (blocks & ~15u))
+    return NDLQR_ERR_INVALID;
+  const ndlqr::Dims& d = c->d;
+  const ndlqr::Dims& u = c->du;
+  int err = prepare_solve(c, nullptr);
+  if (err) return err;
+  err = ensure_xfer(c);
+  if (err) return err;
+  err = rhs_make_current(c, 0xFu);
+  if (err) return err;
+  hipStream_t st = c->stream;
+  HIP_TRY(hipEventRecord(c->ev_start, st));
+  c->apply_blk0 = knot0 >> 3;
+  c->apply_nblk = ((knot0 + nknots - 1) >> 3) - c->apply_blk0 + 1;
+  err = launch_solve(c);
+  c->apply_blk0 = c->apply_nblk = 0;
+  if (err) return err;
+  double* packed = c->xfer;
+  {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, out) == hipSuccess && a.type == hipMemoryTypeDevice && a.device == c->device) packed = out;
+    else (void)hipGetLastError();
+  }
+  const size_t width = ((blocks & 1u) ? u.n : 0) + ((blocks & 2u) ? u.n : 0) + ((blocks & 4u) ? u.m : 0);
+  hipLaunchKernelGGL(ndlqr::pack_selection_generic, dim3(nknots, d.batch), dim3(64), 0, st, u, d, knot0, nknots, blocks & 7u,
+                     (const double*)c->z, packed);
+  HIP_TRY(hipGetLastError());
+  if (packed != out) HIP_TRY(hipMemcpyAsync(out, packed, sizeof(double) * width * nknots * d.batch, hipMemcpyDefault, st));
+  HIP_TRY(hipEventRecord(c->ev_stop, st));
+  c->timing_pending = true;
+  c->state_dirty = false;
+  return NDLQR_OK;
+}
+
 // the step before the most recent one is complete (its `soln` may be read) -- whichever stream it ran on
 int ndlqr_hip_synchronize_previous(NdlqrHipCtx* c) {
   if (!c) return NDLQR_ERR_INVALID;
@@ -1437,6 +1489,7 @@ int ndlqr_hip_upload_rhs(NdlqrHipCtx* c, int p0, int count, const double* rhs) {
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   rhs_written_cur(c, 0xFu);
+  next_solve_on_current_set(c);
   return NDLQR_OK;
 }
 

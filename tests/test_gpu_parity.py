@@ -1390,6 +1390,46 @@ def test_step_on_device_pointers(ndlqr, oracle, n, m, N, batch, flags):
     bs.close()
 
 
+@pytest.mark.parametrize("n,m,N,batch", [(12, 4, 64, 200), (13, 4, 64, 160), (6, 3, 32, 5), (20, 6, 32, 4), (7, 9, 16, 3)])
+def test_solve_delivering_a_slice_alone(ndlqr, oracle, n, m, N, batch):
+    """ndlqr_SolveBatchSlicesAsync: factor + solve computing and delivering a knot range alone -- the solve of a loop that
+    replaces A, B, Q, R every iteration (here: device-side packing of new problems from device memory, ndlqr_DeviceAlloc)
+    and consumes u of knot 0. Slices against the oracle and bit for bit against a plain solve; two calls in flight; the
+    whole vector is refused afterwards and back after a plain solve."""
+    bs = ndlqr.BatchSolver(n, m, N, batch)
+    zb = 2 * n + m
+    keys = ("A", "B", "Q", "R", "q", "r", "d", "x0")
+    for it, (k0, nk, blocks) in enumerate([(0, 1, ndlqr.SOLN_INPUT), (3, 7, ndlqr.SOLN_STATE | ndlqr.SOLN_INPUT), (N - 2, 2, 7)]):
+        gens = [ndlqr.generate_synthetic(n, m, N, 700 + 50 * it + p) for p in range(batch)]
+        flat = [np.stack([g[k] for g in gens]) for k in keys]
+        dev = [ndlqr.DeviceArray(a.shape).set(a) for a in flat]
+        bs.initialize_flat_device(*[a.ptr for a in dev])
+        width = bs.slice_width(blocks)
+        outs = [ndlqr.DeviceArray((batch, nk, width)), ndlqr.pinned_empty((batch, nk, width))]
+        for o in outs:  # (two in flight: one per buffer set)
+            assert bs.solve_slices_async(k0, nk, blocks, o) == 0
+        assert bs.synchronize() == 0
+        got = outs[1]
+        assert np.array_equal(outs[0].get(), got)
+        with pytest.raises(RuntimeError):
+            bs.solutions()
+        assert np.array_equal(bs.solution_slices(k0, nk, blocks), got)
+        assert bs.solve() == 0
+        full = bs.solutions()
+        cols = ([*range(0, n)] if blocks & 1 else []) + ([*range(n, 2 * n)] if blocks & 2 else []) + ([*range(2 * n, zb)] if blocks & 4 else [])
+        padded = np.zeros((batch, N * zb)); padded[:, : bs.nvars] = full
+        assert np.array_equal(got, padded.reshape(batch, N, zb)[:, k0:k0 + nk, :][:, :, cols]), (k0, nk, blocks)
+        for p in (0, batch - 1):
+            g = gens[p]
+            prob = Problem(n, m, N, g["A"], g["B"], g["Q"], g["R"], g["q"], g["r"], g["d"], g["x0"])
+            ref = oracle.solve(prob, 1)[0][: prob.nvars]
+            assert np.linalg.norm(full[p] - ref) <= REL_TOL * np.linalg.norm(ref)
+    with pytest.raises(AssertionError):
+        bs.solve_slices_async(0, 2, 7, ndlqr.pinned_empty((batch, 1, zb)))
+    assert bs.L.ndlqr_SolveBatchSlicesAsync(bs.h, N - 1, 2, 7, None) != 0
+    bs.close()
+
+
 def test_large_download_through_bounce_buffers(ndlqr):
     """ndlqr_CopyBatchSolutions into pageable memory goes through two pinned 8 MB bounce buffers in chunks: a
     download larger than several chunks equals the pinned (single-copy) one and the per-problem one."""
