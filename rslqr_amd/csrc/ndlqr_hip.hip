@@ -470,11 +470,12 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   if (!c || !A || !B || !Q || !R || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
-  // (330 us per 1024 x (12,4,256): 1 GB at 3 TB/s. Taking A_k | B_k through LDS -- whole lines in, transposed out -- made it
-  //  378, eight knots per workgroup changed nothing: left as it is; a loop that cannot afford it writes the device layout
-  //  itself, ndlqr_hip_device_pointers)
-  hipLaunchKernelGGL(ndlqr::pack_flat_generic, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q, R,
-                     q, r, d, x0, c->AB, c->QR, c->rhs);
+  if (c->d.N % 8 == 0)
+    hipLaunchKernelGGL(ndlqr::pack_flat_generic<8>, dim3(c->d.N / 8, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q,
+                       R, q, r, d, x0, c->AB, c->QR, c->rhs);
+  else
+    hipLaunchKernelGGL(ndlqr::pack_flat_generic<1>, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q, R,
+                       q, r, d, x0, c->AB, c->QR, c->rhs);
   HIP_TRY(hipGetLastError());
   rhs_written_cur(c, 0xFu);        // (the whole batch: nothing of the older copies is needed any more)
   next_solve_on_current_set(c);
