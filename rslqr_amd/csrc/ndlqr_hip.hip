@@ -1332,7 +1332,7 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
     if (packed != soln)
       HIP_TRY(hipMemcpyAsync(soln, packed, sizeof(double) * width * c->sel_nknots * d.batch, hipMemcpyDefault, st));
   } else {
-    hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0, st, u, d, c->z, packed);
+    hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(ndlqr::pack_solutions_chunks(u), d.batch), dim3(256), 0, st, u, d, c->z, packed);
     HIP_TRY(hipGetLastError());
     const size_t nvars = (size_t)u.rows * u.N - u.m;
     if (packed != soln) HIP_TRY(hipMemcpyAsync(soln, packed, sizeof(double) * nvars * d.batch, hipMemcpyDefault, st));
@@ -1661,7 +1661,7 @@ static int solve_multi_rhs(NdlqrHipCtx* c, int nrhs, const double* q, const doub
       HIP_TRY(hipMemcpyAsync(soln + s0 * per_set * nknots * width, c->multi_out, sizeof(double) * count * nknots * width,
                              hipMemcpyDeviceToHost, c->stream));
     } else {
-      hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, (unsigned)count), dim3(64), 0, c->stream, uc, dc,
+      hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(ndlqr::pack_solutions_chunks(uc), (unsigned)count), dim3(256), 0, c->stream, uc, dc,
                          (const double*)c->multi_z, c->multi_out);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(soln + s0 * per_set * nvars, c->multi_out, sizeof(double) * count * nvars, hipMemcpyDeviceToHost,
@@ -1762,7 +1762,7 @@ int ndlqr_hip_download_solutions(NdlqrHipCtx* c, int p0, int count, double* soln
   const double* zl = c->z_latest ? c->z_latest : c->z;
   const size_t nvars = (size_t)c->du.rows * d.N - c->du.m, pitch = (size_t)d.rows * d.N;
   hipStream_t st = c->stream;
-  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, count), dim3(64), 0, st, c->du, d, zl + p0 * pitch, c->xfer);
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(ndlqr::pack_solutions_chunks(c->du), count), dim3(256), 0, st, c->du, d, zl + p0 * pitch, c->xfer);
   HIP_TRY(hipGetLastError());
   const size_t total = nvars * count;
   if (host_ptr_is_pinned(soln)) {
@@ -1809,7 +1809,7 @@ int ndlqr_hip_pack_solutions_device(NdlqrHipCtx* c, double* dst) {
   const ndlqr::Dims& d = c->d;
   HIP_TRY(hipSetDevice(c->device));
   // on the stream of the latest solve: ordered behind it, asynchronous for the caller
-  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(d.N, d.batch), dim3(64), 0,
+  hipLaunchKernelGGL(ndlqr::pack_solutions_generic, dim3(ndlqr::pack_solutions_chunks(c->du), d.batch), dim3(256), 0,
                      c->stream_latest ? c->stream_latest : c->stream, c->du, d, c->z_latest ? c->z_latest : c->z, dst);
   HIP_TRY(hipGetLastError());
   return NDLQR_OK;
