@@ -470,7 +470,9 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   if (!c || !A || !B || !Q || !R || !q || !r || !d || !x0) return NDLQR_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(sync_all(c));  // solves in flight on either slot still read the inputs
-  if (c->d.N % 8 == 0)
+  // (eight knots per workgroup while a thread's eight loads -- the same entry of eight consecutive blocks -- stay within what
+  //  the caches hold together: at (64,16) the strided reads of eight 40 KB blocks at once took 9.5 instead of 5 ms)
+  if (c->d.N % 8 == 0 && c->du.n <= 16)
     hipLaunchKernelGGL(ndlqr::pack_flat_generic<8>, dim3(c->d.N / 8, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q,
                        R, q, r, d, x0, c->AB, c->QR, c->rhs);
   else
