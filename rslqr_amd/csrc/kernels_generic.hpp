@@ -370,6 +370,46 @@ static __global__ void pack_flat_generic(Dims du, Dims d, const double* __restri
   }
 }
 
+// The same for larger blocks, one knot per workgroup of 256 threads: the column-major A_k | B_k come in as they lie (whole
+// lines) and leave row-major through LDS -- column j of [A | B] at pack_tile[P j ..], pitch P = n | 1 (odd: the transposed
+// reads of a wavefront, stride P doubles, fall into distinct banks). The direct form reads with a stride of n doubles
+// between lanes: at (64,16) every lane a line of its own, 2.3 TB/s. grid (N, batch), dynamic LDS P (n + m) doubles.
+static __global__ __launch_bounds__(256) void pack_flat_tiled(Dims du, Dims d, const double* __restrict__ A,
+                                                              const double* __restrict__ B, const double* __restrict__ Q,
+                                                              const double* __restrict__ R, const double* __restrict__ q,
+                                                              const double* __restrict__ r, const double* __restrict__ dd,
+                                                              const double* __restrict__ x0, double* __restrict__ AB,
+                                                              double* __restrict__ QR, double* __restrict__ rhs) {
+  extern __shared__ __attribute__((aligned(16))) double pack_tile[];
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int n = du.n, m = du.m, N = du.N, P = n | 1;
+  const size_t pk = (size_t)b * N + k;
+  const double* Ak = A + pk * n * n;
+  const double* Bk = B + pk * n * m;
+  for (int e = threadIdx.x; e < n * du.w; e += blockDim.x) {  // (B_k follows A_k's columns: column j of [A | B] = entries n j ..)
+    const int j = e / n, i = e - j * n;
+    pack_tile[i + P * j] = j < n ? Ak[e] : Bk[e - n * n];
+  }
+  // the vectors meanwhile (independent of the tile)
+  double* qr = QR + pk * d.w;
+  for (int e = threadIdx.x; e < du.w; e += blockDim.x)
+    qr[e < n ? e : d.n + (e - n)] = e < n ? Q[pk * n + e] : R[pk * m + (e - n)];
+  double* z = rhs + pk * d.rows;
+  for (int e = threadIdx.x; e < du.rows; e += blockDim.x) {
+    double v;
+    if (e < n) v = k == 0 ? -x0[(size_t)b * n + e] : -dd[(pk - 1) * n + e];
+    else if (e < 2 * n) v = -q[pk * n + (e - n)];
+    else v = k < N - 1 ? -r[pk * m + (e - 2 * n)] : 0.0;
+    z[e < n ? e : (e < 2 * n ? d.n + (e - n) : 2 * d.n + (e - 2 * n))] = v;
+  }
+  __syncthreads();
+  double* ab = AB + pk * d.n * d.w;
+  for (int e = threadIdx.x; e < n * du.w; e += blockDim.x) {
+    const int i = e / du.w, j = e - i * du.w;
+    ab[i * d.w + (j < n ? j : d.n + (j - n))] = pack_tile[i + P * j];
+  }
+}
+
 // Padded shapes: everything of the device inputs that is not a real entry, once, at context creation: zero
 // couplings, unit weights (dummy states / inputs with Q = R = 1), zero right-hand side -- the dummies solve to exactly
 // zero, S-bar gains a unit diagonal block, nothing else changes. grid (N, batch).

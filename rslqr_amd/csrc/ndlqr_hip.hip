@@ -475,6 +475,9 @@ int ndlqr_hip_pack_flat_device(NdlqrHipCtx* c, const double* A, const double* B,
   if (c->d.N % 8 == 0 && c->du.n <= 16)
     hipLaunchKernelGGL(ndlqr::pack_flat_generic<8>, dim3(c->d.N / 8, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q,
                        R, q, r, d, x0, c->AB, c->QR, c->rhs);
+  else if (c->du.n > 16 && sizeof(double) * (size_t)(c->du.n | 1) * c->du.w <= 64 * 1024)  // through LDS, whole lines in and out
+    hipLaunchKernelGGL(ndlqr::pack_flat_tiled, dim3(c->d.N, c->d.batch), dim3(256), sizeof(double) * (size_t)(c->du.n | 1) * c->du.w,
+                       c->stream, c->du, c->d, A, B, Q, R, q, r, d, x0, c->AB, c->QR, c->rhs);
   else
     hipLaunchKernelGGL(ndlqr::pack_flat_generic<1>, dim3(c->d.N, c->d.batch), dim3(128), 0, c->stream, c->du, c->d, A, B, Q, R,
                        q, r, d, x0, c->AB, c->QR, c->rhs);
