@@ -1391,7 +1391,7 @@ def test_step_on_device_pointers(ndlqr, oracle, n, m, N, batch, flags):
 
 
 @pytest.mark.parametrize("n,m,N,batch", [(12, 4, 64, 200), (13, 4, 64, 160), (6, 3, 32, 5), (20, 6, 32, 4), (7, 9, 16, 3),
-                                         (21, 5, 16, 3), (33, 7, 8, 2), (64, 16, 16, 2)])
+                                         (21, 5, 16, 3), (33, 7, 16, 2), (64, 16, 16, 2)])
 def test_solve_delivering_a_slice_alone(ndlqr, oracle, n, m, N, batch):
     """ndlqr_SolveBatchSlicesAsync: factor + solve computing and delivering a knot range alone -- the solve of a loop that
     replaces A, B, Q, R every iteration (here: device-side packing of new problems from device memory, ndlqr_DeviceAlloc)
