@@ -81,8 +81,13 @@ def _worker(rank, world, port, per_rank, n, m, N, outdir):
 
 def test_two_rank_sharding_matches_single_process(tmp_path):
     world, per_rank, n, m, N = 2, 3, 6, 3, 16
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, per_rank, n, m, N, str(tmp_path)), nprocs=world, join=True)
+    for attempt in range(2):  # (the port is free when it is picked, not necessarily when rank 0 binds it: one retry)
+        try:
+            mp.spawn(_worker, args=(world, _free_port(), per_rank, n, m, N, str(tmp_path)), nprocs=world, join=True)
+            break
+        except Exception:  # noqa: BLE001
+            if attempt:
+                raise
     allsol = np.load(tmp_path / "all.npy")
     assert allsol.shape[0] == world * per_rank
     single = _solve_shard(0, 1, world * per_rank, n, m, N)  # global problems 0..5, seeds 1..6
