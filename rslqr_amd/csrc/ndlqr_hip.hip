@@ -1308,9 +1308,11 @@ int ndlqr_hip_step_async(NdlqrHipCtx* c, const double* q, const double* r, const
   // compact records of the default schedule, and every further step is the right-hand-side re-solve on them (rb_forward,
   // rb_forward_top, rb_backsub: 0.46 instead of 0.59 ms per (12,4,256) x 1024) -- until new inputs are uploaded, which
   // clears rec_complete. Stream-ordered on the primary buffer set like every solve with that flag.
-  // (the runtime-sized separator-only schedule likewise: 8.0 against 11.8 ms at (64,16,512) x 256. The full-record form
-  //  of the small shapes -- tree schedule -- re-solves no faster than it factors and keeps factoring.)
-  const bool generic_records = !pick_small(c);
+  // (the runtime-sized separator-only schedule likewise where its re-solve is the faster one -- beyond 32 states: 8.0
+  //  against 11.5 ms at (64,16,512) x 256, 4.8 against 6.4 at (48,16,512) x 256; at (32,8) the two are equal and at
+  //  (16,4,256) x 1024 the re-solve takes 2.8 ms against 1.9 for factor + solve, profiles/r04_mpc_steps.txt. The
+  //  full-record form of the small shapes -- tree schedule -- re-solves no faster than it factors and keeps factoring.)
+  const bool generic_records = !pick_small(c) && c->d.n > 32;
   if ((c->flags & NDLQR_FLAG_KEEP_RECORDS) && !(c->flags & (NDLQR_FLAG_STRICT_FP | NDLQR_FLAG_KEEP_FACT)) && c->rec_complete &&
       (c->rec_compact || generic_records) && !c->in_alt && try_launch_rhs_records(c)) {
     HIP_TRY(hipGetLastError());

@@ -1280,7 +1280,8 @@ def test_step_selection_and_slices(ndlqr, oracle, n, m, N, batch):
                                                      (11, 3, 128, 80, 0, "reduced-fused2"), (12, 4, 64, 3, 0, "reduced-tree"),
                                                      (7, 9, 16, 3, 0, None), (20, 6, 16, 4, 0, "generic-reduced"),
                                                      (32, 8, 64, 6, 0, "generic-reduced"), (50, 10, 32, 3, 0, "generic-reduced"),
-                                                     (20, 6, 32, 4, 16, "generic-reduced-records"), (5, 2, 2, 5, 0, None),
+                                                     (20, 6, 32, 4, 16, "generic-reduced-records"), (48, 16, 16, 2, 16, "generic-reduced-records (re-solve)"),
+                                                     (5, 2, 2, 5, 0, None),
                                                      (13, 4, 4, 6, 0, None), (8, 4, 4, 3, 16, None), (36, 4, 2, 2, 0, None),
                                                      (4, 2, 64, 50, 0, "knot-lean"), (6, 3, 64, 3, 16, "reduced-tree"),
                                                      (12, 4, 1024, 2, 0, "reduced-tree")])
